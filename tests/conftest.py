@@ -1,0 +1,39 @@
+"""pytest configuration: the ``gpu`` marker and shared fixtures.
+
+``-m "not gpu"`` : oracle vs golden vectors, host logic, C-ABI symbol export (no compute calls).
+``-m gpu``       : parity tests proper - the HIP path through the C-ABI vs oracle / golden vectors.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (valeoai/PAFUSE, /root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  Nothing of the
+reference is copied: it is imported through three shims
+
+  1. stub ``timm`` modules (only DropPath is used, and only in training),
+  2. a SimpleNamespace config tree instead of hydra/omegaconf and a tiny dataset object exposing the
+     part-index tables of common/h3wb_dataset.py:49-61,198-213,
+  3. ``model.device = 'cpu'`` plus a no-op ``Tensor.cuda`` (common/diffusionpose.py:71,288).
+
+Usage:  python tests/golden/make_golden.py            (re-writes every fixture, deterministic)
+
+Real-width fixtures do not store the 35 M weights: they are re-generated from a seed by
+``golden_util.seeded_state_dict`` and a SHA-256 of the result is stored, so the GPU box can prove it
+re-generated identical tensors.
+"""
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("PAFUSE_REFERENCE", "/root/reference")
+
+from tests.golden import golden_util as gu  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------- shims
+def install_shims():
+    class DropPath(torch.nn.Module):          # identity in eval; never exercised in train mode here
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            assert not self.training or self.p == 0.0
+            return x
+
+    def _mk(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    _mk("timm")
+    _mk("timm.data", IMAGENET_DEFAULT_MEAN=(0, 0, 0), IMAGENET_DEFAULT_STD=(1, 1, 1))
+    _mk("timm.models")
+    _mk("timm.models.helpers", load_pretrained=lambda *a, **k: None)
+    _mk("timm.models.layers", DropPath=DropPath, to_2tuple=lambda x: (x, x), trunc_normal_=lambda *a, **k: None)
+    _mk("timm.models.registry", register_model=lambda f: f)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+
+
+def make_args():
+    return SimpleNamespace(
+        general=SimpleNamespace(part_based_model=True),
+        data=SimpleNamespace(num_kps=134, merge_hands=True),
+        model=SimpleNamespace(number_of_frames=27, test_time_augmentation=True, diff_model="MixSTE2",
+                              input_size=5, dep=8, cs=288),
+        ft2d=SimpleNamespace(timestep=1000, scale=1.0),
+    )
+
+
+class FakeDataset:
+    """What D3DP / the pose utilities read from Human3WBDataset (common/diffusionpose.py:73-75)."""
+
+    def __init__(self):
+        self.metadata = {}
+        self.root_indices = dict(gu.ROOT_INDICES)
+        self.parts_joint_indices = {k: list(v) for k, v in gu.DATASET_PART_JOINTS.items()}
+        self.parts_connection_indices = dict(gu.CONNECTION_INDICES)
+
+
+def build_reference_d3dp(P, T, flip=True):
+    from common.diffusionpose import D3DP
+    args = make_args()
+    args.model.test_time_augmentation = flip
+    m = D3DP(args, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, FakeDataset(), is_train=False,
+             num_proposals=P, sampling_timesteps=T)
+    m.device = "cpu"
+    m.eval()
+    return m
+
+
+class NoiseTape:
+    """Patch torch.randn / randn_like so the reference consumes a prepared list of noise tensors."""
+
+    def __init__(self, noises):
+        self.noises = list(noises)
+        self.k = 0
+
+    def __enter__(self):
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+
+        def take(*a, **k):
+            out = self.noises[self.k]
+            self.k += 1
+            return out.clone()
+
+        torch.randn = take
+        torch.randn_like = take
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# -------------------------------------------------------------------------------------------------- G1
+def g1_tiny_mixste():
+    """tiny MixSTE2 (F=3, J=5, C=16, depth 2): full state dict + inputs + output."""
+    from common.mixste import MixSTE2
+    torch.manual_seed(11)
+    m = MixSTE2(num_frame=3, num_joints=5, in_chans=5, embed_dim_ratio=16, depth=2, num_heads=8,
+                mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_path_rate=0.0, is_train=False).eval()
+    with torch.no_grad():
+        m.Spatial_pos_embed.normal_(0, 0.2)
+        m.Temporal_pos_embed.normal_(0, 0.2)
+        for k, p in m.named_parameters():        # make LayerNorm affine parameters non-trivial
+            if "norm" in k or k.startswith("head.0"):
+                p.add_(torch.randn_like(p) * 0.1)
+    g = torch.Generator().manual_seed(12)
+    x2d = torch.rand(2, 3, 5, 2, generator=g) * 2 - 1
+    x3d = torch.randn(2, 4, 3, 5, 3, generator=g)
+    t = torch.tensor([999, 3])
+    with torch.no_grad():
+        out = m(x2d, x3d, t)
+    arrays = {"sd." + k: v for k, v in m.state_dict().items()}
+    save("g1_tiny_mixste.npz", x2d=x2d, x3d=x3d, t=t, out=out, **arrays)
+
+
+# -------------------------------------------------------------------------------------------------- G2
+def g2_schedule():
+    m = build_reference_d3dp(1, 1)
+    arrays = {"buf." + k: v for k, v in m.state_dict().items() if not k.startswith("pose_estimator")}
+    for T in (1, 2, 5, 10, 20, 50):
+        times = torch.linspace(-1, 999, steps=T + 1)
+        times = list(reversed(times.int().tolist()))
+        pairs = list(zip(times[:-1], times[1:]))
+        arrays[f"pairs.{T}"] = np.asarray(pairs, dtype=np.int64)
+        coefs = []
+        for time, time_next in pairs:
+            if time_next < 0:
+                continue
+            alpha = m.alphas_cumprod[time]
+            alpha_next = m.alphas_cumprod[time_next]
+            sigma = 1.0 * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            c = (1 - alpha_next - sigma ** 2).sqrt()
+            coefs.append([alpha_next.sqrt().item(), c.item(), sigma.item()])
+        arrays[f"coefs.{T}"] = np.asarray(coefs, dtype=np.float64).reshape(-1, 3)
+    save("g2_schedule.npz", **arrays)
+
+
+# -------------------------------------------------------------------------------------------------- G3
+def g3_time_mlp():
+    """sinusoid + time_mlp at the three real widths; weights re-generated by key (SHA-256 stored)."""
+    from common.mixste import MixSTE2
+    arrays = {}
+    ts = torch.tensor([999, 899, 799, 699, 599, 499, 399, 299, 199, 99, 0])
+    for part, C in gu.PART_WIDTH.items():
+        m = MixSTE2(num_frame=2, num_joints=2, in_chans=5, embed_dim_ratio=C, depth=1, num_heads=8,
+                    drop_path_rate=0.0, is_train=False).eval()
+        sd = gu.seeded_like(m.time_mlp.state_dict(), seed=31, prefix=f"g3.{part}.time_mlp.")
+        m.time_mlp.load_state_dict(sd)
+        arrays[f"{part}.sha"] = np.frombuffer(gu.sha256_of(sd), dtype=np.uint8)
+        with torch.no_grad():
+            arrays[f"{part}.sin"] = m.time_mlp[0](ts)
+            arrays[f"{part}.out"] = m.time_mlp(ts)
+    save("g3_time_mlp.npz", t=ts, **arrays)
+
+
+# -------------------------------------------------------------------------------------------------- G4
+def g4_blocks():
+    """one real-width Block per part on a few spatial and temporal sequences; weights re-generated by key."""
+    from common.mixste import Block
+    from functools import partial
+    arrays = {}
+    for part, C in gu.PART_WIDTH.items():
+        J = len(gu.PART_JOINTS[part])
+        blk = Block(dim=C, num_heads=8, mlp_ratio=2.0, qkv_bias=True, qk_scale=None,
+                    norm_layer=partial(torch.nn.LayerNorm, eps=1e-6)).eval()
+        sd = gu.seeded_like(blk.state_dict(), seed=41, prefix=f"g4.{part}.")
+        blk.load_state_dict(sd)
+        arrays[f"{part}.sha"] = np.frombuffer(gu.sha256_of(sd), dtype=np.uint8)
+        g = torch.Generator().manual_seed(42)
+        xs = torch.randn(3, J, C, generator=g)
+        xt = torch.randn(4, 27, C, generator=g)
+        with torch.no_grad():
+            arrays[f"{part}.xs"], arrays[f"{part}.ys"] = xs, blk(xs)
+            arrays[f"{part}.xt"], arrays[f"{part}.yt"] = xt, blk(xt)
+    save("g4_blocks.npz", **arrays)
+
+
+# -------------------------------------------------------------------------------------------------- G5
+def g5_d3dp_loops():
+    """full D3DP at real dims: flip P=2,T=2 (every x_start) and no-flip P=1,T=1; one per-part MixSTE2 pass."""
+    arrays = {}
+    m = build_reference_d3dp(2, 2, flip=True)
+    sd = gu.seeded_state_dict(m.state_dict(), seed=51)
+    m.load_state_dict(sd)
+    arrays["sha"] = np.frombuffer(gu.sha256_of(sd), dtype=np.uint8)
+    x2d, x2d_flip = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=2, n=2, seed=1)
+    with NoiseTape(noises) as tape, torch.no_grad():
+        out = m(x2d, None, input_2d_flip=x2d_flip)
+        assert tape.k == 2
+    arrays.update(flip_x2d=x2d, flip_x2d_flip=x2d_flip, flip_out=out)
+
+    # a single denoiser pass per part at a mid-schedule timestep (x_3d of plausible scale)
+    g = torch.Generator().manual_seed(52)
+    x3d = torch.randn(1, 2, 27, 134, 3, generator=g).clamp(-1.1, 1.1)
+    t = torch.tensor([499])
+    with torch.no_grad():
+        for part, idx in m.parts_joint_indices.items():
+            arrays[f"part.{part}"] = m.pose_estimator[part](x2d[..., idx, :], x3d[..., idx, :], t)
+    arrays["part_x3d"] = x3d
+
+    m1 = build_reference_d3dp(1, 1, flip=False)
+    m1.load_state_dict(sd)
+    noises1 = gu.synthetic_noises(B=1, P=1, n=1, seed=2)
+    with NoiseTape(noises1), torch.no_grad():
+        arrays["noflip_out"] = m1(x2d, None)
+    m1f = build_reference_d3dp(1, 1, flip=True)
+    m1f.load_state_dict(sd)
+    with NoiseTape(noises1), torch.no_grad():
+        arrays["flip11_out"] = m1f(x2d, None, input_2d_flip=x2d_flip)
+    save("g5_d3dp.npz", **arrays)
+
+
+# -------------------------------------------------------------------------------------------------- G6
+def g6_index_ops():
+    """integer-valued tensors through the flip permutation, part split/concat and the pose utilities."""
+    from common.utils import center_pose_parts, wb_pose_from_parts
+    ds = FakeDataset()
+    m = build_reference_d3dp(1, 1)
+    g = torch.Generator().manual_seed(61)
+    x = torch.randint(-50, 50, (2, 3, 4, 134, 3), generator=g).float()
+    lr = gu.SYN_JOINTS_LEFT + gu.SYN_JOINTS_RIGHT
+    rl = gu.SYN_JOINTS_RIGHT + gu.SYN_JOINTS_LEFT
+    flipped = x.clone()
+    flipped[:, :, :, :, 0] *= -1
+    flipped[:, :, :, lr] = flipped[:, :, :, rl]
+    d2, d3 = m.split_data(x[:, 0, :, :, :2], x)
+    cat = torch.cat([d3[p] for p in m.pose_estimator.keys()], dim=-2)
+    pose = torch.randint(-50, 50, (2, 4, 134, 3), generator=g).float()
+    centred = center_pose_parts(pose.clone(), ds)
+    wb_in = pose.clone()
+    wb_out = wb_pose_from_parts(wb_in, ds)
+    save("g6_index_ops.npz", x=x, flipped=flipped, cat=cat,
+         split_body=d3["body"], split_face=d3["face"], split_hands=d3["hands"],
+         pose=pose, centred=centred, wb_out=wb_out, wb_in_after=wb_in)
+
+
+# -------------------------------------------------------------------------------------------------- G7
+def g7_metrics():
+    from common.loss import mpjpe_diffusion, mpjpe_diffusion_all_min, mpjpe_diffusion_reproj
+    from common.camera import project_to_2d
+    g = torch.Generator().manual_seed(71)
+    B, T, P = 2, 3, 4
+    pred = torch.randn(B, T, P, 5, 134, 3, generator=g) * 0.3
+    target = torch.randn(B, 5, 134, 3, generator=g) * 0.3
+    target_2d = torch.rand(B, 5, 134, 2, generator=g) * 2 - 1
+    traj = torch.randn(B, 5, 1, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+    cam = torch.tensor([[2.29, 2.287, 0.025, 0.029, -0.207, 0.247, -0.003, -0.0009, -0.001]])
+    absolute = (pred + traj[:, None, None]).reshape(B * T * P * 5, 134, 3)
+    reproj = project_to_2d(absolute, cam.repeat(B * T * P * 5, 1)).reshape(B, T, P, 5, 134, 2)
+    save("g7_metrics.npz", pred=pred, target=target, target_2d=target_2d, traj=traj, cam=cam, reproj=reproj,
+         j_best=mpjpe_diffusion_all_min(pred, target),
+         p_best=mpjpe_diffusion(pred.clone(), target.clone())[0],
+         p_agg=mpjpe_diffusion_all_min(pred, target, mean_pos=True),
+         j_agg=mpjpe_diffusion_reproj(pred, target, reproj, target_2d))
+
+
+if __name__ == "__main__":
+    install_shims()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
+                 g6=g6_index_ops, g7=g7_metrics)
+    for w in which:
+        table[w]()

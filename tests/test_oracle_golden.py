@@ -1,0 +1,128 @@
+"""The oracle (oracle/d3dp_oracle.py) against every golden vector captured from the real reference.
+
+These pins are what allows the GPU parity tests to use the oracle as the checker at other sizes/seeds.
+"""
+import numpy as np
+import torch
+
+from oracle import d3dp_oracle as orc
+from tests.golden import golden_util as gu
+from tests.conftest import load_golden
+
+
+def _sub(z, prefix):
+    return {k[len(prefix):]: v for k, v in z.items() if k.startswith(prefix)}
+
+
+def test_g1_tiny_mixste_bit_level():
+    z = load_golden("g1_tiny_mixste.npz")
+    sd = _sub(z, "sd.")
+    out = orc.mixste2_eval(sd, "", z["x2d"], z["x3d"], z["t"], depth=2, heads=8)
+    assert out.shape == z["out"].shape
+    assert torch.allclose(out, z["out"], rtol=0, atol=2e-6), (out - z["out"]).abs().max()
+
+
+def test_g2_schedule_exact():
+    z = load_golden("g2_schedule.npz")
+    bufs = orc.schedule_buffers(1000)
+    ref = _sub(z, "buf.")
+    assert set(ref) == set(bufs) and len(bufs) == 12
+    for k, v in bufs.items():
+        assert v.dtype == torch.float64
+        assert torch.equal(v, ref[k]), k
+    for T in (1, 2, 5, 10, 20, 50):
+        pairs = orc.ddim_time_pairs(1000, T)
+        assert pairs == [tuple(p) for p in z[f"pairs.{T}"].tolist()]
+        coefs = [[float(x) for x in orc.ddim_coefficients(bufs["alphas_cumprod"], a, b)]
+                 for a, b in pairs if b >= 0]
+        assert np.array_equal(np.asarray(coefs).reshape(-1, 3), z[f"coefs.{T}"].numpy())
+    assert orc.ddim_time_pairs(1000, 10)[0] == (999, 899) and orc.ddim_time_pairs(1000, 10)[-1] == (99, -1)
+
+
+def test_g3_time_mlp():
+    z = load_golden("g3_time_mlp.npz")
+    for part, C in gu.PART_WIDTH.items():
+        shapes = {"1.weight": (2 * C, C), "1.bias": (2 * C,), "3.weight": (C, 2 * C), "3.bias": (C,)}
+        sd = {k: gu.seeded_tensor(f"g3.{part}.time_mlp.{k}", s, 31) for k, s in shapes.items()}
+        assert gu.sha256_of(sd) == z[f"{part}.sha"].numpy().tobytes()
+        arg = z["t"][:, None] * orc.sinusoid_frequencies(C)[None, :]
+        assert torch.equal(torch.cat((arg.sin(), arg.cos()), -1), z[f"{part}.sin"])
+        out = orc.timestep_embedding({"time_mlp." + k: v for k, v in sd.items()}, "", z["t"], C)
+        assert torch.allclose(out, z[f"{part}.out"], rtol=0, atol=1e-6)
+
+
+def test_g4_blocks():
+    z = load_golden("g4_blocks.npz")
+    for part, C in gu.PART_WIDTH.items():
+        shapes = {"norm1.weight": (C,), "norm1.bias": (C,), "attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,),
+                  "attn.proj.weight": (C, C), "attn.proj.bias": (C,), "norm2.weight": (C,), "norm2.bias": (C,),
+                  "mlp.fc1.weight": (2 * C, C), "mlp.fc1.bias": (2 * C,), "mlp.fc2.weight": (C, 2 * C),
+                  "mlp.fc2.bias": (C,)}
+        sd = {k: gu.seeded_tensor(f"g4.{part}.{k}", s, 41) for k, s in shapes.items()}
+        assert gu.sha256_of(sd) == z[f"{part}.sha"].numpy().tobytes()
+        for tag in ("s", "t"):
+            y = orc.transformer_block(sd, "", z[f"{part}.x{tag}"], heads=8)
+            assert torch.allclose(y, z[f"{part}.y{tag}"], rtol=0, atol=5e-6), (part, tag)
+
+
+def _g5_state_dict(z):
+    from tests.golden.state_template import d3dp_template
+    sd = gu.seeded_state_dict(d3dp_template(), seed=51)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    return sd
+
+
+def test_g5_d3dp_loops():
+    z = load_golden("g5_d3dp.npz")
+    sd = _g5_state_dict(z)
+    assert len(sd) == 636
+    x2d, x2d_flip = gu.synthetic_inputs_2d(B=1)
+    assert torch.equal(x2d, z["flip_x2d"]) and torch.equal(x2d_flip, z["flip_x2d_flip"])
+    # single denoiser pass per part
+    t = torch.tensor([499])
+    for part, idx in orc.PART_JOINTS.items():
+        out = orc.mixste2_eval(sd, f"pose_estimator.{part}.", x2d[..., idx, :], z["part_x3d"][..., idx, :], t)
+        assert torch.allclose(out, z[f"part.{part}"], rtol=0, atol=2e-5), part
+    # flip-TTA loop P=2, T=2
+    noises = gu.synthetic_noises(B=1, P=2, n=2, seed=1)
+    out = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2d_flip)
+    assert out.shape == (1, 2, 2, 27, 134, 3) and out.dtype == torch.float32
+    assert torch.allclose(out, z["flip_out"], rtol=0, atol=2e-5), (out - z["flip_out"]).abs().max()
+    # P=1, T=1 both samplers (BASELINE config 1: CPU plumbing)
+    n1 = gu.synthetic_noises(B=1, P=1, n=1, seed=2)
+    o_nf = orc.ddim_sample(sd, x2d, n1, 1)
+    assert torch.allclose(o_nf, z["noflip_out"], rtol=0, atol=2e-5)
+    o_f = orc.ddim_sample(sd, x2d, n1, 1, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2d_flip)
+    assert torch.allclose(o_f, z["flip11_out"], rtol=0, atol=2e-5)
+
+
+def test_g6_index_ops_bit_exact():
+    z = load_golden("g6_index_ops.npz")
+    x = z["x"]
+    perm = orc.flip_permutation(gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT)
+    flipped = x[:, :, :, perm].clone()
+    flipped[..., 0] *= -1
+    assert torch.equal(flipped, z["flipped"])
+    assert torch.equal(perm[perm], torch.arange(134))                     # an involution
+    parts = [x[..., idx, :] for idx in orc.PART_JOINTS.values()]
+    assert torch.equal(parts[0], z["split_body"]) and torch.equal(parts[1], z["split_face"])
+    assert torch.equal(parts[2], z["split_hands"])
+    assert torch.equal(torch.cat(parts, dim=-2), z["cat"]) and torch.equal(z["cat"], x)
+    assert torch.equal(orc.center_pose_parts(z["pose"].clone()), z["centred"])
+    wb_in = z["pose"].clone()
+    assert torch.equal(orc.wb_pose_from_parts(wb_in), z["wb_out"])
+    assert torch.equal(wb_in, z["wb_in_after"])                           # the reference's in-place side effect
+    assert torch.all(z["wb_out"][..., 0, :] == 0)
+
+
+def test_g7_metrics():
+    z = load_golden("g7_metrics.npz")
+    pred, target = z["pred"], z["target"]
+    B, T, P, F = pred.shape[:4]
+    absolute = (pred + z["traj"][:, None, None]).reshape(B * T * P * F, 134, 3)
+    reproj = orc.project_to_2d(absolute, z["cam"].repeat(B * T * P * F, 1)).reshape(B, T, P, F, 134, 2)
+    assert torch.allclose(reproj, z["reproj"], rtol=0, atol=1e-6)
+    assert torch.allclose(orc.j_best(pred, target), z["j_best"], rtol=0, atol=1e-7)
+    assert torch.allclose(orc.p_best(pred, target), z["p_best"], rtol=0, atol=1e-7)
+    assert torch.allclose(orc.p_agg(pred, target), z["p_agg"], rtol=0, atol=1e-7)
+    assert torch.allclose(orc.j_agg(pred, target, z["reproj"], z["target_2d"]), z["j_agg"], rtol=0, atol=1e-7)
