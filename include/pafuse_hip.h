@@ -1,0 +1,146 @@
+/*
+ * pafuse_hip.h - C ABI of the MI355X (gfx950) implementation of the PAFUSE hot path:
+ * the D3DP DDIM denoising loop over three per-body-part MixSTE spatio-temporal transformers.
+ *
+ * Every entry point takes plain device pointers, sizes and a HIP stream (as void*); no torch types.
+ * All tensors are dense row-major fp32 in device memory unless stated; "t" vectors are int64.
+ * Return value: 0 on success, a negative PAFUSE_E_* code otherwise (pafuse_last_error() has the text).
+ * Nothing here allocates, synchronises or touches the default stream: launches go to `stream` only, scratch
+ * comes from the caller's workspace, so every call can be captured into a hipGraph.
+ *
+ * Reference interface each entry point replaces (paths relative to valeoai/PAFUSE):
+ *   pafuse_linear            torch.nn.Linear (+ nn.GELU) as used in common/mixste.py:30-43,54,57
+ *   pafuse_layernorm         torch.nn.LayerNorm as used in common/mixste.py:96,101,203-204,208
+ *   pafuse_attention         Attention.forward between qkv and proj, common/mixste.py:65-79
+ *   pafuse_block_forward     Block.forward, common/mixste.py:113-116
+ *   pafuse_time_embed        MixSTE2.time_mlp, common/mixste.py:127-139,179-184
+ *   pafuse_mixste2_forward   MixSTE2.forward (is_train=False), common/mixste.py:278-298
+ *   pafuse_d3dp_sample       D3DP.ddim_sample_flip / ddim_sample, common/diffusionpose.py:227-316
+ *                            (with model_predictions[_fliping] :174-225, pred_parts/split_data :163-172,328-335)
+ */
+#ifndef PAFUSE_HIP_H
+#define PAFUSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAFUSE_OK 0
+#define PAFUSE_E_ARG (-1)       /* null pointer / bad size */
+#define PAFUSE_E_SHAPE (-2)     /* a width this build has no kernel for */
+#define PAFUSE_E_WORKSPACE (-3) /* workspace too small */
+#define PAFUSE_E_HIP (-4)       /* a HIP launch failed */
+
+#define PAFUSE_MAX_DEPTH 16
+#define PAFUSE_MAX_PARTS 4
+
+/* Parameters of one transformer block; names follow the reference state dict
+ * ({STE,TTE}blocks.<i>.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.{weight,bias}). Linear weights are
+ * [out,in] row-major exactly as torch stores them - nothing is re-packed. */
+typedef struct pafuse_block_weights {
+    const float *norm1_w, *norm1_b; /* [C] */
+    const float *qkv_w, *qkv_b;     /* [3C,C], [3C] */
+    const float *proj_w, *proj_b;   /* [C,C], [C] */
+    const float *norm2_w, *norm2_b; /* [C] */
+    const float *fc1_w, *fc1_b;     /* [2C,C], [2C] */
+    const float *fc2_w, *fc2_b;     /* [C,2C], [C] */
+} pafuse_block_weights;
+
+/* One MixSTE2 (common/mixste.py:141-210): F frames, J joints of this part, C channels, `depth` spatial +
+ * `depth` temporal blocks, `heads` heads (C % heads == 0), mlp hidden = 2C. */
+typedef struct pafuse_mixste2_weights {
+    int32_t frames, joints, channels, depth, heads, in_chans; /* in_chans must be 5 (2-D + 3-D) */
+    const float *patch_w, *patch_b;                           /* Spatial_patch_to_embedding [C,5], [C] */
+    const float *pos_spatial;                                 /* Spatial_pos_embed [J,C] */
+    const float *pos_temporal;                                /* Temporal_pos_embed [F,C] */
+    const float *tm1_w, *tm1_b, *tm3_w, *tm3_b;               /* time_mlp.1 [2C,C],[2C]; time_mlp.3 [C,2C],[C] */
+    const float *freqs;                                       /* [C/2] sinusoid frequencies (mixste.py:134-136) */
+    const float *snorm_w, *snorm_b, *tnorm_w, *tnorm_b;       /* Spatial_norm, Temporal_norm (eps 1e-6) */
+    const float *hnorm_w, *hnorm_b;                           /* head.0 LayerNorm (eps 1e-5) */
+    const float *head_w, *head_b;                             /* head.1 [3,C], [3] */
+    pafuse_block_weights ste[PAFUSE_MAX_DEPTH];
+    pafuse_block_weights tte[PAFUSE_MAX_DEPTH];
+} pafuse_mixste2_weights;
+
+/* Everything D3DP's sampler needs besides the tensors (common/diffusionpose.py:59-155). */
+typedef struct pafuse_d3dp_config {
+    int32_t num_parts;                 /* 3: body, face, hands (iteration order = concat order) */
+    int32_t num_kps;                   /* 134 */
+    int32_t frames;                    /* 27 */
+    int32_t flip;                      /* 1: ddim_sample_flip, 0: ddim_sample */
+    float scale;                       /* args.ft2d.scale */
+    pafuse_mixste2_weights part[PAFUSE_MAX_PARTS];
+    const int32_t *part_joints[PAFUSE_MAX_PARTS]; /* device: joint indices of each part (split_data) */
+    const int32_t *joint_part;         /* device [num_kps]: part id of every joint */
+    const int32_t *joint_local;        /* device [num_kps]: index of the joint inside its part */
+    const int32_t *flip_perm;          /* device [num_kps]: flipped[j] = orig[perm[j]] (diffusionpose.py:197-198) */
+} pafuse_d3dp_config;
+
+/* Per-step scalars of the loop, computed by the host exactly as the reference does in fp64
+ * (common/diffusionpose.py:157-161, 302-306). */
+typedef struct pafuse_ddim_step {
+    int64_t time;                /* timestep fed to the denoisers */
+    int32_t last;                /* 1 when time_next < 0: img = x_start, no update */
+    double sqrt_recip_acp;       /* sqrt_recip_alphas_cumprod[time] */
+    double sqrt_recipm1_acp;     /* sqrt_recipm1_alphas_cumprod[time] */
+    double sqrt_alpha_next, c, sigma;
+} pafuse_ddim_step;
+
+const char *pafuse_version(void);
+const char *pafuse_last_error(void);
+
+/* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU.  K,N multiples of 32. */
+int pafuse_linear(const float *A, const float *W, const float *bias, float *out, int64_t M, int32_t N, int32_t K,
+                  int32_t act, void *stream);
+
+/* out[M,C] = LayerNorm(x[M,C]) * w + b  (biased variance, eps inside the sqrt). */
+int pafuse_layernorm(const float *x, const float *w, const float *b, float *out, int64_t M, int32_t C, float eps,
+                     void *stream);
+
+/* o[M,C] = softmax(q k^T * d^-1/2) v per (sequence, head) on qkv[M,3C] laid out [.., 3, heads, d].
+ * Sequence s (0..nseq) holds rows  (s / inner) * inner * L * tstride_outer ... described by:
+ *   row(s, t) = (s / group) * group_stride + (s % group) * seq_stride + t * tok_stride
+ * spatial: group=1, group_stride=L, seq_stride=0, tok_stride=1; temporal: group=J, group_stride=F*J,
+ * seq_stride=1, tok_stride=J. */
+int pafuse_attention(const float *qkv, float *o, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group,
+                     int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void *stream);
+
+/* x[S*L,C] <- Block(x) in place for S contiguous sequences of L tokens (Block.forward, eps 1e-6). */
+size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C);
+int pafuse_block_forward(const pafuse_block_weights *w, float *x, int64_t S, int32_t L, int32_t C, int32_t heads,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* temb[B,C] = time_mlp(t[B]) */
+int pafuse_time_embed(const pafuse_mixste2_weights *w, const int64_t *t, int32_t B, float *temb, void *stream);
+
+/* MixSTE2.forward, eval: x2d[B,F,J,2], x3d[B,P,F,J,3], t[B] -> out[B,P,F,J,3]. */
+size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights *w, int32_t B, int32_t P);
+int pafuse_mixste2_forward(const pafuse_mixste2_weights *w, const float *x2d, const float *x3d, const int64_t *t,
+                           int32_t B, int32_t P, float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The whole DDIM loop for B clips x P hypotheses and `nsteps` sampling steps.
+ *   x2d, x2d_flip [B,F,J,2] (x2d_flip ignored when cfg->flip == 0)
+ *   noise [n_draws,B,P,F,J,3]: draw 0 is the initial img, draw k the randn_like of the k-th update
+ *         (n_draws >= 1 + number of steps with last == 0)
+ *   out   [B,nsteps,P,F,J,3]: x_start of every step (torch.stack(preds_all, dim=1))
+ * `aux_streams` (may be NULL / n_aux 0): extra HIP streams the parts are spread over; events are created
+ * and destroyed inside the call only when aux streams are given. */
+size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config *cfg, int32_t B, int32_t P);
+int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *steps, int32_t nsteps,
+                       const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,
+                       int32_t P, float *out, void *workspace, size_t workspace_bytes, void *stream,
+                       void *const *aux_streams, int32_t n_aux);
+
+/* Replays the GEMM launches of one flip-TTA denoiser pass (all three parts) back to back on `stream`, for
+ * bench.py's per-kernel roofline measurement: returns the number of launches, adds their algorithmic FLOPs to
+ * *flops.  Uses (and overwrites) the workspace like pafuse_d3dp_sample does. */
+int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config *cfg, int32_t B, int32_t P, void *workspace,
+                             size_t workspace_bytes, void *stream, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAFUSE_HIP_H */

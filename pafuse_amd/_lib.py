@@ -1,0 +1,97 @@
+"""ctypes binding of libpafuse_hip.so (the C ABI declared in include/pafuse_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU fallback: if the
+shared object is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpafuse_hip.so")
+
+MAX_DEPTH = 16
+MAX_PARTS = 4
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+
+class BlockWeights(C.Structure):
+    _names = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+              "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+    _fields_ = [(n, C.c_void_p) for n in _names]
+
+
+class MixSTE2Weights(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("frames", "joints", "channels", "depth", "heads", "in_chans")] +
+                [(n, C.c_void_p) for n in ("patch_w", "patch_b", "pos_spatial", "pos_temporal",
+                                           "tm1_w", "tm1_b", "tm3_w", "tm3_b", "freqs",
+                                           "snorm_w", "snorm_b", "tnorm_w", "tnorm_b",
+                                           "hnorm_w", "hnorm_b", "head_w", "head_b")] +
+                [("ste", BlockWeights * MAX_DEPTH), ("tte", BlockWeights * MAX_DEPTH)])
+
+
+class D3DPConfig(C.Structure):
+    _fields_ = [("num_parts", C.c_int32), ("num_kps", C.c_int32), ("frames", C.c_int32), ("flip", C.c_int32),
+                ("scale", C.c_float),
+                ("part", MixSTE2Weights * MAX_PARTS),
+                ("part_joints", C.c_void_p * MAX_PARTS),
+                ("joint_part", C.c_void_p), ("joint_local", C.c_void_p), ("flip_perm", C.c_void_p)]
+
+
+class DDIMStep(C.Structure):
+    _fields_ = [("time", C.c_int64), ("last", C.c_int32),
+                ("sqrt_recip_acp", C.c_double), ("sqrt_recipm1_acp", C.c_double),
+                ("sqrt_alpha_next", C.c_double), ("c", C.c_double), ("sigma", C.c_double)]
+
+
+# every symbol include/pafuse_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "pafuse_version": (C.c_char_p, []),
+    "pafuse_last_error": (C.c_char_p, []),
+    "pafuse_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_void_p]),
+    "pafuse_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
+                                   C.c_void_p]),
+    "pafuse_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "pafuse_block_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "pafuse_block_forward": (C.c_int, [C.POINTER(BlockWeights), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pafuse_time_embed": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pafuse_mixste2_workspace_bytes": (C.c_size_t, [C.POINTER(MixSTE2Weights), C.c_int32, C.c_int32]),
+    "pafuse_mixste2_forward": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "pafuse_d3dp_workspace_bytes": (C.c_size_t, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32]),
+    "pafuse_d3dp_sample": (C.c_int, [C.POINTER(D3DPConfig), C.POINTER(DDIMStep), C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
+    "pafuse_d3dp_replay_gemms": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class PafuseError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and attach the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PafuseError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise PafuseError(f"pafuse_hip error {rc}: {load().pafuse_last_error().decode()}")
+    return rc

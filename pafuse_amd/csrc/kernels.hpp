@@ -1,0 +1,672 @@
+// kernels.hpp - device kernels of the PAFUSE hot path for gfx950 (MI355X, CDNA4).  Wave = 64 lanes.
+//
+// All arithmetic is fp32 (the parity contract is 1e-4 mm MPJPE, SURVEY.md section 7 "Hard parts" 1), with the
+// reference's fp64 islands kept in fp64.  Contractions run on the f32-input matrix cores
+// (v_mfma_f32_32x32x2_f32 for the linear layers, v_mfma_f32_16x16x4_f32 for attention).
+//
+// Token matrix layout: one row per (r, f, j) with r = flip*B*P + b*P + p, row-major [M, C].  The reference's
+// "(b f) n c <-> (b n) f c" rearranges (common/mixste.py:244,270,274,288) never materialise here: linear layers
+// and norms are per-row, and attention addresses the rows of a sequence through strides.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pafuse {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;   // K-chunk of the linear-layer kernels
+constexpr int LDK = 36;  // padded LDS row (floats): 144 B stride makes the ds_read_b128 fragment reads conflict-free
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    // nn.GELU() default (approximate='none'): x * 0.5 * (1 + erf(x / sqrt(2)))   (common/mixste.py:25,32)
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// sum over the 32 lanes that share (lane >> 5); every lane of the half ends with the total
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32);
+    return half_wave_sum(v);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Linear layer:  out = epilogue(A[M,K] @ W[N,K]^T + bias)
+// ----------------------------------------------------------------------------------------------------------------
+enum { EPI_BIAS = 0, EPI_ROWLN = 1 };
+
+struct GemmParams {
+    const float* A;     // [M,K]
+    const float* W;     // [N,K]  (torch nn.Linear.weight)
+    const float* bias;  // [N]
+    float* out;         // EPI_BIAS: [M,N]
+    int64_t M;
+    int N, K;
+    int act;  // EPI_BIAS: 0 none, 1 GELU
+    // EPI_ROWLN (the workgroup owns whole rows, N == BN):  y = A W^T + bias + resid
+    //   z  = post_w ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;  out_x = z
+    //   n  = next_w ? LN(z; next) : -  ;  out_n = n   |  out_head = n @ head_w^T + head_b
+    const float* resid;
+    float* out_x;
+    float* out_n;
+    const float* post_w;
+    const float* post_b;
+    float post_eps;
+    const float* pos;
+    int posJ, posF;
+    const float* next_w;
+    const float* next_b;
+    float next_eps;
+    const float* head_w;
+    const float* head_b;
+    float* out_head;
+};
+
+template <int WM, int WN, int NT>
+struct GemmTile {
+    static constexpr int NTHR = WM * WN * 64;
+    static constexpr int BM = WM * 32;
+    static constexpr int BN = WN * NT * 32;
+    static constexpr int STAGE_FLOATS = (BM + BN) * LDK;
+};
+
+// Workgroup = WM x WN waves, each wave a 32 x (32*NT) strip of the BM x BN tile, K streamed in 32-wide chunks:
+// global -> registers (issued before the MFMAs of the current chunk) -> LDS (after them), NSTAGE LDS buffers.
+// Fragment reads are ds_read_b128: lane (r = lane&31, h = lane>>5) takes k = 8g+4h..8g+4h+3 of row r, and MFMA
+// step (g, j) multiplies k = 8g+j (h = 0) and 8g+4+j (h = 1): a permutation of k shared by A and W.
+template <int WM, int WN, int NT, int EPI, int NSTAGE>
+__global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
+    using T = GemmTile<WM, WN, NT>;
+    constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
+    constexpr int A_LD = BM * 8 / NTHR, W_LD = BN * 8 / NTHR;
+    static_assert((BM * 8) % NTHR == 0 && (BN * 8) % NTHR == 0, "staging must divide evenly");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Ws = smem + NSTAGE * BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_n = p.N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int K = p.K;
+
+    const float* a_src[A_LD];
+    int a_dst[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int idx = tid + i * NTHR, row = idx >> 3, c4 = idx & 7;
+        int64_t gm = m0 + row;
+        gm = gm < p.M ? gm : p.M - 1;  // tail rows read a valid row; their results are never stored
+        a_src[i] = p.A + gm * K + c4 * 4;
+        a_dst[i] = row * LDK + c4 * 4;
+    }
+    const float* w_src[W_LD];
+    int w_dst[W_LD];
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+        const int idx = tid + i * NTHR, row = idx >> 3, c4 = idx & 7;
+        w_src[i] = p.W + (int64_t)(n0 + row) * K + c4 * 4;
+        w_dst[i] = row * LDK + c4 * 4;
+    }
+    f32x4 a_reg[A_LD], w_reg[W_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i]);
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i]);
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(As + a_dst[i]) = a_reg[i];
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Ws + w_dst[i]) = w_reg[i];
+    __syncthreads();
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+    const int a_frag = (wm * 32 + r) * LDK + 4 * h;
+    const int w_frag = (wn * NT * 32 + r) * LDK + 4 * h;
+    const int nk = K / BK;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int cur = (NSTAGE == 2) ? (kc & 1) : 0;
+        const bool more = kc + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (kc + 1) * BK);
+#pragma unroll
+            for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i] + (kc + 1) * BK);
+        }
+        const float* Ac = As + cur * BM * LDK + a_frag;
+        const float* Wc = Ws + cur * BN * LDK + w_frag;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(Ac + 8 * g);
+            f32x4 wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
+        }
+        if (NSTAGE == 1) __syncthreads();  // everyone done reading before the single buffer is refilled
+        if (more) {
+            const int nxt = (NSTAGE == 2) ? (cur ^ 1) : 0;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(As + nxt * BM * LDK + a_dst[i]) = a_reg[i];
+#pragma unroll
+            for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Ws + nxt * BN * LDK + w_dst[i]) = w_reg[i];
+        }
+        __syncthreads();
+    }
+
+    // accumulator element (nt, reg) of this lane is  row = (reg&3) + 8*(reg>>2) + 4*h,  col = 32*nt + r  of the strip
+    if (EPI == EPI_BIAS) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + (wn * NT + nt) * 32 + r;
+            const float bv = p.bias[n];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (m < p.M) {
+                    float v = acc[nt][reg] + bv;
+                    if (p.act) v = gelu_erf(v);
+                    p.out[m * p.N + n] = v;
+                }
+            }
+        }
+        return;
+    } else {
+        // ---- whole-row epilogue: residual, LayerNorms, optional 3-wide head ---------------------------------
+        float* red = smem;  // [slot][BM][WN] partial sums; the staging buffers are dead after the last barrier
+        const float invC = 1.0f / (float)p.N;
+        int64_t mrow[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) mrow[reg] = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+
+        auto row_total = [&](float (&s)[16], int slot) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s[reg] = half_wave_sum(s[reg]);
+            if (WN > 1) {
+                float* rs = red + slot * BM * WN;
+                if (r == 0) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        rs[(wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN + wn] = s[reg];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float* q = rs + (wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN;
+                    float t = q[0];
+#pragma unroll
+                    for (int w = 1; w < WN; ++w) t += q[w];
+                    s[reg] = t;
+                }
+            }
+        };
+        // in-place LayerNorm of the row fragments held in acc
+        auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot) {
+            float s[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float t = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) t += acc[nt][reg];
+                s[reg] = t;
+            }
+            row_total(s, slot);
+            float mean[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                mean[reg] = s[reg] * invC;
+                float t = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float d = acc[nt][reg] - mean[reg];
+                    t += d * d;
+                }
+                s[reg] = t;
+            }
+            row_total(s, slot + 1);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s[reg] = 1.0f / sqrtf(s[reg] * invC + eps);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (wn * NT + nt) * 32 + r;
+                const float g = gw[n], b = gb[n];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) acc[nt][reg] = (acc[nt][reg] - mean[reg]) * s[reg] * g + b;
+            }
+        };
+
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = (wn * NT + nt) * 32 + r;
+            const float bv = p.bias[n];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float rv = (mrow[reg] < p.M) ? p.resid[mrow[reg] * p.N + n] : 0.f;
+                acc[nt][reg] = (acc[nt][reg] + bv) + rv;
+            }
+        }
+        if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
+        if (p.pos) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int f = (int)((mrow[reg] / p.posJ) % p.posF);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][reg] += p.pos[f * p.N + (wn * NT + nt) * 32 + r];
+            }
+        }
+        if (p.out_x) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (wn * NT + nt) * 32 + r;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    if (mrow[reg] < p.M) p.out_x[mrow[reg] * p.N + n] = acc[nt][reg];
+            }
+        }
+        if (p.next_w) {
+            layer_norm(p.next_w, p.next_b, p.next_eps, 2);
+            if (p.out_n) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = (wn * NT + nt) * 32 + r;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (mrow[reg] < p.M) p.out_n[mrow[reg] * p.N + n] = acc[nt][reg];
+                }
+            }
+            if (p.out_head) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float s[16];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) s[reg] = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float hw = p.head_w[k * p.N + (wn * NT + nt) * 32 + r];
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) s[reg] += acc[nt][reg] * hw;
+                    }
+                    row_total(s, 4 + k);
+                    if (wn == 0 && r == 0) {
+                        const float hb = p.head_b[k];
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            if (mrow[reg] < p.M) p.out_head[mrow[reg] * 3 + k] = s[reg] + hb;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Attention between qkv and proj (common/mixste.py:65-79): one (sequence, head) per group of LP/16 waves, each
+// wave one tile of 16 queries.  S^T = K Q^T on 16x16x4 MFMAs puts the query on the lane and the keys in the
+// accumulator registers, so softmax reduces in registers + two xor-shuffles and the probabilities are already
+// the A operand of P V.
+// ----------------------------------------------------------------------------------------------------------------
+struct AttnParams {
+    const float* qkv;  // [M, 3C]
+    float* o;          // [M, C]
+    int64_t nseq;
+    int L, C, heads, d;
+    int64_t group, group_stride, seq_stride, tok_stride;
+    float scale;
+};
+
+template <int LP, int DP, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
+    constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16, ITEMS = NW / QT, LDV = DP + 4;
+    constexpr int NTHR = NW * 64, C4 = DP / 4;
+    static_assert(NW % QT == 0, "waves must be a multiple of the query tiles");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                     // [ITEMS][LP][LDV]
+    float* Vs = smem + ITEMS * LP * LDV;  // [ITEMS][LP][LDV]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nitems = p.nseq * p.heads;
+    const int C3 = 3 * p.C;
+
+    // stage K and V of this workgroup's items (zero-padded to LP x DP)
+    for (int il = 0; il < ITEMS; ++il) {
+        const int64_t item = (int64_t)blockIdx.x * ITEMS + il;
+        const bool ok = item < nitems;
+        const int64_t seq = ok ? item / p.heads : 0;
+        const int head = ok ? (int)(item % p.heads) : 0;
+        const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
+        for (int idx = tid; idx < LP * C4; idx += NTHR) {
+            const int t = idx / C4, c4 = idx % C4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (ok && t < p.L && c4 * 4 < p.d) {
+                const float* src = p.qkv + (base + t * p.tok_stride) * C3 + head * p.d + c4 * 4;
+                kv = *reinterpret_cast<const f32x4*>(src + p.C);
+                vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            }
+            *reinterpret_cast<f32x4*>(Ks + (il * LP + t) * LDV + c4 * 4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + (il * LP + t) * LDV + c4 * 4) = vv;
+        }
+    }
+    __syncthreads();
+
+    const int il = wave / QT, qt = wave % QT;
+    const int64_t item = (int64_t)blockIdx.x * ITEMS + il;
+    if (item >= nitems) return;
+    const int64_t seq = item / p.heads;
+    const int head = (int)(item % p.heads);
+    const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    // Q fragments straight from global: query = 16*qt + l15, dk = 16*s + 4*g .. +3
+    f32x4 qf[SD];
+    {
+        const int q = qt * 16 + l15;
+#pragma unroll
+        for (int s = 0; s < SD; ++s) {
+            qf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < p.L && 16 * s + 4 * g < p.d)
+                qf[s] = *reinterpret_cast<const f32x4*>(p.qkv + (base + q * p.tok_stride) * C3 + head * p.d + 16 * s +
+                                                        4 * g);
+        }
+    }
+    const float* Kb = Ks + il * LP * LDV;
+    const float* Vb = Vs + il * LP * LDV;
+    f32x4 sc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < SD; ++s) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + (kt * 16 + l15) * LDV + 16 * s + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qf[s][j], sc[kt], 0, 0, 0);
+        }
+    }
+    // sc[kt][reg] = <q, k> for query 16*qt + l15 and key 16*kt + 4*g + reg
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int key = kt * 16 + 4 * g + reg;
+            const float v = key < p.L ? sc[kt][reg] * p.scale : -INFINITY;
+            sc[kt][reg] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float e = expf(sc[kt][reg] - mx);
+            sc[kt][reg] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) sc[kt][reg] = sc[kt][reg] / sum;
+
+    f32x4 oc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) oc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float* vrow = Vb + (kt * 16 + 4 * g + reg) * LDV + l15;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                oc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][reg], vrow[ct * 16], oc[ct], 0, 0, 0);
+        }
+    // oc[ct][reg] = O[query 16*qt + 4*g + reg][channel 16*ct + l15]
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int ch = ct * 16 + l15;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int q = qt * 16 + 4 * g + reg;
+            if (q < p.L && ch < p.d) p.o[(base + q * p.tok_stride) * p.C + head * p.d + ch] = oc[ct][reg];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Row-wise LayerNorm, one wave per row (stand-alone form; inside the loop the norms live in GEMM epilogues)
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int LN_MAX_PER_LANE = 12;  // C <= 768
+
+__device__ __forceinline__ void wave_layer_norm(float (&v)[LN_MAX_PER_LANE], int C, int lane, const float* w,
+                                                const float* b, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+        if (lane + 64 * i < C) s += v[i];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+        if (lane + 64 * i < C) {
+            const float d = v[i] - mean;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+        if (lane + 64 * i < C) v[i] = (v[i] - mean) * rstd * w[lane + 64 * i] + b[lane + 64 * i];
+}
+
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const float* w, const float* b, float* out,
+                                                        int64_t M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) v[i] = (lane + 64 * i < C) ? x[row * C + lane + 64 * i] : 0.f;
+    wave_layer_norm(v, C, lane, w, b, eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+        if (lane + 64 * i < C) out[row * C + lane + 64 * i] = v[i];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Timestep embedding: sinusoid -> Linear(C,2C) -> GELU -> Linear(2C,C)   (common/mixste.py:127-139,179-184)
+// One workgroup per batch row.  `freqs` is the host-computed omega table so that t*omega is the same fp32
+// product the reference forms; sin/cos are the accurate device functions (arguments reach 999 rad).
+// ----------------------------------------------------------------------------------------------------------------
+struct TimeEmbedParams {
+    const int64_t* t;  // [B] or null -> t_scalar
+    int64_t t_scalar;
+    const float* freqs;
+    const float *w1, *b1, *w3, *b3;
+    float* out;  // [B,C]
+    int C;
+};
+
+__global__ void __launch_bounds__(256) time_embed_kernel(const TimeEmbedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* emb = smem;        // [C]
+    float* hid = smem + p.C;  // [2C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, C = p.C, half = C / 2;
+    const float tf = (float)(p.t ? p.t[b] : p.t_scalar);
+    for (int i = tid; i < half; i += 256) {
+        const float a = tf * p.freqs[i];
+        emb[i] = sinf(a);
+        emb[half + i] = cosf(a);
+    }
+    __syncthreads();
+    for (int o = wave; o < 2 * C; o += 4) {
+        float s = 0.f;
+        for (int k = lane; k < C; k += 64) s += p.w1[(int64_t)o * C + k] * emb[k];
+        s = wave_sum(s);
+        if (lane == 0) hid[o] = gelu_erf(s + p.b1[o]);
+    }
+    __syncthreads();
+    for (int o = wave; o < C; o += 4) {
+        float s = 0.f;
+        for (int k = lane; k < 2 * C; k += 64) s += p.w3[(int64_t)o * 2 * C + k] * hid[k];
+        s = wave_sum(s);
+        if (lane == 0) p.out[(int64_t)b * C + o] = s + p.b3[o];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Embedding of one part: clamp / scale / flip / joint gather of the noised 3-D pose, 2-D broadcast over P,
+// Linear(5 -> C) + spatial pos-embed + time embed (common/diffusionpose.py:193-198, 328-335;
+// common/mixste.py:227-235), then LayerNorm (norm1 of STEblocks[0]) for the first QKV GEMM.  One wave per token.
+// ----------------------------------------------------------------------------------------------------------------
+struct EmbedParams {
+    const float* x3d;       // [B,P,F,J3,3]  (J3 = joints of the x3d tensor: num_kps in the loop, J in mixste2_forward)
+    const float* x2d;       // [B,F,J2,2]
+    const float* x2d_flip;  // same, or null
+    const int32_t* joints;  // [J] index of this part's joints in the J3/J2 axes, or null (identity)
+    const int32_t* perm;    // [J3] flip permutation, or null
+    const float *pw, *pb, *pos, *temb;  // [C,5], [C], [J,C], [B,C]
+    const float *n_w, *n_b;             // next LayerNorm
+    float n_eps;
+    float *x, *xn;  // [M,C]
+    int B, P, F, J, J3, C, nflip;
+    int do_clamp;
+    float scale;
+};
+
+__global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t M = (int64_t)p.nflip * p.B * p.P * p.F * p.J;
+    if (row >= M) return;
+    const int j = (int)(row % p.J);
+    const int f = (int)((row / p.J) % p.F);
+    const int64_t rr = row / ((int64_t)p.J * p.F);
+    const int pp = (int)(rr % p.P);
+    const int b = (int)((rr / p.P) % p.B);
+    const int fl = (int)(rr / ((int64_t)p.P * p.B));
+    const int jj = p.joints ? p.joints[j] : j;
+    const int j3 = fl ? p.perm[jj] : jj;
+    const float* s2 = (fl ? p.x2d_flip : p.x2d) + (((int64_t)b * p.F + f) * p.J3 + jj) * 2;
+    const float* s3 = p.x3d + ((((int64_t)b * p.P + pp) * p.F + f) * p.J3 + j3) * 3;
+    float in[5] = {s2[0], s2[1], s3[0], s3[1], s3[2]};
+    if (p.do_clamp) {
+        const float lim = 1.1f * p.scale;
+#pragma unroll
+        for (int i = 2; i < 5; ++i) in[i] = fminf(fmaxf(in[i], -lim), lim) / p.scale;
+    }
+    if (fl) in[2] = -in[2];
+    float v[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = 0.f;
+        if (c < p.C) {
+            const float* wr = p.pw + c * 5;
+            float a = in[0] * wr[0];
+            a += in[1] * wr[1];
+            a += in[2] * wr[2];
+            a += in[3] * wr[3];
+            a += in[4] * wr[4];
+            a += p.pb[c];
+            a += p.pos[j * p.C + c];
+            a += p.temb[(int64_t)b * p.C + c];
+            v[i] = a;
+            p.x[row * p.C + c] = a;
+        }
+    }
+    wave_layer_norm(v, p.C, lane, p.n_w, p.n_b, p.n_eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+        if (lane + 64 * i < p.C) p.xn[row * p.C + lane + 64 * i] = v[i];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// End of a DDIM step (common/diffusionpose.py:211-223 and :298-312): part concat, un-flip, TTA average, scale,
+// clamp -> x_start (written into preds_all[:, step]); epsilon in fp64; img update with the step's noise draw.
+// One thread per (b, p, f, joint).  Every fp32 op is individually rounded (no FMA contraction) like the
+// reference's separate ATen ops.
+// ----------------------------------------------------------------------------------------------------------------
+struct FinalizeParams {
+    const float* pred[4];  // per part [nflip*B*P*F*Jp, 3]
+    int Jp[4];
+    const int32_t *joint_part, *joint_local, *perm;
+    float* img;          // [B,P,F,J,3] in/out
+    const float* noise;  // [B,P,F,J,3] or null when last
+    float* out;          // [B,T,P,F,J,3]
+    int B, P, F, J, T, step, flip, last;
+    float scale;
+    double sr, srm1, c;
+    float an_f, c_f, sigma_f;
+};
+
+__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.P * p.F * p.J;
+    if (e >= total) return;
+    const int j = (int)(e % p.J);
+    const int f = (int)((e / p.J) % p.F);
+    const int64_t bp = e / ((int64_t)p.J * p.F);
+    const int pp = (int)(bp % p.P);
+    const int b = (int)(bp / p.P);
+    const int part = p.joint_part[j], lj = p.joint_local[j];
+    const float* a = p.pred[part] + ((bp * p.F + f) * p.Jp[part] + lj) * 3;
+    float x0[3] = {a[0], a[1], a[2]};
+    if (p.flip) {
+        const int js = p.perm[j];
+        const int part2 = p.joint_part[js], lj2 = p.joint_local[js];
+        const float* u = p.pred[part2] + ((((int64_t)p.B * p.P + bp) * p.F + f) * p.Jp[part2] + lj2) * 3;
+        x0[0] = __fdiv_rn(__fadd_rn(x0[0], -u[0]), 2.0f);
+        x0[1] = __fdiv_rn(__fadd_rn(x0[1], u[1]), 2.0f);
+        x0[2] = __fdiv_rn(__fadd_rn(x0[2], u[2]), 2.0f);
+    }
+    const float lim = 1.1f * p.scale;
+    float* o = p.out + ((((int64_t)b * p.T + p.step) * p.P + pp) * p.F + f) * p.J * 3 + j * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        x0[k] = fminf(fmaxf(__fmul_rn(x0[k], p.scale), -lim), lim);
+        o[k] = x0[k];
+    }
+    float* im = p.img + e * 3;
+    if (p.last) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) im[k] = x0[k];
+        return;
+    }
+    const float* nz = p.noise + e * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double eps64 = __ddiv_rn(__dsub_rn(__dmul_rn(p.sr, (double)im[k]), (double)x0[k]), p.srm1);
+        if (p.flip) {
+            // pred_noise.float(); then fp32 tensor ops with fp64 0-dim scalars demoted to fp32
+            const float eps = (float)eps64;
+            im[k] = __fadd_rn(__fadd_rn(__fmul_rn(x0[k], p.an_f), __fmul_rn(p.c_f, eps)), __fmul_rn(p.sigma_f, nz[k]));
+        } else {
+            // ddim_sample keeps eps in fp64 and casts img at the end (common/diffusionpose.py:264-267)
+            const double t1 = (double)__fmul_rn(x0[k], p.an_f);
+            const double t2 = __dmul_rn(p.c, eps64);
+            const double t3 = (double)__fmul_rn(p.sigma_f, nz[k]);
+            im[k] = (float)__dadd_rn(__dadd_rn(t1, t2), t3);
+        }
+    }
+}
+
+}  // namespace pafuse

@@ -1,0 +1,475 @@
+// pafuse_hip.hip - host side of the C ABI declared in include/pafuse_hip.h: argument checks, kernel selection
+// per width, the MixSTE2 layer schedule and the D3DP DDIM loop.  No allocation, no synchronisation.
+#include "../../include/pafuse_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "kernels.hpp"
+
+using namespace pafuse;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PAFUSE_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return PAFUSE_OK;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------ GEMM dispatch
+template <int WM, int WN, int NT, int EPI, int NSTAGE>
+int launch_gemm(const GemmParams& p, hipStream_t s) {
+    using T = GemmTile<WM, WN, NT>;
+    constexpr size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(EPI != EPI_ROWLN || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "reduction scratch must fit");
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE>;
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int64_t tiles_m = (p.M + T::BM - 1) / T::BM;
+    const int64_t tiles = tiles_m * (p.N / T::BN);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, s, p);
+    return check_launch("gemm_kernel");
+}
+
+int gemm_bias(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return PAFUSE_OK;
+    if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
+        return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
+    if (p.N % 128 == 0) return launch_gemm<4, 1, 4, EPI_BIAS, 2>(p, s);
+    if (p.N % 224 == 0) return launch_gemm<4, 1, 7, EPI_BIAS, 1>(p, s);
+    if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 2>(p, s);
+    if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 2>(p, s);
+    return launch_gemm<4, 1, 1, EPI_BIAS, 2>(p, s);
+}
+
+int gemm_rowln(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return PAFUSE_OK;
+    if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
+    switch (p.N) {
+        case 384: return launch_gemm<2, 4, 3, EPI_ROWLN, 1>(p, s);
+        case 256: return launch_gemm<2, 4, 2, EPI_ROWLN, 1>(p, s);
+        case 224: return launch_gemm<4, 1, 7, EPI_ROWLN, 1>(p, s);
+        case 128: return launch_gemm<2, 2, 2, EPI_ROWLN, 1>(p, s);
+        case 64: return launch_gemm<2, 2, 1, EPI_ROWLN, 1>(p, s);
+        default: return fail(PAFUSE_E_SHAPE, "no whole-row kernel for channel width %d (have 64,128,224,256,384)", p.N);
+    }
+}
+
+bool width_supported(int C) { return C == 384 || C == 256 || C == 224 || C == 128 || C == 64; }
+
+// ------------------------------------------------------------------------------------------- attention dispatch
+template <int LP, int DP, int NW>
+int launch_attn(const AttnParams& p, hipStream_t s) {
+    constexpr int ITEMS = NW / (LP / 16);
+    constexpr size_t lds = (size_t)2 * ITEMS * LP * (DP + 4) * sizeof(float);
+    const int64_t nitems = p.nseq * p.heads;
+    const int64_t grid = (nitems + ITEMS - 1) / ITEMS;
+    if (grid > 0x7fffffff) return fail(PAFUSE_E_ARG, "attention grid out of range");
+    hipLaunchKernelGGL((attn_kernel<LP, DP, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, s, p);
+    return check_launch("attn_kernel");
+}
+
+int attention(const AttnParams& p, hipStream_t s) {
+    if (p.nseq <= 0) return PAFUSE_OK;
+    if (p.d % 4 || p.d > 48 || p.L > 80 || p.L <= 0)
+        return fail(PAFUSE_E_SHAPE, "attention: head dim %d (need %%4, <=48) / length %d (need <=80)", p.d, p.L);
+    const int dp = p.d <= 32 ? 32 : 48;
+    const int lp = p.L <= 32 ? 32 : (p.L <= 48 ? 48 : 80);
+    if (dp == 32) {
+        if (lp == 32) return launch_attn<32, 32, 4>(p, s);
+        if (lp == 48) return launch_attn<48, 32, 6>(p, s);
+        return launch_attn<80, 32, 5>(p, s);
+    }
+    if (lp == 32) return launch_attn<32, 48, 4>(p, s);
+    if (lp == 48) return launch_attn<48, 48, 6>(p, s);
+    return launch_attn<80, 48, 5>(p, s);
+}
+
+// --------------------------------------------------------------------------------------- per-part activations
+struct PartBuffers {
+    float *x, *xn, *o, *wide;  // [M,C], [M,C], [M,C], [M,3C] (qkv, then the MLP hidden [M,2C])
+    float* temb;               // [B,C]
+    float* pred;               // [M,3]
+};
+
+size_t part_buffer_bytes(int64_t M, int C, int B) {
+    return 3 * align_up((size_t)M * C * 4) + align_up((size_t)M * 3 * C * 4) + align_up((size_t)B * C * 4) +
+           align_up((size_t)M * 3 * 4);
+}
+
+char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb) {
+    pb.x = (float*)base;
+    base += align_up((size_t)M * C * 4);
+    pb.xn = (float*)base;
+    base += align_up((size_t)M * C * 4);
+    pb.o = (float*)base;
+    base += align_up((size_t)M * C * 4);
+    pb.wide = (float*)base;
+    base += align_up((size_t)M * 3 * C * 4);
+    pb.temb = (float*)base;
+    base += align_up((size_t)B * C * 4);
+    pb.pred = (float*)base;
+    base += align_up((size_t)M * 3 * 4);
+    return base;
+}
+
+int check_weights(const pafuse_mixste2_weights* w) {
+    if (!w) return fail(PAFUSE_E_ARG, "null weights");
+    if (w->in_chans != 5) return fail(PAFUSE_E_SHAPE, "in_chans must be 5, got %d", w->in_chans);
+    if (w->depth < 1 || w->depth > PAFUSE_MAX_DEPTH) return fail(PAFUSE_E_SHAPE, "depth %d out of range", w->depth);
+    if (!width_supported(w->channels)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", w->channels);
+    if (w->heads <= 0 || w->channels % w->heads) return fail(PAFUSE_E_SHAPE, "heads %d !| C %d", w->heads, w->channels);
+    const int d = w->channels / w->heads;
+    if (d % 4 || d > 48) return fail(PAFUSE_E_SHAPE, "head dim %d unsupported", d);
+    if (w->joints < 1 || w->joints > 80 || w->frames < 1 || w->frames > 80)
+        return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..80", w->joints, w->frames);
+    return PAFUSE_OK;
+}
+
+// one transformer block on the fixed-layout token matrix; `post`/`next` describe the epilogue of its fc2 GEMM
+struct BlockTail {
+    const float *post_w, *post_b;
+    float post_eps;
+    const float* pos;
+    int posJ, posF;
+    const float *next_w, *next_b;
+    float next_eps;
+    const float *head_w, *head_b;
+    float* out_head;
+};
+
+int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
+              int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
+              hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
+    int rc;
+    GemmParams g{};
+    // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
+    g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
+    if ((rc = gemm_bias(g, s))) return rc;
+    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
+    if (!gemms_only) {
+        AttnParams a{};
+        a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
+        a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
+        a.scale = 1.0f / sqrtf((float)(C / heads));  // head_dim ** -0.5                    mixste.py:52
+        if ((rc = attention(a, s))) return rc;
+    }
+    // x = x + o Wproj^T + b ; xn = LN2(x)                                               mixste.py:80,114-115
+    g = GemmParams{};
+    g.A = pb.o, g.W = bw.proj_w, g.bias = bw.proj_b, g.M = M, g.N = C, g.K = C;
+    g.resid = pb.x, g.out_x = pb.x, g.out_n = pb.xn;
+    g.next_w = bw.norm2_w, g.next_b = bw.norm2_b, g.next_eps = 1e-6f;
+    if ((rc = gemm_rowln(g, s))) return rc;
+    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
+    // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
+    g = GemmParams{};
+    g.A = pb.xn, g.W = bw.fc1_w, g.bias = bw.fc1_b, g.out = pb.wide, g.M = M, g.N = 2 * C, g.K = C, g.act = 1;
+    if ((rc = gemm_bias(g, s))) return rc;
+    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
+    // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
+    g = GemmParams{};
+    g.A = pb.wide, g.W = bw.fc2_w, g.bias = bw.fc2_b, g.M = M, g.N = C, g.K = 2 * C;
+    g.resid = pb.x, g.out_x = tail.out_head ? nullptr : pb.x, g.out_n = tail.out_head ? nullptr : pb.xn;
+    g.post_w = tail.post_w, g.post_b = tail.post_b, g.post_eps = tail.post_eps;
+    g.pos = tail.pos, g.posJ = tail.posJ, g.posF = tail.posF;
+    g.next_w = tail.next_w, g.next_b = tail.next_b, g.next_eps = tail.next_eps;
+    g.head_w = tail.head_w, g.head_b = tail.head_b, g.out_head = tail.out_head;
+    if (!tail.next_w) g.out_n = nullptr;
+    if ((rc = gemm_rowln(g, s))) return rc;
+    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
+    return PAFUSE_OK;
+}
+
+// the 2*depth blocks + head of one MixSTE2 on rows already embedded in pb.x / pb.xn; result in pb.pred [M,3]
+int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, int64_t R, hipStream_t s,
+                      bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
+    const int F = w->frames, J = w->joints, C = w->channels;
+    const int64_t M = R * F * J;
+    int rc;
+    for (int i = 0; i < w->depth; ++i) {
+        BlockTail t{};
+        // spatial block i: sequences = the J joints of one (r, f); then Spatial_norm; TTE block 0 first adds the
+        // temporal position embedding; the next LayerNorm is norm1 of temporal block i.
+        t.post_w = w->snorm_w, t.post_b = w->snorm_b, t.post_eps = 1e-6f;
+        if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
+        t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
+        if ((rc = run_block(w->ste[i], pb, M, C, w->heads, R * F, J, 1, J, 0, 1, t, s, gemms_only, flops, launches)))
+            return rc;
+        // temporal block i: sequences = the F frames of one (r, j); then Temporal_norm; next is norm1 of spatial
+        // block i+1, or the head (LayerNorm eps 1e-5 + Linear(C,3)) after the last block.
+        t = BlockTail{};
+        t.post_w = w->tnorm_w, t.post_b = w->tnorm_b, t.post_eps = 1e-6f;
+        if (i + 1 < w->depth) {
+            t.next_w = w->ste[i + 1].norm1_w, t.next_b = w->ste[i + 1].norm1_b, t.next_eps = 1e-6f;
+        } else {
+            t.next_w = w->hnorm_w, t.next_b = w->hnorm_b, t.next_eps = 1e-5f;
+            t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pb.pred;
+        }
+        if ((rc = run_block(w->tte[i], pb, M, C, w->heads, R * J, F, J, (int64_t)F * J, 1, J, t, s, gemms_only, flops,
+                            launches)))
+            return rc;
+    }
+    return PAFUSE_OK;
+}
+
+int launch_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int64_t t_scalar, int B, float* out,
+                      hipStream_t s) {
+    TimeEmbedParams p{};
+    p.t = t, p.t_scalar = t_scalar, p.freqs = w->freqs;
+    p.w1 = w->tm1_w, p.b1 = w->tm1_b, p.w3 = w->tm3_w, p.b3 = w->tm3_b, p.out = out, p.C = w->channels;
+    hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(256), (size_t)3 * w->channels * sizeof(float), s, p);
+    return check_launch("time_embed_kernel");
+}
+
+__global__ void copy_kernel(const float* src, float* dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+const char* pafuse_version(void) { return "pafuse_hip 0.1 (gfx950, f32 MFMA)"; }
+const char* pafuse_last_error(void) { return g_err; }
+
+int pafuse_linear(const float* A, const float* W, const float* bias, float* out, int64_t M, int32_t N, int32_t K,
+                  int32_t act, void* stream) {
+    if (!A || !W || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear: null pointer or negative M");
+    GemmParams g{};
+    g.A = A, g.W = W, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act;
+    return gemm_bias(g, (hipStream_t)stream);
+}
+
+int pafuse_layernorm(const float* x, const float* w, const float* b, float* out, int64_t M, int32_t C, float eps,
+                     void* stream) {
+    if (!x || !w || !b || !out || M < 0) return fail(PAFUSE_E_ARG, "layernorm: null pointer or negative M");
+    if (C <= 0 || C > 64 * LN_MAX_PER_LANE) return fail(PAFUSE_E_SHAPE, "layernorm: C=%d out of range", C);
+    if (M == 0) return PAFUSE_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, out,
+                       M, C, eps);
+    return check_launch("layernorm_kernel");
+}
+
+int pafuse_attention(const float* qkv, float* o, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group,
+                     int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void* stream) {
+    if (!qkv || !o || nseq < 0 || heads <= 0 || C % heads || group <= 0)
+        return fail(PAFUSE_E_ARG, "attention: bad argument");
+    AttnParams a{};
+    a.qkv = qkv, a.o = o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
+    a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
+    a.scale = 1.0f / sqrtf((float)(C / heads));
+    return attention(a, (hipStream_t)stream);
+}
+
+size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C) { return part_buffer_bytes(rows, C, 1); }
+
+int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int32_t L, int32_t C, int32_t heads,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!w || !x || !workspace || S < 0) return fail(PAFUSE_E_ARG, "block_forward: bad argument");
+    if (!width_supported(C)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", C);
+    const int64_t M = S * L;
+    if (workspace_bytes < pafuse_block_workspace_bytes(M, C)) return fail(PAFUSE_E_WORKSPACE, "workspace too small");
+    if (M == 0) return PAFUSE_OK;
+    hipStream_t s = (hipStream_t)stream;
+    PartBuffers pb;
+    carve_part((char*)workspace, M, C, 1, pb);
+    pb.x = x;
+    int rc = pafuse_layernorm(x, w->norm1_w, w->norm1_b, pb.xn, M, C, 1e-6f, stream);
+    if (rc) return rc;
+    BlockTail t{};  // plain Block.forward: no post norm, nothing after
+    return run_block(*w, pb, M, C, heads, S, L, 1, L, 0, 1, t, s);
+}
+
+int pafuse_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int32_t B, float* temb, void* stream) {
+    if (!w || !t || !temb || B <= 0) return fail(PAFUSE_E_ARG, "time_embed: bad argument");
+    if (w->channels % 2 || w->channels > 1024) return fail(PAFUSE_E_SHAPE, "time_embed: C=%d", w->channels);
+    return launch_time_embed(w, t, 0, B, temb, (hipStream_t)stream);
+}
+
+size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights* w, int32_t B, int32_t P) {
+    if (!w) return 0;
+    return part_buffer_bytes((int64_t)B * P * w->frames * w->joints, w->channels, B);
+}
+
+int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, const float* x3d, const int64_t* t,
+                           int32_t B, int32_t P, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!x2d || !x3d || !t || !out || !workspace || B <= 0 || P <= 0)
+        return fail(PAFUSE_E_ARG, "mixste2_forward: bad argument");
+    if (workspace_bytes < pafuse_mixste2_workspace_bytes(w, B, P)) return fail(PAFUSE_E_WORKSPACE, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t R = (int64_t)B * P, M = R * w->frames * w->joints;
+    PartBuffers pb;
+    carve_part((char*)workspace, M, w->channels, B, pb);
+    if ((rc = launch_time_embed(w, t, 0, B, pb.temb, s))) return rc;
+    EmbedParams e{};
+    e.x3d = x3d, e.x2d = x2d, e.x2d_flip = nullptr, e.joints = nullptr, e.perm = nullptr;
+    e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb.temb;
+    e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
+    e.x = pb.x, e.xn = pb.xn;
+    e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
+    e.do_clamp = 0, e.scale = 1.f;
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, e);
+    if ((rc = check_launch("embed_kernel"))) return rc;
+    if ((rc = run_mixste_layers(w, pb, R, s))) return rc;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((M * 3 + 255) / 256)), dim3(256), 0, s, pb.pred, out, M * 3);
+    return check_launch("copy_kernel");
+}
+
+size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config* cfg, int32_t B, int32_t P) {
+    if (!cfg) return 0;
+    const int nflip = cfg->flip ? 2 : 1;
+    size_t total = align_up((size_t)B * P * cfg->frames * cfg->num_kps * 3 * 4);  // img
+    for (int i = 0; i < cfg->num_parts; ++i) {
+        const pafuse_mixste2_weights& w = cfg->part[i];
+        total += part_buffer_bytes((int64_t)nflip * B * P * w.frames * w.joints, w.channels, B);
+    }
+    return total;
+}
+
+static int d3dp_check(const pafuse_d3dp_config* cfg, int B, int P) {
+    if (!cfg || B <= 0 || P <= 0) return fail(PAFUSE_E_ARG, "d3dp: bad argument");
+    if (cfg->num_parts < 1 || cfg->num_parts > PAFUSE_MAX_PARTS) return fail(PAFUSE_E_SHAPE, "num_parts %d", cfg->num_parts);
+    int total = 0;
+    for (int i = 0; i < cfg->num_parts; ++i) {
+        int rc = check_weights(&cfg->part[i]);
+        if (rc) return rc;
+        if (cfg->part[i].frames != cfg->frames) return fail(PAFUSE_E_SHAPE, "part %d: frames mismatch", i);
+        if (!cfg->part_joints[i]) return fail(PAFUSE_E_ARG, "part %d: null joint list", i);
+        total += cfg->part[i].joints;
+    }
+    if (total != cfg->num_kps) return fail(PAFUSE_E_SHAPE, "parts cover %d joints, expected %d", total, cfg->num_kps);
+    if (!cfg->joint_part || !cfg->joint_local || (cfg->flip && !cfg->flip_perm))
+        return fail(PAFUSE_E_ARG, "d3dp: null index table");
+    return PAFUSE_OK;
+}
+
+int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* steps, int32_t nsteps, const float* x2d,
+                       const float* x2d_flip, const float* noise, int32_t n_draws, int32_t B, int32_t P, float* out,
+                       void* workspace, size_t workspace_bytes, void* stream, void* const* aux_streams, int32_t n_aux) {
+    int rc = d3dp_check(cfg, B, P);
+    if (rc) return rc;
+    if (!steps || nsteps <= 0 || !x2d || !noise || !out || !workspace || (cfg->flip && !x2d_flip) || n_draws < 1)
+        return fail(PAFUSE_E_ARG, "d3dp_sample: bad argument");
+    int need = 1;
+    for (int k = 0; k < nsteps; ++k) need += steps[k].last ? 0 : 1;
+    if (n_draws < need) return fail(PAFUSE_E_ARG, "d3dp_sample: %d noise draws given, %d needed", n_draws, need);
+    if (workspace_bytes < pafuse_d3dp_workspace_bytes(cfg, B, P)) return fail(PAFUSE_E_WORKSPACE, "workspace too small");
+
+    hipStream_t s0 = (hipStream_t)stream;
+    const int nflip = cfg->flip ? 2 : 1, F = cfg->frames, J = cfg->num_kps, NP = cfg->num_parts;
+    const int64_t R = (int64_t)nflip * B * P;
+    const int64_t img_elems = (int64_t)B * P * F * J * 3;
+    char* base = (char*)workspace;
+    float* img = (float*)base;
+    base += align_up((size_t)img_elems * 4);
+    PartBuffers pb[PAFUSE_MAX_PARTS];
+    for (int i = 0; i < NP; ++i)
+        base = carve_part(base, R * F * cfg->part[i].joints, cfg->part[i].channels, B, pb[i]);
+
+    // parts are independent inside a step: spread them over the aux streams when given
+    hipStream_t ps[PAFUSE_MAX_PARTS];
+    for (int i = 0; i < NP; ++i) ps[i] = (n_aux > 0 && i > 0) ? (hipStream_t)aux_streams[(i - 1) % n_aux] : s0;
+    const bool multi = n_aux > 0 && NP > 1;
+    hipEvent_t ev_fork = nullptr, ev_join[PAFUSE_MAX_PARTS] = {};
+    if (multi) {
+        hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        for (int i = 1; i < NP; ++i) hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
+    }
+
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((img_elems + 255) / 256)), dim3(256), 0, s0, noise, img, img_elems);
+    if ((rc = check_launch("copy_kernel"))) return rc;
+    int draw = 1;
+    for (int k = 0; k < nsteps && rc == PAFUSE_OK; ++k) {
+        const pafuse_ddim_step& st = steps[k];
+        if (multi) {
+            hipEventRecord(ev_fork, s0);
+            for (int i = 1; i < NP; ++i) hipStreamWaitEvent(ps[i], ev_fork, 0);
+        }
+        for (int i = 0; i < NP && rc == PAFUSE_OK; ++i) {
+            const pafuse_mixste2_weights* w = &cfg->part[i];
+            if ((rc = launch_time_embed(w, nullptr, st.time, B, pb[i].temb, ps[i]))) break;
+            EmbedParams e{};
+            e.x3d = img, e.x2d = x2d, e.x2d_flip = x2d_flip, e.joints = cfg->part_joints[i], e.perm = cfg->flip_perm;
+            e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb[i].temb;
+            e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
+            e.x = pb[i].x, e.xn = pb[i].xn;
+            e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
+            e.do_clamp = 1, e.scale = cfg->scale;
+            const int64_t M = R * F * w->joints;
+            hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, ps[i], e);
+            if ((rc = check_launch("embed_kernel"))) break;
+            rc = run_mixste_layers(w, pb[i], R, ps[i]);
+        }
+        if (rc) break;
+        if (multi)
+            for (int i = 1; i < NP; ++i) {
+                hipEventRecord(ev_join[i], ps[i]);
+                hipStreamWaitEvent(s0, ev_join[i], 0);
+            }
+        FinalizeParams f{};
+        for (int i = 0; i < NP; ++i) f.pred[i] = pb[i].pred, f.Jp[i] = cfg->part[i].joints;
+        f.joint_part = cfg->joint_part, f.joint_local = cfg->joint_local, f.perm = cfg->flip_perm;
+        f.img = img, f.noise = st.last ? nullptr : noise + (int64_t)draw * img_elems, f.out = out;
+        f.B = B, f.P = P, f.F = F, f.J = J, f.T = nsteps, f.step = k, f.flip = cfg->flip, f.last = st.last;
+        f.scale = cfg->scale, f.sr = st.sqrt_recip_acp, f.srm1 = st.sqrt_recipm1_acp, f.c = st.c;
+        f.an_f = (float)st.sqrt_alpha_next, f.c_f = (float)st.c, f.sigma_f = (float)st.sigma;
+        const int64_t n = (int64_t)B * P * F * J;
+        hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s0, f);
+        rc = check_launch("finalize_kernel");
+        if (!st.last) ++draw;
+    }
+    if (multi) {
+        hipEventDestroy(ev_fork);
+        for (int i = 1; i < NP; ++i) hipEventDestroy(ev_join[i]);
+    }
+    return rc;
+}
+
+int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, void* workspace,
+                             size_t workspace_bytes, void* stream, double* flops) {
+    int rc = d3dp_check(cfg, B, P);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < pafuse_d3dp_workspace_bytes(cfg, B, P))
+        return fail(PAFUSE_E_WORKSPACE, "workspace too small");
+    const int nflip = cfg->flip ? 2 : 1;
+    const int64_t R = (int64_t)nflip * B * P;
+    char* base = (char*)workspace + align_up((size_t)B * P * cfg->frames * cfg->num_kps * 3 * 4);
+    int launches = 0;
+    double fl = 0.0;
+    for (int i = 0; i < cfg->num_parts; ++i) {
+        PartBuffers pb;
+        base = carve_part(base, R * cfg->frames * cfg->part[i].joints, cfg->part[i].channels, B, pb);
+        if ((rc = run_mixste_layers(&cfg->part[i], pb, R, (hipStream_t)stream, true, &fl, &launches))) return rc;
+    }
+    if (flops) *flops += fl;
+    return launches;
+}
+
+}  // extern "C"

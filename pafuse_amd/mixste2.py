@@ -1,0 +1,147 @@
+"""MixSTE2 - drop-in for the reference denoiser (common/mixste.py:141-298) backed by the HIP library.
+
+The module owns exactly the reference's parameters (same names, shapes, creation order and default init, so
+``torch.manual_seed(s); MixSTE2(...)`` yields the reference's weights and ``load_state_dict`` accepts its
+checkpoints), but has no per-layer Python forward: ``forward`` hands raw device pointers to
+``pafuse_mixste2_forward`` (include/pafuse_hip.h), which runs the fused gfx950 kernels.
+"""
+import ctypes as C
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _AttentionParams(nn.Module):
+    """qkv / proj of common/mixste.py:46-61 (parameters only)."""
+
+    def __init__(self, dim, qkv_bias):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _MlpParams(nn.Module):
+    """fc1 / fc2 of common/mixste.py:24-35 (parameters only)."""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _BlockParams(nn.Module):
+    """norm1, attn, norm2, mlp of common/mixste.py:84-103 (parameters only, in the reference's creation order)."""
+
+    def __init__(self, dim, mlp_ratio, qkv_bias, norm_layer):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = _AttentionParams(dim, qkv_bias)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _MlpParams(dim, int(dim * mlp_ratio))
+
+
+def sinusoid_frequencies(dim):
+    """omega table of SinusoidalPositionEmbeddings (common/mixste.py:134-136), evaluated by the same CPU ops."""
+    half = dim // 2
+    step = math.log(10000) / (half - 1)
+    return torch.exp(torch.arange(half) * -step)
+
+
+def _ptr(t, what):
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise _lib.PafuseError(f"{what}: expected a contiguous fp32 tensor on the HIP device, got "
+                               f"{t.dtype} contiguous={t.is_contiguous()} device={t.device}")
+    return t.data_ptr()
+
+
+class MixSTE2(nn.Module):
+    def __init__(self, num_frame=9, num_joints=17, in_chans=5, embed_dim_ratio=32, depth=4,
+                 num_heads=8, mlp_ratio=2., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None, is_train=True):
+        super().__init__()
+        if qk_scale is not None or not qkv_bias or mlp_ratio != 2.0 or drop_rate or attn_drop_rate:
+            raise NotImplementedError("the HIP path implements the PAFUSE configuration: qkv_bias=True, "
+                                      "qk_scale=None, mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        C_ = embed_dim_ratio
+        self.is_train = is_train
+        self.num_frame, self.num_joints, self.in_chans = num_frame, num_joints, in_chans
+        self.embed_dim, self.block_depth, self.num_heads = C_, depth, num_heads
+        self.drop_path_rate = drop_path_rate
+
+        self.Spatial_patch_to_embedding = nn.Linear(in_chans, C_)
+        self.Spatial_pos_embed = nn.Parameter(torch.zeros(1, num_joints, C_))
+        self.Temporal_pos_embed = nn.Parameter(torch.zeros(1, num_frame, C_))
+        # index 0 stands for the parameter-free sinusoid, 2 for GELU: keys time_mlp.1.* / time_mlp.3.*
+        self.time_mlp = nn.Sequential(nn.Identity(), nn.Linear(C_, C_ * 2), nn.GELU(), nn.Linear(C_ * 2, C_))
+        self.STEblocks = nn.ModuleList([_BlockParams(C_, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.TTEblocks = nn.ModuleList([_BlockParams(C_, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.Spatial_norm = norm_layer(C_)
+        self.Temporal_norm = norm_layer(C_)
+        self.head = nn.Sequential(nn.LayerNorm(C_), nn.Linear(C_, 3))
+        self.register_buffer("_freqs", sinusoid_frequencies(C_), persistent=False)
+        self._wcache = None
+
+    # ------------------------------------------------------------------------------------------- C structs
+    def weights_struct(self):
+        """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes)."""
+        params = [p for p in self.parameters()] + [self._freqs]
+        key = tuple(p.data_ptr() for p in params)
+        if self._wcache is not None and self._wcache[0] == key:
+            return self._wcache[1]
+        if self.block_depth > _lib.MAX_DEPTH:
+            raise _lib.PafuseError(f"depth {self.block_depth} > {_lib.MAX_DEPTH}")
+        w = _lib.MixSTE2Weights()
+        w.frames, w.joints, w.channels = self.num_frame, self.num_joints, self.embed_dim
+        w.depth, w.heads, w.in_chans = self.block_depth, self.num_heads, self.in_chans
+        w.patch_w = _ptr(self.Spatial_patch_to_embedding.weight, "patch weight")
+        w.patch_b = _ptr(self.Spatial_patch_to_embedding.bias, "patch bias")
+        w.pos_spatial = _ptr(self.Spatial_pos_embed, "Spatial_pos_embed")
+        w.pos_temporal = _ptr(self.Temporal_pos_embed, "Temporal_pos_embed")
+        w.tm1_w, w.tm1_b = _ptr(self.time_mlp[1].weight, "time_mlp.1"), _ptr(self.time_mlp[1].bias, "time_mlp.1")
+        w.tm3_w, w.tm3_b = _ptr(self.time_mlp[3].weight, "time_mlp.3"), _ptr(self.time_mlp[3].bias, "time_mlp.3")
+        w.freqs = _ptr(self._freqs, "freqs")
+        w.snorm_w, w.snorm_b = _ptr(self.Spatial_norm.weight, "Spatial_norm"), _ptr(self.Spatial_norm.bias, "Spatial_norm")
+        w.tnorm_w, w.tnorm_b = _ptr(self.Temporal_norm.weight, "Temporal_norm"), _ptr(self.Temporal_norm.bias, "Temporal_norm")
+        w.hnorm_w, w.hnorm_b = _ptr(self.head[0].weight, "head.0"), _ptr(self.head[0].bias, "head.0")
+        w.head_w, w.head_b = _ptr(self.head[1].weight, "head.1"), _ptr(self.head[1].bias, "head.1")
+        for dst, blocks in ((w.ste, self.STEblocks), (w.tte, self.TTEblocks)):
+            for i, blk in enumerate(blocks):
+                fill_block_struct(dst[i], blk)
+        self._wcache = (key, w)
+        return w
+
+    # ---------------------------------------------------------------------------------------------- forward
+    def forward(self, x_2d, x_3d, t):
+        """x_2d [B,F,J,2], x_3d [B,P,F,J,3], t [B] int64 -> [B,P,F,J,3]  (common/mixste.py:278-298, eval)."""
+        if self.is_train:
+            raise NotImplementedError("training forward/backward is a 'next' row (SURVEY.md section 8f n2)")
+        lib = _lib.load()
+        if not x_3d.is_cuda:
+            raise _lib.PafuseError("MixSTE2 runs on the HIP device only (no CPU fallback)")
+        B, P, F, J, _ = x_3d.shape
+        assert (F, J) == (self.num_frame, self.num_joints) and x_2d.shape == (B, F, J, 2) and t.shape == (B,)
+        x_2d = x_2d.contiguous().float()
+        x_3d = x_3d.contiguous().float()
+        t = t.contiguous().long()
+        w = self.weights_struct()
+        out = torch.empty(B, P, F, J, 3, device=x_3d.device, dtype=torch.float32)
+        nbytes = lib.pafuse_mixste2_workspace_bytes(C.byref(w), B, P)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x_3d.device)
+        stream = torch.cuda.current_stream(x_3d.device).cuda_stream
+        _lib.check(lib.pafuse_mixste2_forward(C.byref(w), x_2d.data_ptr(), x_3d.data_ptr(), t.data_ptr(), B, P,
+                                              out.data_ptr(), ws.data_ptr(), nbytes, stream))
+        return out
+
+
+def fill_block_struct(dst, blk):
+    dst.norm1_w, dst.norm1_b = _ptr(blk.norm1.weight, "norm1"), _ptr(blk.norm1.bias, "norm1")
+    dst.qkv_w, dst.qkv_b = _ptr(blk.attn.qkv.weight, "qkv"), _ptr(blk.attn.qkv.bias, "qkv")
+    dst.proj_w, dst.proj_b = _ptr(blk.attn.proj.weight, "proj"), _ptr(blk.attn.proj.bias, "proj")
+    dst.norm2_w, dst.norm2_b = _ptr(blk.norm2.weight, "norm2"), _ptr(blk.norm2.bias, "norm2")
+    dst.fc1_w, dst.fc1_b = _ptr(blk.mlp.fc1.weight, "fc1"), _ptr(blk.mlp.fc1.bias, "fc1")
+    dst.fc2_w, dst.fc2_b = _ptr(blk.mlp.fc2.weight, "fc2"), _ptr(blk.mlp.fc2.bias, "fc2")

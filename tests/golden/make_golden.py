@@ -284,11 +284,21 @@ def g7_metrics():
          j_agg=mpjpe_diffusion_reproj(pred, target, reproj, target_2d))
 
 
+# -------------------------------------------------------------------------------------------------- G8
+def g8_default_init():
+    """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
+    from common.mixste import MixSTE2
+    torch.manual_seed(123)
+    m = MixSTE2(num_frame=27, num_joints=42, in_chans=5, embed_dim_ratio=256, depth=2, num_heads=8,
+                drop_path_rate=0.0, is_train=False)
+    save("g8_init.npz", sha=np.frombuffer(gu.sha256_of(m.state_dict()), dtype=np.uint8))
+
+
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
-                 g6=g6_index_ops, g7=g7_metrics)
+                 g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init)
     for w in which:
         table[w]()

@@ -1,0 +1,230 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Tolerances (fp32 path): pointwise 2e-5 on O(1) activations after 16 blocks (summation order differs from
+ATen's); 1e-4 mm on every MPJPE aggregate (the north-star bar; model units are metres, x1000 = mm).
+"""
+import pytest
+import torch
+
+from oracle import d3dp_oracle as orc
+from tests.conftest import load_golden
+from tests.golden import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _seeded(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ------------------------------------------------------------------------------------------------ unit ops
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 1152, 384), (77, 384, 768), (300, 672, 224),
+                                   (129, 448, 224), (64, 768, 256), (1, 512, 256), (50, 96, 64), (33, 32, 32)])
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_linear(M, N, K, act):
+    from pafuse_amd import ops
+    x, w, b = _seeded((M, K), 1), _seeded((N, K), 2, K ** -0.5), _seeded((N,), 3, 0.1)
+    ref = torch.nn.functional.linear(x, w, b)
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act).cpu()
+    assert torch.allclose(out, ref, rtol=0, atol=3e-6), (out - ref).abs().max()
+
+
+def test_linear_exact_integers():
+    """A = I-like and asymmetric integer W: catches any row/col or k-permutation slip exactly."""
+    from pafuse_amd import ops
+    M, N, K = 96, 224, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
+    b = torch.arange(N).float()
+    out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+    assert torch.equal(out, x @ w.t() + b)
+
+
+@pytest.mark.parametrize("C,eps", [(384, 1e-6), (224, 1e-5), (256, 1e-6), (64, 1e-6)])
+def test_layernorm(C, eps):
+    from pafuse_amd import ops
+    x, w, b = _seeded((37, C), 1, 2.0) + 0.5, 1 + _seeded((C,), 2, 0.1), _seeded((C,), 3, 0.1)
+    ref = torch.nn.functional.layer_norm(x, (C,), w, b, eps)
+    out = ops.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), eps).cpu()
+    assert torch.allclose(out, ref, rtol=0, atol=2e-6)
+
+
+def _attn_ref(qkv, S, L, heads):
+    C = qkv.shape[-1] // 3
+    d = C // heads
+    q, k, v = qkv.view(S, L, 3, heads, d).permute(2, 0, 3, 1, 4)
+    w = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1)
+    return (w @ v).transpose(1, 2).reshape(S * L, C)
+
+
+@pytest.mark.parametrize("L,C", [(24, 384), (27, 384), (68, 224), (27, 224), (42, 256), (27, 256), (5, 64), (80, 384)])
+def test_attention_contiguous(L, C):
+    from pafuse_amd import ops
+    S, heads = 7, 8
+    qkv = _seeded((S * L, 3 * C), 11)
+    out = ops.attention(qkv.to(DEV), heads, S, L).cpu()
+    ref = _attn_ref(qkv, S, L, heads)
+    assert torch.allclose(out, ref, rtol=0, atol=2e-6), (out - ref).abs().max()
+
+
+def test_attention_temporal_strides():
+    """temporal addressing: sequence (r, j) = rows (r*F + f)*J + j."""
+    from pafuse_amd import ops
+    R, F, J, C, heads = 3, 27, 24, 384, 8
+    qkv = _seeded((R * F * J, 3 * C), 12)
+    out = ops.attention(qkv.to(DEV), heads, R * J, F, group=J, group_stride=F * J, seq_stride=1, tok_stride=J).cpu()
+    seqs = qkv.view(R, F, J, 3 * C).permute(0, 2, 1, 3).reshape(R * J * F, 3 * C)
+    ref = _attn_ref(seqs, R * J, F, heads).view(R, J, F, C).permute(0, 2, 1, 3).reshape(R * F * J, C)
+    assert torch.allclose(out, ref, rtol=0, atol=2e-6)
+
+
+def test_g3_time_embed_golden():
+    import pafuse_amd
+    from pafuse_amd import ops
+    z = load_golden("g3_time_mlp.npz")
+    for part, C in gu.PART_WIDTH.items():
+        m = pafuse_amd.MixSTE2(2, 2, 5, C, 1, 8, drop_path_rate=0.0, is_train=False)
+        sd = {k: gu.seeded_tensor(f"g3.{part}.time_mlp.{k}", v.shape, 31) for k, v in m.time_mlp.state_dict().items()}
+        assert gu.sha256_of(sd) == z[f"{part}.sha"].numpy().tobytes()
+        m.time_mlp.load_state_dict(sd)
+        out = ops.time_embed(m.to(DEV), z["t"].to(DEV)).cpu()
+        assert torch.allclose(out, z[f"{part}.out"], rtol=0, atol=5e-6), (part, (out - z[f"{part}.out"]).abs().max())
+
+
+def test_g4_blocks_golden():
+    from functools import partial
+    from pafuse_amd import ops
+    from pafuse_amd.mixste2 import _BlockParams
+    z = load_golden("g4_blocks.npz")
+    for part, C in gu.PART_WIDTH.items():
+        blk = _BlockParams(C, 2.0, True, partial(torch.nn.LayerNorm, eps=1e-6))
+        sd = gu.seeded_like(blk.state_dict(), seed=41, prefix=f"g4.{part}.")
+        assert gu.sha256_of(sd) == z[f"{part}.sha"].numpy().tobytes()
+        blk.load_state_dict(sd)
+        blk = blk.to(DEV)
+        for tag in ("s", "t"):
+            y = ops.block_forward(blk, z[f"{part}.x{tag}"].to(DEV)).cpu()
+            ref = z[f"{part}.y{tag}"]
+            assert torch.allclose(y, ref, rtol=0, atol=1e-5), (part, tag, (y - ref).abs().max())
+
+
+# --------------------------------------------------------------------------------------- denoiser and loop
+@pytest.fixture(scope="module")
+def g5():
+    from __graft_entry__ import make_model
+    z = load_golden("g5_d3dp.npz")
+    model, sd = make_model(2, 2, seed=51)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    return z, model, sd
+
+
+def test_g5_part_denoisers_golden(g5):
+    z, model, sd = g5
+    x2d, _ = gu.synthetic_inputs_2d(B=1)
+    t = torch.tensor([499], device=DEV)
+    for part, idx in model.parts_joint_indices.items():
+        out = model.pose_estimator[part](x2d[..., idx, :].to(DEV), z["part_x3d"][..., idx, :].to(DEV), t).cpu()
+        ref = z[f"part.{part}"]
+        assert torch.allclose(out, ref, rtol=0, atol=2e-5), (part, (out - ref).abs().max())
+
+
+def test_g5_flip_loop_golden(g5):
+    z, model, sd = g5
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=2, n=2, seed=1)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    assert out.shape == (1, 2, 2, 27, 134, 3)
+    assert torch.allclose(out, z["flip_out"], rtol=0, atol=5e-5), (out - z["flip_out"]).abs().max()
+
+
+def test_g5_p1t1_both_samplers_golden(g5):
+    from __graft_entry__ import make_model
+    z, _, sd = g5
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    n1 = gu.synthetic_noises(B=1, P=1, n=1, seed=2)
+    for flip, key in ((False, "noflip_out"), (True, "flip11_out")):
+        m, _ = make_model(1, 1, seed=51, flip=flip)
+        m.noise_fn = lambda k, shape, device: n1[k]
+        out = m(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV) if flip else None).cpu()
+        assert torch.allclose(out, z[key], rtol=0, atol=5e-5), (key, (out - z[key]).abs().max())
+
+
+def _mpjpe_report(pred, target, x2d):
+    """J-Best / P-Best / P-Agg / J-Agg in mm on whole-body poses (reference main_h3wb.py:327-348)."""
+    pred = orc.wb_pose_from_parts(pred.clone())
+    target = orc.wb_pose_from_parts(target.clone())
+    B, T, P, F = pred.shape[:4]
+    cam = torch.tensor([[2.29, 2.287, 0.025, 0.029, -0.207, 0.247, -0.003, -0.0009, -0.001]])
+    traj = torch.tensor([0.0, 0.0, 4.0])
+    reproj = orc.project_to_2d((pred + traj).reshape(-1, 134, 3), cam.repeat(B * T * P * F, 1)).reshape(B, T, P, F, 134, 2)
+    return {"J-Best": orc.j_best(pred, target) * 1000, "P-Best": orc.p_best(pred, target) * 1000,
+            "P-Agg": orc.p_agg(pred, target) * 1000, "J-Agg": orc.j_agg(pred, target, reproj, x2d) * 1000}
+
+
+@pytest.mark.parametrize("B,P,T", [(1, 5, 5), (2, 3, 2)])
+def test_loop_vs_oracle_mpjpe(B, P, T):
+    """BASELINE configs[1] shape (P=5, T=5) in the fp32 path, and a B>1 case: pointwise and MPJPE parity."""
+    from __graft_entry__ import make_model
+    model, sd = make_model(P, T, seed=77)
+    x2d, x2f = gu.synthetic_inputs_2d(B=B, seed=1234)
+    noises = gu.synthetic_noises(B=B, P=P, n=T, seed=3)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    ref = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    assert torch.allclose(out, ref, rtol=0, atol=1e-4), (out - ref).abs().max()
+    target = orc.center_pose_parts(gu.synthetic_target_3d(B))
+    got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
+    for k in want:
+        assert (got[k] - want[k]).abs().max() <= 1e-4, (k, got[k], want[k])       # mm
+
+
+def test_noflip_multistep_vs_oracle():
+    """ddim_sample (no TTA): works for any P here; the reference itself only runs it at P=1."""
+    from __graft_entry__ import make_model
+    model, sd = make_model(3, 3, seed=78, flip=False)
+    x2d, _ = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=3, n=3, seed=4)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None).cpu()
+    ref = orc.ddim_sample(sd, x2d, noises, 3)
+    assert torch.allclose(out, ref, rtol=0, atol=1e-4), (out - ref).abs().max()
+
+
+def test_hypothesis_axis_is_independent():
+    """size-independent property used at full size: a hypothesis' trajectory does not depend on the others, so
+    running P=4 equals running its two halves (this is what makes the 8-GPU sharding exact)."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(4, 2, seed=79)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=4, n=2, seed=5)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    full = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    halves = []
+    for lo, hi in ((0, 2), (2, 4)):
+        model.proposal_shard = (lo, hi)
+        halves.append(model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)))
+    model.proposal_shard = None
+    assert torch.equal(full, torch.cat(halves, dim=2))
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()
+
+
+def test_errors_are_loud():
+    import pafuse_amd
+    from pafuse_amd import _lib, ops
+    with pytest.raises(_lib.PafuseError):
+        ops.linear(torch.zeros(4, 33, device=DEV), torch.zeros(32, 33, device=DEV), torch.zeros(32, device=DEV))
+    m = pafuse_amd.MixSTE2(3, 5, 5, 16, 2, 8, drop_path_rate=0.0, is_train=False).to(DEV)
+    with pytest.raises(_lib.PafuseError):       # width 16 has no kernel: refuse, never fall back
+        m(torch.zeros(1, 3, 5, 2, device=DEV), torch.zeros(1, 1, 3, 5, 3, device=DEV), torch.zeros(1, dtype=torch.long, device=DEV))
+    with pytest.raises(_lib.PafuseError):       # CPU tensors: no CPU fallback
+        pafuse_amd.MixSTE2(27, 24, 5, 384, 1, 8, drop_path_rate=0.0, is_train=False)(
+            torch.zeros(1, 27, 24, 2), torch.zeros(1, 1, 27, 24, 3), torch.zeros(1, dtype=torch.long))

@@ -1,0 +1,89 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every declared symbol; the module
+mirrors keep the reference's state-dict layout and initialisation; host-side schedule scalars match golden."""
+import os
+import re
+
+import pytest
+import torch
+
+from tests.conftest import ROOT, load_golden
+from tests.golden import golden_util as gu
+
+
+def _built():
+    import __graft_entry__ as g
+    g.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _built()
+    from pafuse_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "pafuse_hip.h")).read()
+    declared = set(re.findall(r"\b(pafuse_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.pafuse_version()
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes mirrors must have the C layout: check against sizes computed by the C compiler."""
+    import ctypes, subprocess, tempfile
+    from pafuse_amd import _lib
+    src = '#include "pafuse_hip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n",' \
+          'sizeof(pafuse_block_weights),sizeof(pafuse_mixste2_weights),sizeof(pafuse_d3dp_config),' \
+          'sizeof(pafuse_ddim_step));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [ctypes.sizeof(_lib.BlockWeights), ctypes.sizeof(_lib.MixSTE2Weights),
+                     ctypes.sizeof(_lib.D3DPConfig), ctypes.sizeof(_lib.DDIMStep)]
+
+
+def test_state_dict_layout_matches_reference():
+    from __graft_entry__ import make_model
+    from tests.golden.state_template import d3dp_template
+    model, sd = make_model(2, 2, device="cpu")
+    tmpl = d3dp_template()
+    got = model.state_dict()
+    assert len(got) == 636 and set(got) == set(tmpl)
+    for k, v in tmpl.items():
+        assert tuple(got[k].shape) == tuple(v.shape) and got[k].dtype == v.dtype, k
+    assert gu.sha256_of(sd) == load_golden("g5_d3dp.npz")["sha"].numpy().tobytes()
+    # DataParallel checkpoints: module.-prefixed keys load after stripping
+    model.load_state_dict({k[7:]: v for k, v in {"module." + k: v for k, v in sd.items()}.items()})
+
+
+def test_schedule_buffers_and_step_scalars_match_golden():
+    from __graft_entry__ import make_model
+    z = load_golden("g2_schedule.npz")
+    for T in (1, 5, 10):
+        model, _ = make_model(1, T, device="cpu")
+        for k in ("betas", "alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                  "posterior_mean_coef2", "posterior_log_variance_clipped"):
+            assert torch.equal(getattr(model, k), z["buf." + k]), k
+        assert model.time_pairs() == [tuple(p) for p in z[f"pairs.{T}"].tolist()]
+        steps = model.ddim_steps()
+        coefs = [[s.sqrt_alpha_next, s.c, s.sigma] for s in steps if not s.last]
+        assert torch.equal(torch.tensor(coefs, dtype=torch.float64).reshape(-1, 3), z[f"coefs.{T}"])
+        assert steps[len(steps) - 1].last == 1 and steps[0].time == 999
+
+
+def test_default_init_matches_reference_rng_order():
+    """torch.manual_seed(s); MixSTE2(...) must draw the reference's initial weights (same creation order)."""
+    import pafuse_amd
+    z = load_golden("g8_init.npz")
+    torch.manual_seed(123)
+    m = pafuse_amd.MixSTE2(num_frame=27, num_joints=42, in_chans=5, embed_dim_ratio=256, depth=2, num_heads=8,
+                           drop_path_rate=0.0, is_train=False)
+    assert gu.sha256_of(m.state_dict()) == z["sha"].numpy().tobytes()
+
+
+def test_cpu_call_raises_not_falls_back():
+    import pafuse_amd
+    from pafuse_amd import _lib
+    m = pafuse_amd.MixSTE2(27, 24, 5, 384, 1, 8, drop_path_rate=0.0, is_train=False)
+    with pytest.raises(_lib.PafuseError):
+        m(torch.zeros(1, 27, 24, 2), torch.zeros(1, 1, 27, 24, 3), torch.zeros(1, dtype=torch.long))
