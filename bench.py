@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py - hypotheses/sec through the D3DP DDIM loop on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one full D3DP.forward: T=10 DDIM steps with flip-TTA over one synthetic batch of B=1 H3WB clip
+(27 frames x 134 keypoints) and P=20 hypotheses per GPU (BASELINE configs[2]: "H3WB paper setting, P=20 T=10").
+Inputs, weights and noise are resident in HBM before the timed region.  With N > 1 the hypothesis axis is
+sharded (weak scaling: P = 20*N, 20 per rank) and every step ends with the single RCCL all-gather of the
+per-rank predictions.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      the dominant kernel (f32-MFMA linear-layer GEMM, `gemm_kernel`): algorithmic FLOPs of the 192 GEMM
+                launches of one flip-TTA denoiser pass divided by their HIP-event time (launched back to back on
+                the stream torch uses), against the 157.3 TFLOP/s dense f32 matrix peak.
+  roofline_loop the same fraction for the whole timed loop (2*T*69.38 GFLOP per hypothesis, everything included).
+  cpu_baseline  the CPU oracle (a port of the reference's ATen path, oracle/) timed on the host cores of this box
+                on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md section 3 (one denoiser pass)
+PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--proposals", type=int, default=20, help="hypotheses per GPU")
+    ap.add_argument("--timesteps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1, help="clips per forward")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from tests.golden import golden_util as gu
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    ge.build()
+    from pafuse_amd import _lib
+    from pafuse_amd.parallel import ShardedSampler
+    import ctypes as C
+
+    B, T, P_local = args.batch, args.timesteps, args.proposals
+    P_total = P_local * world
+    model, sd = ge.make_model(P_total, T, seed=51, device=dev)
+    if args.streams > 0:
+        model.aux_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+    sampler = ShardedSampler(model)
+    x2d, x2f = gu.synthetic_inputs_2d(B=B)
+    x2d, x2f = x2d.to(dev), x2f.to(dev)
+    torch.manual_seed(1234)                  # identical on every rank: each draws the full-P noise, keeps its slice
+
+    def step():
+        return sampler(x2d, None, input_2d_flip=x2f)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert out.shape == (B, T, P_total, 27, 134, 3) and bool(torch.isfinite(out).all())
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    sec_per_step = elapsed / args.steps
+    value = B * P_total / sec_per_step
+    loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
+
+    line = {
+        "metric": "hypotheses/sec through DDIM loop (H3WB 133-kp, P=20, T=10)",
+        "value": round(value, 3), "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"D3DP.forward flip-TTA DDIM loop, H3WB 27x134 clips, B={B}, P={P_local}/GPU "
+                               f"(P={P_total} total), T={T}, part-based MixSTE2 body/face/hands 384/224/256 ch, depth 8",
+                   "B": B, "P_per_gpu": P_local, "P_total": P_total, "T": T, "flip_tta": True,
+                   "parallelism": f"hypothesis-sharded x{world} + 1 all-gather" if world > 1 else "single GPU",
+                   "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
+        "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(loop_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                          "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"},
+    }
+
+    # ---- dominant kernel: the 192 linear-layer GEMM launches of one flip-TTA denoiser pass, HIP-event timed ----
+    if not args.no_roofline and rank == 0:
+        lib = _lib.load()
+        cfg = model.config_struct(True)
+        nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P_local)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        reps = 3
+        flops = C.c_double(0.0)
+        launches = _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
+                                                           stream.cuda_stream, C.byref(flops)))       # warm-up
+        torch.cuda.synchronize(dev)
+        flops = C.c_double(0.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
+                                                    stream.cuda_stream, C.byref(flops)))
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        n = launches * reps
+        achieved = flops.value / (ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": "pafuse::gemm_kernel (v_mfma_f32_32x32x2_f32)",
+                            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
+                            "flops_per_launch": round(flops.value / n / 1e9, 3),
+                            "flops_unit": "GFLOP (algorithmic 2*M*N*K)"}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------------------
+    if not args.no_cpu_baseline and rank == 0:
+        from oracle import d3dp_oracle as orc
+        cores = torch.get_num_threads()
+        Pc, Tc = 2, 2
+        noises = gu.synthetic_noises(B=1, P=Pc, n=Tc, seed=9)
+        xc, xcf = gu.synthetic_inputs_2d(B=1)
+        orc.ddim_sample(sd, xc, gu.synthetic_noises(B=1, P=1, n=1, seed=9), 1, gu.SYN_JOINTS_LEFT,
+                        gu.SYN_JOINTS_RIGHT, inputs_2d_flip=xcf)                                   # warm-up
+        t0 = time.perf_counter()
+        orc.ddim_sample(sd, xc, noises, Tc, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=xcf)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(Pc * Tc / dt / T, 4), "unit": "hypotheses/s", "cores": cores,
+                                "kind": "port",
+                                "sample": f"oracle/d3dp_oracle.py (torch CPU fp32) flip-TTA loop B=1 P={Pc} T={Tc} = "
+                                          f"{Pc * Tc} hypothesis-steps in {dt:.2f} s, scaled to T={T}"}
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -120,7 +120,8 @@ def sinusoid_frequencies(dim: int) -> Tensor:
 
 def timestep_embedding(sd: Dict[str, Tensor], pre: str, t: Tensor, dim: int) -> Tensor:
     """sinusoid -> Linear -> GELU(erf) -> Linear (reference common/mixste.py:127-139, 179-184); t int64 [B]."""
-    arg = t[:, None] * sinusoid_frequencies(dim)[None, :]
+    arg = t[:, None] * sinusoid_frequencies(dim)[None, :]          # fp32 product, as the reference forms it
+    arg = arg.to(sd[pre + "time_mlp.1.weight"].dtype)              # (fp64 only for the error-budget runs)
     emb = torch.cat((arg.sin(), arg.cos()), dim=-1)
     hid = F.gelu(F.linear(emb, sd[pre + "time_mlp.1.weight"], sd[pre + "time_mlp.1.bias"]))
     return F.linear(hid, sd[pre + "time_mlp.3.weight"], sd[pre + "time_mlp.3.bias"])
