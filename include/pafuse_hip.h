@@ -113,8 +113,9 @@ size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C);
 int pafuse_block_forward(const pafuse_block_weights *w, float *x, int64_t S, int32_t L, int32_t C, int32_t heads,
                          void *workspace, size_t workspace_bytes, void *stream);
 
-/* temb[B,C] = time_mlp(t[B]) */
-int pafuse_time_embed(const pafuse_mixste2_weights *w, const int64_t *t, int32_t B, float *temb, void *stream);
+/* temb[B,C] = time_mlp(t[B]);  hid_scratch: [B,2C] floats of device scratch */
+int pafuse_time_embed(const pafuse_mixste2_weights *w, const int64_t *t, int32_t B, float *temb, float *hid_scratch,
+                      void *stream);
 
 /* MixSTE2.forward, eval: x2d[B,F,J,2], x3d[B,P,F,J,3], t[B] -> out[B,P,F,J,3]. */
 size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights *w, int32_t B, int32_t P);

@@ -86,8 +86,7 @@ template <int WM, int WN, int NT, int EPI, int NSTAGE>
 __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
-    constexpr int A_LD = BM * 8 / NTHR, W_LD = BN * 8 / NTHR;
-    static_assert((BM * 8) % NTHR == 0 && (BN * 8) % NTHR == 0, "staging must divide evenly");
+    constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;  // float4 per thread per chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Ws = smem + NSTAGE * BM * LDK;
@@ -96,7 +95,14 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int tiles_n = p.N / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
+    // contiguous run of tiles - the N-tiles of one M-tile then hit the same L2 for their A rows (speed only).
+    int tile;
+    {
+        const int nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, rem = nb & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
     const int K = p.K;
@@ -105,7 +111,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     int a_dst[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int idx = tid + i * NTHR, row = idx >> 3, c4 = idx & 7;
+        int idx = tid + i * NTHR;
+        idx = idx < BM * 8 ? idx : BM * 8 - 1;  // surplus threads duplicate the last float4 (same value, same slot)
+        const int row = idx >> 3, c4 = idx & 7;
         int64_t gm = m0 + row;
         gm = gm < p.M ? gm : p.M - 1;  // tail rows read a valid row; their results are never stored
         a_src[i] = p.A + gm * K + c4 * 4;
@@ -115,7 +123,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     int w_dst[W_LD];
 #pragma unroll
     for (int i = 0; i < W_LD; ++i) {
-        const int idx = tid + i * NTHR, row = idx >> 3, c4 = idx & 7;
+        int idx = tid + i * NTHR;
+        idx = idx < BN * 8 ? idx : BN * 8 - 1;
+        const int row = idx >> 3, c4 = idx & 7;
         w_src[i] = p.W + (int64_t)(n0 + row) * K + c4 * 4;
         w_dst[i] = row * LDK + c4 * 4;
     }
@@ -150,6 +160,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
         }
         const float* Ac = As + cur * BM * LDK + a_frag;
         const float* Wc = Ws + cur * BN * LDK + w_frag;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 af = *reinterpret_cast<const f32x4*>(Ac + 8 * g);
@@ -162,6 +173,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
                 for (int nt = 0; nt < NT; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         if (NSTAGE == 1) __syncthreads();  // everyone done reading before the single buffer is refilled
         if (more) {
             const int nxt = (NSTAGE == 2) ? (cur ^ 1) : 0;
@@ -174,143 +186,158 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     }
 
     // accumulator element (nt, reg) of this lane is  row = (reg&3) + 8*(reg>>2) + 4*h,  col = 32*nt + r  of the strip
-    if (EPI == EPI_BIAS) {
+    if constexpr (EPI == EPI_BIAS) {
+        // Coalesced store: each wave transposes its strip through its own LDS slab, NTH 32-column blocks at a
+        // time, and writes whole 128/256-byte row segments with dwordx4 stores (16 instead of 64 store
+        // instructions per lane for a 32x128 strip; the scalar-store tail cost 17 % of the kernel).
+        constexpr int WAVES = WM * WN;
+        constexpr int FIT = (NSTAGE * T::STAGE_FLOATS / (WAVES * 32) - 4) / 32;
+        constexpr int NTH = FIT >= 4 ? 4 : (FIT >= 2 ? 2 : 1);
+        static_assert(FIT >= 1, "epilogue slab does not fit the staging LDS");
+        constexpr int ST = 32 * NTH + 4;
+        float* slab = smem + wave * 32 * ST;
+        const int64_t mw = m0 + wm * 32;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = n0 + (wn * NT + nt) * 32 + r;
-            const float bv = p.bias[n];
+        for (int nt0 = 0; nt0 < NT; nt0 += NTH) {
+            const int nth = (NT - nt0) < NTH ? (NT - nt0) : NTH;  // compile-time after unrolling
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int64_t m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (m < p.M) {
-                    float v = acc[nt][reg] + bv;
-                    if (p.act) v = gelu_erf(v);
-                    p.out[m * p.N + n] = v;
+            for (int q = 0; q < NTH; ++q) {
+                if (q < nth) {
+                    const float bv = p.bias[n0 + (wn * NT + nt0 + q) * 32 + r];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = acc[nt0 + q][reg] + bv;
+                        if (p.act) v = gelu_erf(v);
+                        slab[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST + q * 32 + r] = v;
+                    }
                 }
             }
+            __syncthreads();
+            const int c4n = 8 * (nth == 3 ? 4 : nth);  // float4 per row segment (nth is 1, 2 or 4 by construction)
+            const int rpi = 64 / c4n;
+            const int row_in = lane / c4n, c4 = lane % c4n;
+#pragma unroll
+            for (int i = 0; i < 32 * 8 * NTH / 64; ++i) {
+                const int row = i * rpi + row_in;
+                if (row < 32 && c4 < 8 * nth && mw + row < p.M) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ST + c4 * 4);
+                    *reinterpret_cast<f32x4*>(p.out + (mw + row) * p.N + n0 + (wn * NT + nt0) * 32 + c4 * 4) = v;
+                }
+            }
+            if (nt0 + NTH < NT) __syncthreads();
         }
         return;
     } else {
         // ---- whole-row epilogue: residual, LayerNorms, optional 3-wide head ---------------------------------
-        float* red = smem;  // [slot][BM][WN] partial sums; the staging buffers are dead after the last barrier
-        const float invC = 1.0f / (float)p.N;
-        int64_t mrow[16];
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) mrow[reg] = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-
-        auto row_total = [&](float (&s)[16], int slot) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) s[reg] = half_wave_sum(s[reg]);
-            if (WN > 1) {
-                float* rs = red + slot * BM * WN;
-                if (r == 0) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        rs[(wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN + wn] = s[reg];
-                }
-                __syncthreads();
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const float* q = rs + (wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * WN;
-                    float t = q[0];
-#pragma unroll
-                    for (int w = 1; w < WN; ++w) t += q[w];
-                    s[reg] = t;
-                }
-            }
-        };
-        // in-place LayerNorm of the row fragments held in acc
-        auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot) {
-            float s[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float t = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) t += acc[nt][reg];
-                s[reg] = t;
-            }
-            row_total(s, slot);
-            float mean[16];
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                mean[reg] = s[reg] * invC;
-                float t = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float d = acc[nt][reg] - mean[reg];
-                    t += d * d;
-                }
-                s[reg] = t;
-            }
-            row_total(s, slot + 1);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) s[reg] = 1.0f / sqrtf(s[reg] * invC + eps);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = (wn * NT + nt) * 32 + r;
-                const float g = gw[n], b = gb[n];
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) acc[nt][reg] = (acc[nt][reg] - mean[reg]) * s[reg] * g + b;
-            }
-        };
-
+        // The BM x N accumulator tile goes to LDS row-major (stride N+4); then each half-wave owns one row at a
+        // time, lane li holding float4 columns li, li+32, ...: LayerNorm statistics are 5-step xor-shuffle sums,
+        // and every global access (residual, positional row, x, xn) is a fully coalesced dwordx4.
+        constexpr int WAVES = WM * WN;
+        const int N = p.N, YS = N + 4, NQ = N / 4;  // NQ float4 per row
+        constexpr int NV = (BN / 4 + 31) / 32;       // float4 per lane per row
+        float* Y = smem;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int n = (wn * NT + nt) * 32 + r;
-            const float bv = p.bias[n];
+            const int col = (wn * NT + nt) * 32 + r;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float rv = (mrow[reg] < p.M) ? p.resid[mrow[reg] * p.N + n] : 0.f;
-                acc[nt][reg] = (acc[nt][reg] + bv) + rv;
-            }
+            for (int reg = 0; reg < 16; ++reg)
+                Y[(wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * YS + col] = acc[nt][reg];
         }
-        if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
-        if (p.pos) {
+        __syncthreads();
+        const int li = lane & 31, hh = lane >> 5;
+        const float invC = 1.0f / (float)N;
+        f32x4 bias4[NV], pw4[NV], pb4[NV], nw4[NV], nb4[NV];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int f = (int)((mrow[reg] / p.posJ) % p.posF);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][reg] += p.pos[f * p.N + (wn * NT + nt) * 32 + r];
-            }
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = li + 32 * i;
+            const bool ok = c4 < NQ;
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            bias4[i] = ok ? *reinterpret_cast<const f32x4*>(p.bias + 4 * c4) : z4;
+            pw4[i] = (ok && p.post_w) ? *reinterpret_cast<const f32x4*>(p.post_w + 4 * c4) : z4;
+            pb4[i] = (ok && p.post_w) ? *reinterpret_cast<const f32x4*>(p.post_b + 4 * c4) : z4;
+            nw4[i] = (ok && p.next_w) ? *reinterpret_cast<const f32x4*>(p.next_w + 4 * c4) : z4;
+            nb4[i] = (ok && p.next_w) ? *reinterpret_cast<const f32x4*>(p.next_b + 4 * c4) : z4;
         }
-        if (p.out_x) {
+        // LayerNorm of the row spread over this half-wave (two-pass: mean, then centred sum of squares)
+        auto row_norm = [&](f32x4 (&v)[NV], const f32x4 (&g4)[NV], const f32x4 (&b4)[NV], float eps) {
+            float s = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = (wn * NT + nt) * 32 + r;
+            for (int i = 0; i < NV; ++i)
+                if (li + 32 * i < NQ) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            const float mean = half_wave_sum(s) * invC;
+            float q = 0.f;
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg)
-                    if (mrow[reg] < p.M) p.out_x[mrow[reg] * p.N + n] = acc[nt][reg];
-            }
-        }
-        if (p.next_w) {
-            layer_norm(p.next_w, p.next_b, p.next_eps, 2);
-            if (p.out_n) {
+            for (int i = 0; i < NV; ++i)
+                if (li + 32 * i < NQ) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int n = (wn * NT + nt) * 32 + r;
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[i][e] - mean;
+                        q += d * d;
+                    }
+                }
+            const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invC + eps);
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        if (mrow[reg] < p.M) p.out_n[mrow[reg] * p.N + n] = acc[nt][reg];
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g4[i][e] + b4[i][e];
+        };
+#pragma unroll 1
+        for (int row = 2 * wave + hh; row < BM; row += 2 * WAVES) {  // row is uniform per half-wave
+            const int64_t m = m0 + row;
+            const bool live = m < p.M;  // uniform per half-wave; dead rows still take part in the shuffles
+            const int64_t mo = (live ? m : p.M - 1) * N;
+            f32x4 v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c4 = li + 32 * i;
+                if (c4 < NQ) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * YS + 4 * c4);
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + mo + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] = (y[e] + bias4[i][e]) + rs[e];
+                } else {
+                    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            if (p.out_head) {
+            if (p.post_w) row_norm(v, pw4, pb4, p.post_eps);
+            if (p.pos) {
+                const int f = (int)((m / p.posJ) % p.posF);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float s[16];
+                for (int i = 0; i < NV; ++i) {
+                    const int c4 = li + 32 * i;
+                    if (c4 < NQ) {
+                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * N + 4 * c4);
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) s[reg] = 0.f;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const float hw = p.head_w[k * p.N + (wn * NT + nt) * 32 + r];
-#pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) s[reg] += acc[nt][reg] * hw;
+                        for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
                     }
-                    row_total(s, 4 + k);
-                    if (wn == 0 && r == 0) {
-                        const float hb = p.head_b[k];
+                }
+            }
+            if (p.out_x && live) {
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg)
-                            if (mrow[reg] < p.M) p.out_head[mrow[reg] * 3 + k] = s[reg] + hb;
+                for (int i = 0; i < NV; ++i)
+                    if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_x + mo + 4 * (li + 32 * i)) = v[i];
+            }
+            if (p.next_w) {
+                row_norm(v, nw4, nb4, p.next_eps);
+                if (p.out_n && live) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i)
+                        if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_n + mo + 4 * (li + 32 * i)) = v[i];
+                }
+                if (p.out_head) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) {
+                            const int c4 = li + 32 * i;
+                            if (c4 < NQ) {
+                                const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * N + 4 * c4);
+                                s += (v[i][0] * hw[0] + v[i][1] * hw[1]) + (v[i][2] * hw[2] + v[i][3] * hw[3]);
+                            }
+                        }
+                        s = half_wave_sum(s);
+                        if (li == 0 && live) p.out_head[m * 3 + k] = s + p.head_b[k];
                     }
                 }
             }
@@ -493,42 +520,49 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const fl
 
 // ----------------------------------------------------------------------------------------------------------------
 // Timestep embedding: sinusoid -> Linear(C,2C) -> GELU -> Linear(2C,C)   (common/mixste.py:127-139,179-184)
-// One workgroup per batch row.  `freqs` is the host-computed omega table so that t*omega is the same fp32
-// product the reference forms; sin/cos are the accurate device functions (arguments reach 999 rad).
+// `freqs` is the host-computed omega table so that t*omega is the same fp32 product the reference forms; sin/cos
+// are the accurate device functions (arguments reach 999 rad).
 // ----------------------------------------------------------------------------------------------------------------
 struct TimeEmbedParams {
     const int64_t* t;  // [B] or null -> t_scalar
     int64_t t_scalar;
     const float* freqs;
     const float *w1, *b1, *w3, *b3;
+    float* hid;  // [B,2C] scratch
     float* out;  // [B,C]
     int C;
 };
 
-__global__ void __launch_bounds__(256) time_embed_kernel(const TimeEmbedParams p) {
+// phase 0: hid = GELU(W1 sinusoid(t) + b1)   phase 1: out = W3 hid + b3.   grid = (ceil(rows/8), B), 8 waves per
+// workgroup, one output row per wave (coalesced weight-row reads + wave reduction).
+template <int PHASE>
+__global__ void __launch_bounds__(512) time_embed_kernel(const TimeEmbedParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* emb = smem;        // [C]
-    float* hid = smem + p.C;  // [2C]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, C = p.C, half = C / 2;
-    const float tf = (float)(p.t ? p.t[b] : p.t_scalar);
-    for (int i = tid; i < half; i += 256) {
-        const float a = tf * p.freqs[i];
-        emb[i] = sinf(a);
-        emb[half + i] = cosf(a);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, C = p.C;
+    const int K = PHASE == 0 ? C : 2 * C, NOUT = PHASE == 0 ? 2 * C : C;
+    if (PHASE == 0) {
+        const int half = C / 2;
+        const float tf = (float)(p.t ? p.t[b] : p.t_scalar);
+        for (int i = tid; i < half; i += 512) {
+            const float a = tf * p.freqs[i];
+            smem[i] = sinf(a);
+            smem[half + i] = cosf(a);
+        }
+    } else {
+        for (int i = tid; i < K; i += 512) smem[i] = p.hid[(int64_t)b * K + i];
     }
     __syncthreads();
-    for (int o = wave; o < 2 * C; o += 4) {
-        float s = 0.f;
-        for (int k = lane; k < C; k += 64) s += p.w1[(int64_t)o * C + k] * emb[k];
-        s = wave_sum(s);
-        if (lane == 0) hid[o] = gelu_erf(s + p.b1[o]);
-    }
-    __syncthreads();
-    for (int o = wave; o < C; o += 4) {
-        float s = 0.f;
-        for (int k = lane; k < 2 * C; k += 64) s += p.w3[(int64_t)o * 2 * C + k] * hid[k];
-        s = wave_sum(s);
-        if (lane == 0) p.out[(int64_t)b * C + o] = s + p.b3[o];
+    const int o = blockIdx.x * 8 + wave;
+    if (o >= NOUT) return;
+    const float* w = (PHASE == 0 ? p.w1 : p.w3) + (int64_t)o * K;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s += w[k] * smem[k];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (PHASE == 0)
+            p.hid[(int64_t)b * NOUT + o] = gelu_erf(s + p.b1[o]);
+        else
+            p.out[(int64_t)b * NOUT + o] = s + p.b3[o];
     }
 }
 

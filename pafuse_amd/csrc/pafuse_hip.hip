@@ -38,9 +38,10 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 template <int WM, int WN, int NT, int EPI, int NSTAGE>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
-    constexpr size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
+    constexpr size_t stage_bytes = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
+    constexpr size_t ytile_bytes = EPI == EPI_ROWLN ? (size_t)T::BM * (T::BN + 4) * sizeof(float) : 0;
+    constexpr size_t lds = stage_bytes > ytile_bytes ? stage_bytes : ytile_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert(EPI != EPI_ROWLN || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "reduction scratch must fit");
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
@@ -59,7 +60,6 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
     if (p.N % 128 == 0) return launch_gemm<4, 1, 4, EPI_BIAS, 2>(p, s);
-    if (p.N % 224 == 0) return launch_gemm<4, 1, 7, EPI_BIAS, 1>(p, s);
     if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 2>(p, s);
     if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 2>(p, s);
     return launch_gemm<4, 1, 1, EPI_BIAS, 2>(p, s);
@@ -69,11 +69,13 @@ int gemm_rowln(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
     switch (p.N) {
-        case 384: return launch_gemm<2, 4, 3, EPI_ROWLN, 1>(p, s);
-        case 256: return launch_gemm<2, 4, 2, EPI_ROWLN, 1>(p, s);
-        case 224: return launch_gemm<4, 1, 7, EPI_ROWLN, 1>(p, s);
-        case 128: return launch_gemm<2, 2, 2, EPI_ROWLN, 1>(p, s);
-        case 64: return launch_gemm<2, 2, 1, EPI_ROWLN, 1>(p, s);
+        // 32-row tiles, single LDS stage: 2-4 independent workgroups per CU fill each other's barrier gaps
+        // (measured on MI355X, tools/gemm_bench.hip: 64/128-row whole-row tiles leave the matrix pipe idle 40-60 %)
+        case 384: return launch_gemm<1, 4, 3, EPI_ROWLN, 1>(p, s);
+        case 256: return launch_gemm<1, 8, 1, EPI_ROWLN, 1>(p, s);
+        case 224: return launch_gemm<1, 7, 1, EPI_ROWLN, 1>(p, s);
+        case 128: return launch_gemm<1, 4, 1, EPI_ROWLN, 1>(p, s);
+        case 64: return launch_gemm<1, 2, 1, EPI_ROWLN, 1>(p, s);
         default: return fail(PAFUSE_E_SHAPE, "no whole-row kernel for channel width %d (have 64,128,224,256,384)", p.N);
     }
 }
@@ -236,11 +238,13 @@ int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, in
 }
 
 int launch_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int64_t t_scalar, int B, float* out,
-                      hipStream_t s) {
+                      float* hid_scratch, hipStream_t s) {
     TimeEmbedParams p{};
+    const int C = w->channels;
     p.t = t, p.t_scalar = t_scalar, p.freqs = w->freqs;
-    p.w1 = w->tm1_w, p.b1 = w->tm1_b, p.w3 = w->tm3_w, p.b3 = w->tm3_b, p.out = out, p.C = w->channels;
-    hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(256), (size_t)3 * w->channels * sizeof(float), s, p);
+    p.w1 = w->tm1_w, p.b1 = w->tm1_b, p.w3 = w->tm3_w, p.b3 = w->tm3_b, p.hid = hid_scratch, p.out = out, p.C = C;
+    hipLaunchKernelGGL(time_embed_kernel<0>, dim3((2 * C + 7) / 8, B), dim3(512), (size_t)C * sizeof(float), s, p);
+    hipLaunchKernelGGL(time_embed_kernel<1>, dim3((C + 7) / 8, B), dim3(512), (size_t)2 * C * sizeof(float), s, p);
     return check_launch("time_embed_kernel");
 }
 
@@ -305,10 +309,12 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
     return run_block(*w, pb, M, C, heads, S, L, 1, L, 0, 1, t, s);
 }
 
-int pafuse_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int32_t B, float* temb, void* stream) {
+int pafuse_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int32_t B, float* temb, float* hid_scratch,
+                      void* stream) {
     if (!w || !t || !temb || B <= 0) return fail(PAFUSE_E_ARG, "time_embed: bad argument");
     if (w->channels % 2 || w->channels > 1024) return fail(PAFUSE_E_SHAPE, "time_embed: C=%d", w->channels);
-    return launch_time_embed(w, t, 0, B, temb, (hipStream_t)stream);
+    if (!hid_scratch) return fail(PAFUSE_E_ARG, "time_embed: null scratch");
+    return launch_time_embed(w, t, 0, B, temb, hid_scratch, (hipStream_t)stream);
 }
 
 size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights* w, int32_t B, int32_t P) {
@@ -327,7 +333,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     const int64_t R = (int64_t)B * P, M = R * w->frames * w->joints;
     PartBuffers pb;
     carve_part((char*)workspace, M, w->channels, B, pb);
-    if ((rc = launch_time_embed(w, t, 0, B, pb.temb, s))) return rc;
+    if ((rc = launch_time_embed(w, t, 0, B, pb.temb, pb.wide, s))) return rc;
     EmbedParams e{};
     e.x3d = x3d, e.x2d = x2d, e.x2d_flip = nullptr, e.joints = nullptr, e.perm = nullptr;
     e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb.temb;
@@ -414,7 +420,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
         }
         for (int i = 0; i < NP && rc == PAFUSE_OK; ++i) {
             const pafuse_mixste2_weights* w = &cfg->part[i];
-            if ((rc = launch_time_embed(w, nullptr, st.time, B, pb[i].temb, ps[i]))) break;
+            if ((rc = launch_time_embed(w, nullptr, st.time, B, pb[i].temb, pb[i].wide, ps[i]))) break;
             EmbedParams e{};
             e.x3d = img, e.x2d = x2d, e.x2d_flip = x2d_flip, e.joints = cfg->part_joints[i], e.perm = cfg->flip_perm;
             e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb[i].temb;

@@ -64,5 +64,6 @@ def time_embed(model, t):
     w = model.weights_struct()
     t = t.contiguous().long()
     out = torch.empty(t.shape[0], model.embed_dim, device=t.device, dtype=torch.float32)
-    _lib.check(lib.pafuse_time_embed(C.byref(w), t.data_ptr(), t.shape[0], out.data_ptr(), _stream(t)))
+    hid = torch.empty(t.shape[0], 2 * model.embed_dim, device=t.device, dtype=torch.float32)
+    _lib.check(lib.pafuse_time_embed(C.byref(w), t.data_ptr(), t.shape[0], out.data_ptr(), hid.data_ptr(), _stream(t)))
     return out

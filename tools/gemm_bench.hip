@@ -1,0 +1,103 @@
+// gemm_bench.hip - stand-alone timing of the linear-layer kernels at the hot-path shapes (dev tool).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip -o gpurun_out/gemm_bench && ./gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../pafuse_amd/csrc/kernels.hpp"
+using namespace pafuse;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int WM, int WN, int NT, int EPI, int NSTAGE>
+float time_gemm(const char* tag, GemmParams p, int reps = 20) {
+    using T = GemmTile<WM, WN, NT>;
+    if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
+    if (const char* r = getenv("GB_REPS")) reps = atoi(r);
+    size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * 4;
+    if (EPI == EPI_ROWLN && (size_t)T::BM * (T::BN + 4) * 4 > lds) lds = (size_t)T::BM * (T::BN + 4) * 4;
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    printf("%-34s M=%6ld N=%4d K=%3d tiles=%5ld lds=%6zu : %8.1f us  %6.1f TF/s (%.1f%%)\n", tag, (long)p.M, p.N, p.K,
+           (long)tiles, lds, us, tf, tf / 157.3 * 100);
+    return us;
+}
+
+int main() {
+    const int64_t Mmax = 73440;
+    float *A, *W, *bias, *out, *x, *xn, *vec;
+    CK(hipMalloc(&A, Mmax * 768 * 4)); CK(hipMalloc(&W, 1152 * 768 * 4)); CK(hipMalloc(&bias, 1152 * 4));
+    CK(hipMalloc(&out, Mmax * 1152 * 4)); CK(hipMalloc(&x, Mmax * 384 * 4)); CK(hipMalloc(&xn, Mmax * 384 * 4));
+    CK(hipMalloc(&vec, 1152 * 4));
+    std::vector<float> h(Mmax * 768);
+    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    CK(hipMemcpy(A, h.data(), Mmax * 768 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data(), 1152 * 768 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(bias, h.data(), 1152 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(vec, h.data() + 5000, 1152 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(x, h.data(), Mmax * 384 * 4, hipMemcpyHostToDevice));
+    GemmParams p{};
+    p.A = A, p.W = W, p.bias = bias, p.out = out;
+    p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
+    { const char* f = getenv("GB_FILTER"); if (!f) time_gemm<4, 1, 4, EPI_BIAS, 2>("(warm-up, ignore)", p, 200); }
+    // body
+    p.M = 25920, p.N = 1152, p.K = 384, p.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 2>("body qkv  <4,1,4> s2", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1>("body qkv  <4,1,4> s1", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 2>("body qkv  <4,1,3> s2", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 2>("body qkv  <4,1,2> s2", p);
+    time_gemm<2, 2, 3, EPI_BIAS, 2>("body qkv  <2,2,3> s2", p);
+    p.N = 768, p.act = 1; time_gemm<4, 1, 4, EPI_BIAS, 2>("body fc1+gelu <4,1,4> s2", p);
+    p.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 2>("body fc1 nogelu <4,1,4> s2", p);
+    // face
+    p.M = 73440, p.N = 672, p.K = 224, p.act = 0; time_gemm<4, 1, 7, EPI_BIAS, 1>("face qkv  <4,1,7> s1", p);
+    time_gemm<4, 1, 7, EPI_BIAS, 2>("face qkv  <4,1,7> s2", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 2>("face qkv  <4,1,3> s2", p);
+    time_gemm<4, 1, 1, EPI_BIAS, 2>("face qkv  <4,1,1> s2", p);
+    // hands
+    p.M = 45360, p.N = 768, p.K = 256; time_gemm<4, 1, 4, EPI_BIAS, 2>("hands qkv <4,1,4> s2", p);
+    // rowln
+    GemmParams q{};
+    q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
+    q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
+    q.M = 25920, q.N = 384, q.K = 384; time_gemm<2, 4, 3, EPI_ROWLN, 1>("body proj rowln <2,4,3> s1", q);
+    time_gemm<2, 4, 3, EPI_ROWLN, 2>("body proj rowln <2,4,3> s2", q);
+    q.K = 768; time_gemm<2, 4, 3, EPI_ROWLN, 1>("body fc2  rowln <2,4,3> s1", q);
+    time_gemm<2, 4, 3, EPI_ROWLN, 2>("body fc2  rowln <2,4,3> s2", q);
+    q.M = 73440, q.N = 224, q.K = 224; time_gemm<4, 1, 7, EPI_ROWLN, 1>("face proj rowln <4,1,7> s1", q);
+    time_gemm<4, 1, 7, EPI_ROWLN, 2>("face proj rowln <4,1,7> s2", q);
+    time_gemm<2, 7, 1, EPI_ROWLN, 2>("face proj rowln <2,7,1> s2", q);
+    time_gemm<1, 7, 1, EPI_ROWLN, 2>("face proj rowln <1,7,1> s2", q);
+    q.K = 448; time_gemm<4, 1, 7, EPI_ROWLN, 1>("face fc2  rowln <4,1,7> s1", q);
+    time_gemm<4, 1, 7, EPI_ROWLN, 2>("face fc2  rowln <4,1,7> s2", q);
+    time_gemm<2, 7, 1, EPI_ROWLN, 2>("face fc2  rowln <2,7,1> s2", q);
+    time_gemm<1, 7, 1, EPI_ROWLN, 2>("face fc2  rowln <1,7,1> s2", q);
+    q.M = 45360, q.N = 256, q.K = 256; time_gemm<2, 4, 2, EPI_ROWLN, 1>("hands proj rowln <2,4,2> s1", q);
+    time_gemm<2, 4, 2, EPI_ROWLN, 2>("hands proj rowln <2,4,2> s2", q);
+    q.K = 512; time_gemm<2, 4, 2, EPI_ROWLN, 1>("hands fc2  rowln <2,4,2> s1", q);
+    time_gemm<2, 4, 2, EPI_ROWLN, 2>("hands fc2  rowln <2,4,2> s2", q);
+    q.M = 25920, q.N = 384, q.K = 384; time_gemm<1, 4, 3, EPI_ROWLN, 1>("body proj rowln <1,4,3> s1", q);
+    q.K = 768; time_gemm<1, 4, 3, EPI_ROWLN, 1>("body fc2  rowln <1,4,3> s1", q);
+    q.M = 45360, q.N = 256, q.K = 256; time_gemm<1, 4, 2, EPI_ROWLN, 1>("hands proj rowln <1,4,2> s1", q);
+    q.K = 512; time_gemm<1, 4, 2, EPI_ROWLN, 1>("hands fc2  rowln <1,4,2> s1", q);
+    time_gemm<1, 4, 2, EPI_ROWLN, 2>("hands fc2  rowln <1,4,2> s2", q);
+    time_gemm<1, 8, 1, EPI_ROWLN, 2>("hands fc2  rowln <1,8,1> s2", q);
+    time_gemm<1, 8, 1, EPI_ROWLN, 1>("hands fc2  rowln <1,8,1> s1", q);
+    q.M = 73440, q.N = 224, q.K = 448; time_gemm<1, 7, 1, EPI_ROWLN, 1>("face fc2  rowln <1,7,1> s1", q);
+    q.K = 224; time_gemm<1, 7, 1, EPI_ROWLN, 1>("face proj rowln <1,7,1> s1", q);
+    // same shapes as plain-bias kernels: what the whole-row epilogue costs
+    p.M = 25920, p.N = 384, p.K = 768, p.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 2>("body fc2 as plain <4,1,4> s2", p);
+    p.M = 73440, p.N = 224, p.K = 448; time_gemm<4, 1, 7, EPI_BIAS, 1>("face fc2 as plain <4,1,7> s1", p);
+    return 0;
+}
