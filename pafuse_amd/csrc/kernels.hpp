@@ -82,8 +82,8 @@ struct GemmTile {
 // global -> registers (issued before the MFMAs of the current chunk) -> LDS (after them), NSTAGE LDS buffers.
 // Fragment reads are ds_read_b128: lane (r = lane&31, h = lane>>5) takes k = 8g+4h..8g+4h+3 of row r, and MFMA
 // step (g, j) multiplies k = 8g+j (h = 0) and 8g+4+j (h = 1): a permutation of k shared by A and W.
-template <int WM, int WN, int NT, int EPI, int NSTAGE>
-__global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
+__global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
     constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;  // float4 per thread per chunk
@@ -107,37 +107,50 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     const int n0 = tile_n * BN;
     const int K = p.K;
 
-    const float* a_src[A_LD];
-    int a_dst[A_LD];
+    // Staging addresses: a wave-uniform base (SGPR pair) plus one 32-bit per-thread offset; thread t stages the
+    // float4 at row (t>>3) + i*(NTHR/8), column chunk t&7.  Tail rows of A read a valid row (never stored);
+    // surplus threads (BM*8 < NTHR) duplicate row BM-1 (same value, same slot).
+    constexpr int RSTEP = NTHR / 8;
+    const int trow = tid >> 3, tc4 = tid & 7;
+    const float* Abase = p.A + m0 * K;
+    const float* Wbase = p.W + (int64_t)n0 * K;
+    int a_off[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        int idx = tid + i * NTHR;
-        idx = idx < BM * 8 ? idx : BM * 8 - 1;  // surplus threads duplicate the last float4 (same value, same slot)
-        const int row = idx >> 3, c4 = idx & 7;
-        int64_t gm = m0 + row;
-        gm = gm < p.M ? gm : p.M - 1;  // tail rows read a valid row; their results are never stored
-        a_src[i] = p.A + gm * K + c4 * 4;
-        a_dst[i] = row * LDK + c4 * 4;
+        int row = trow + i * RSTEP;
+        row = row < BM ? row : BM - 1;
+        const int64_t lim = p.M - 1 - m0;  // >= 0
+        const int grow = row < lim ? row : (int)lim;
+        a_off[i] = grow * K + tc4 * 4;
     }
-    const float* w_src[W_LD];
-    int w_dst[W_LD];
-#pragma unroll
-    for (int i = 0; i < W_LD; ++i) {
-        int idx = tid + i * NTHR;
-        idx = idx < BN * 8 ? idx : BN * 8 - 1;
-        const int row = idx >> 3, c4 = idx & 7;
-        w_src[i] = p.W + (int64_t)(n0 + row) * K + c4 * 4;
-        w_dst[i] = row * LDK + c4 * 4;
-    }
+    int w_row0 = trow;  // BN*8 is a multiple of NTHR for every instantiated tile except when clamped below
+    const int a_dst0 = (trow < BM ? trow : BM - 1) * LDK + tc4 * 4;
+    const int w_dst0 = trow * LDK + tc4 * 4;
+    auto a_dst = [&](int i) {
+        if ((i + 1) * RSTEP <= BM) return a_dst0 + i * RSTEP * LDK;  // compile-time after unrolling
+        int row = trow + i * RSTEP;
+        row = row < BM ? row : BM - 1;
+        return row * LDK + tc4 * 4;
+    };
+    static_assert((BN * 8) % NTHR == 0, "W staging must divide evenly");
+    const int w_off = w_row0 * K + tc4 * 4;
     f32x4 a_reg[A_LD], w_reg[W_LD];
+    auto load_chunk = [&](int kc) {
+        const float* Ak = Abase + kc * BK;
+        const float* Wk = Wbase + kc * BK;
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i]);
+        for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(Ak + a_off[i]);
 #pragma unroll
-    for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i]);
+        for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)i * RSTEP * K + w_off);
+    };
+    auto store_chunk = [&](float* Ad, float* Wd) {
 #pragma unroll
-    for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(As + a_dst[i]) = a_reg[i];
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(Ad + a_dst(i)) = a_reg[i];
 #pragma unroll
-    for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Ws + w_dst[i]) = w_reg[i];
+        for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Wd + w_dst0 + i * RSTEP * LDK) = w_reg[i];
+    };
+    load_chunk(0);
+    store_chunk(As, Ws);
     __syncthreads();
 
     f32x16 acc[NT];
@@ -152,12 +165,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = (NSTAGE == 2) ? (kc & 1) : 0;
         const bool more = kc + 1 < nk;
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_src[i] + (kc + 1) * BK);
-#pragma unroll
-            for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(w_src[i] + (kc + 1) * BK);
-        }
+        if (more) load_chunk(kc + 1);
         const float* Ac = As + cur * BM * LDK + a_frag;
         const float* Wc = Ws + cur * BN * LDK + w_frag;
         __builtin_amdgcn_s_setprio(1);
@@ -177,10 +185,7 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
         if (NSTAGE == 1) __syncthreads();  // everyone done reading before the single buffer is refilled
         if (more) {
             const int nxt = (NSTAGE == 2) ? (cur ^ 1) : 0;
-#pragma unroll
-            for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(As + nxt * BM * LDK + a_dst[i]) = a_reg[i];
-#pragma unroll
-            for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Ws + nxt * BN * LDK + w_dst[i]) = w_reg[i];
+            store_chunk(As + nxt * BM * LDK, Ws + nxt * BN * LDK);
         }
         __syncthreads();
     }
@@ -235,31 +240,12 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
         constexpr int WAVES = WM * WN;
         const int N = p.N, YS = N + 4, NQ = N / 4;  // NQ float4 per row
         constexpr int NV = (BN / 4 + 31) / 32;       // float4 per lane per row
-        float* Y = smem;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = (wn * NT + nt) * 32 + r;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                Y[(wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h) * YS + col] = acc[nt][reg];
-        }
-        __syncthreads();
+        float* Y = smem;                             // [32][N+4]: one 32-row band (the rows of one wm) at a time
         const int li = lane & 31, hh = lane >> 5;
         const float invC = 1.0f / (float)N;
-        f32x4 bias4[NV], pw4[NV], pb4[NV], nw4[NV], nb4[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c4 = li + 32 * i;
-            const bool ok = c4 < NQ;
-            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            bias4[i] = ok ? *reinterpret_cast<const f32x4*>(p.bias + 4 * c4) : z4;
-            pw4[i] = (ok && p.post_w) ? *reinterpret_cast<const f32x4*>(p.post_w + 4 * c4) : z4;
-            pb4[i] = (ok && p.post_w) ? *reinterpret_cast<const f32x4*>(p.post_b + 4 * c4) : z4;
-            nw4[i] = (ok && p.next_w) ? *reinterpret_cast<const f32x4*>(p.next_w + 4 * c4) : z4;
-            nb4[i] = (ok && p.next_w) ? *reinterpret_cast<const f32x4*>(p.next_b + 4 * c4) : z4;
-        }
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         // LayerNorm of the row spread over this half-wave (two-pass: mean, then centred sum of squares)
-        auto row_norm = [&](f32x4 (&v)[NV], const f32x4 (&g4)[NV], const f32x4 (&b4)[NV], float eps) {
+        auto row_norm = [&](f32x4 (&v)[NV], const float* gw, const float* gb, float eps) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -277,70 +263,89 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_kernel(const GemmParams p) {
                 }
             const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invC + eps);
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g4[i][e] + b4[i][e];
-        };
-#pragma unroll 1
-        for (int row = 2 * wave + hh; row < BM; row += 2 * WAVES) {  // row is uniform per half-wave
-            const int64_t m = m0 + row;
-            const bool live = m < p.M;  // uniform per half-wave; dead rows still take part in the shuffles
-            const int64_t mo = (live ? m : p.M - 1) * N;
-            f32x4 v[NV];
-#pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c4 = li + 32 * i;
                 if (c4 < NQ) {
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * YS + 4 * c4);
-                    const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + mo + 4 * c4);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + 4 * c4);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + 4 * c4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = (y[e] + bias4[i][e]) + rs[e];
-                } else {
-                    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
                 }
             }
-            if (p.post_w) row_norm(v, pw4, pb4, p.post_eps);
-            if (p.pos) {
-                const int f = (int)((m / p.posJ) % p.posF);
+        };
+#pragma unroll 1
+        for (int band = 0; band < WM; ++band) {
+            if (wm == band) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = (wn * NT + nt) * 32 + r;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) Y[((reg & 3) + 8 * (reg >> 2) + 4 * h) * YS + col] = acc[nt][reg];
+                }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int row = 2 * wave + hh; row < 32; row += 2 * WAVES) {  // row is uniform per half-wave
+                const int64_t m = m0 + band * 32 + row;
+                const bool live = m < p.M;  // dead rows still take part in the shuffles
+                const int64_t mo = (live ? m : p.M - 1) * N;
+                f32x4 v[NV];
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const int c4 = li + 32 * i;
+                    v[i] = z4;
                     if (c4 < NQ) {
-                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * N + 4 * c4);
+                        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * YS + 4 * c4);
+                        const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + 4 * c4);
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + mo + 4 * c4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
+                        for (int e = 0; e < 4; ++e) v[i][e] = (y[e] + bs[e]) + rs[e];
                     }
                 }
-            }
-            if (p.out_x && live) {
+                if (p.post_w) row_norm(v, p.post_w, p.post_b, p.post_eps);
+                if (p.pos) {
+                    const int f = (int)((m / p.posJ) % p.posF);
 #pragma unroll
-                for (int i = 0; i < NV; ++i)
-                    if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_x + mo + 4 * (li + 32 * i)) = v[i];
-            }
-            if (p.next_w) {
-                row_norm(v, nw4, nb4, p.next_eps);
-                if (p.out_n && live) {
+                    for (int i = 0; i < NV; ++i) {
+                        const int c4 = li + 32 * i;
+                        if (c4 < NQ) {
+                            const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * N + 4 * c4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
+                        }
+                    }
+                }
+                if (p.out_x && live) {
 #pragma unroll
                     for (int i = 0; i < NV; ++i)
-                        if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_n + mo + 4 * (li + 32 * i)) = v[i];
+                        if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_x + mo + 4 * (li + 32 * i)) = v[i];
                 }
-                if (p.out_head) {
+                if (p.next_w) {
+                    row_norm(v, p.next_w, p.next_b, p.next_eps);
+                    if (p.out_n && live) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        float s = 0.f;
+                        for (int i = 0; i < NV; ++i)
+                            if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_n + mo + 4 * (li + 32 * i)) = v[i];
+                    }
+                    if (p.out_head) {
 #pragma unroll
-                        for (int i = 0; i < NV; ++i) {
-                            const int c4 = li + 32 * i;
-                            if (c4 < NQ) {
-                                const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * N + 4 * c4);
-                                s += (v[i][0] * hw[0] + v[i][1] * hw[1]) + (v[i][2] * hw[2] + v[i][3] * hw[3]);
+                        for (int k = 0; k < 3; ++k) {
+                            float s = 0.f;
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) {
+                                const int c4 = li + 32 * i;
+                                if (c4 < NQ) {
+                                    const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * N + 4 * c4);
+                                    s += (v[i][0] * hw[0] + v[i][1] * hw[1]) + (v[i][2] * hw[2] + v[i][3] * hw[3]);
+                                }
                             }
+                            s = half_wave_sum(s);
+                            if (li == 0 && live) p.out_head[m * 3 + k] = s + p.head_b[k];
                         }
-                        s = half_wave_sum(s);
-                        if (li == 0 && live) p.out_head[m * 3 + k] = s + p.head_b[k];
                     }
                 }
             }
+            if (band + 1 < WM) __syncthreads();
         }
     }
 }
