@@ -68,7 +68,23 @@ struct GemmParams {
     const float* head_w;
     const float* head_b;
     float* out_head;
+    unsigned long long* stamps;  // diagnostic builds (-DPAFUSE_STAMPS) only: per wave {start, loop end, end}
 };
+
+#ifdef PAFUSE_STAMPS
+__device__ __forceinline__ unsigned long long pafuse_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define PAFUSE_STAMP(i)                                                                         \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                    \
+    p.stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (i)] = pafuse_stamp()
+#else
+#define PAFUSE_STAMP(i)
+#endif
 
 template <int WM, int WN, int NT>
 struct GemmTile {
@@ -95,6 +111,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
     const int tiles_n = p.N / BN;
+    PAFUSE_STAMP(0);
     // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so hand each XCD a
     // contiguous run of tiles - the N-tiles of one M-tile then hit the same L2 for their A rows (speed only).
     int tile;
@@ -190,6 +207,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
         __syncthreads();
     }
 
+    PAFUSE_STAMP(1);
     // accumulator element (nt, reg) of this lane is  row = (reg&3) + 8*(reg>>2) + 4*h,  col = 32*nt + r  of the strip
     if constexpr (EPI == EPI_BIAS) {
         // Coalesced store: each wave transposes its strip through its own LDS slab, NTH 32-column blocks at a
@@ -231,6 +249,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
             }
             if (nt0 + NTH < NT) __syncthreads();
         }
+        PAFUSE_STAMP(2);
         return;
     } else {
         // ---- whole-row epilogue: residual, LayerNorms, optional 3-wide head ---------------------------------
@@ -244,8 +263,18 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
         const int li = lane & 31, hh = lane >> 5;
         const float invC = 1.0f / (float)N;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        // column constants (bias, the two LayerNorms' gamma/beta) live in LDS behind the Y band: ds_read latency,
+        // no hoisted registers
+        float* Pc = smem + 32 * YS;  // [5][N]
+        for (int c = tid; c < N; c += NTHR) {
+            Pc[c] = p.bias[c];
+            Pc[N + c] = p.post_w ? p.post_w[c] : 0.f;
+            Pc[2 * N + c] = p.post_w ? p.post_b[c] : 0.f;
+            Pc[3 * N + c] = p.next_w ? p.next_w[c] : 0.f;
+            Pc[4 * N + c] = p.next_w ? p.next_b[c] : 0.f;
+        }
         // LayerNorm of the row spread over this half-wave (two-pass: mean, then centred sum of squares)
-        auto row_norm = [&](f32x4 (&v)[NV], const float* gw, const float* gb, float eps) {
+        auto row_norm = [&](f32x4 (&v)[NV], const float* g, const float* b, float eps) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i)
@@ -266,15 +295,29 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
             for (int i = 0; i < NV; ++i) {
                 const int c4 = li + 32 * i;
                 if (c4 < NQ) {
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + 4 * c4);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + 4 * c4);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * c4);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 4 * c4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
                 }
             }
         };
+        constexpr int RIT = (32 + 2 * WAVES - 1) / (2 * WAVES);  // row iterations per band
 #pragma unroll 1
         for (int band = 0; band < WM; ++band) {
+            // residual rows (and positional rows) of this band: issue every global load up front
+            f32x4 rs[RIT][NV];
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int row = 2 * wave + hh + it * 2 * WAVES;
+                int64_t m = m0 + band * 32 + row;
+                m = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c4 = li + 32 * i;
+                    rs[it][i] = (c4 < NQ && row < 32) ? *reinterpret_cast<const f32x4*>(p.resid + m * N + 4 * c4) : z4;
+                }
+            }
             if (wm == band) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -284,69 +327,73 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
                 }
             }
             __syncthreads();
-#pragma unroll 1
-            for (int row = 2 * wave + hh; row < 32; row += 2 * WAVES) {  // row is uniform per half-wave
-                const int64_t m = m0 + band * 32 + row;
-                const bool live = m < p.M;  // dead rows still take part in the shuffles
-                const int64_t mo = (live ? m : p.M - 1) * N;
-                f32x4 v[NV];
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const int c4 = li + 32 * i;
-                    v[i] = z4;
-                    if (c4 < NQ) {
-                        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * YS + 4 * c4);
-                        const f32x4 bs = *reinterpret_cast<const f32x4*>(p.bias + 4 * c4);
-                        const f32x4 rs = *reinterpret_cast<const f32x4*>(p.resid + mo + 4 * c4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[i][e] = (y[e] + bs[e]) + rs[e];
-                    }
-                }
-                if (p.post_w) row_norm(v, p.post_w, p.post_b, p.post_eps);
-                if (p.pos) {
-                    const int f = (int)((m / p.posJ) % p.posF);
+            for (int it = 0; it < RIT; ++it) {
+                const int row = 2 * wave + hh + it * 2 * WAVES;  // uniform per half-wave
+                if (row < 32) {
+                    const int64_t m = m0 + band * 32 + row;
+                    const bool live = m < p.M;  // dead rows still take part in the shuffles
+                    const int64_t mo = (live ? m : p.M - 1) * N;
+                    f32x4 v[NV];
 #pragma unroll
                     for (int i = 0; i < NV; ++i) {
                         const int c4 = li + 32 * i;
+                        v[i] = z4;
                         if (c4 < NQ) {
-                            const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * N + 4 * c4);
+                            const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * YS + 4 * c4);
+                            const f32x4 bs = *reinterpret_cast<const f32x4*>(Pc + 4 * c4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
+                            for (int e = 0; e < 4; ++e) v[i][e] = (y[e] + bs[e]) + rs[it][i][e];
                         }
                     }
-                }
-                if (p.out_x && live) {
+                    if (p.post_w) row_norm(v, Pc + N, Pc + 2 * N, p.post_eps);
+                    if (p.pos) {  // only the first spatial block of a pass
+                        const int f = (int)((m / p.posJ) % p.posF);
 #pragma unroll
-                    for (int i = 0; i < NV; ++i)
-                        if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_x + mo + 4 * (li + 32 * i)) = v[i];
-                }
-                if (p.next_w) {
-                    row_norm(v, p.next_w, p.next_b, p.next_eps);
-                    if (p.out_n && live) {
+                        for (int i = 0; i < NV; ++i) {
+                            const int c4 = li + 32 * i;
+                            if (c4 < NQ) {
+                                const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * N + 4 * c4);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
+                            }
+                        }
+                    }
+                    if (p.out_x && live) {
 #pragma unroll
                         for (int i = 0; i < NV; ++i)
-                            if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_n + mo + 4 * (li + 32 * i)) = v[i];
+                            if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_x + mo + 4 * (li + 32 * i)) = v[i];
                     }
-                    if (p.out_head) {
+                    if (p.next_w) {
+                        row_norm(v, Pc + 3 * N, Pc + 4 * N, p.next_eps);
+                        if (p.out_n && live) {
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            float s = 0.f;
+                            for (int i = 0; i < NV; ++i)
+                                if (li + 32 * i < NQ)
+                                    *reinterpret_cast<f32x4*>(p.out_n + mo + 4 * (li + 32 * i)) = v[i];
+                        }
+                        if (p.out_head) {
 #pragma unroll
-                            for (int i = 0; i < NV; ++i) {
-                                const int c4 = li + 32 * i;
-                                if (c4 < NQ) {
-                                    const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * N + 4 * c4);
-                                    s += (v[i][0] * hw[0] + v[i][1] * hw[1]) + (v[i][2] * hw[2] + v[i][3] * hw[3]);
+                            for (int k = 0; k < 3; ++k) {
+                                float s = 0.f;
+#pragma unroll
+                                for (int i = 0; i < NV; ++i) {
+                                    const int c4 = li + 32 * i;
+                                    if (c4 < NQ) {
+                                        const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * N + 4 * c4);
+                                        s += (v[i][0] * hw[0] + v[i][1] * hw[1]) + (v[i][2] * hw[2] + v[i][3] * hw[3]);
+                                    }
                                 }
+                                s = half_wave_sum(s);
+                                if (li == 0 && live) p.out_head[m * 3 + k] = s + p.head_b[k];
                             }
-                            s = half_wave_sum(s);
-                            if (li == 0 && live) p.out_head[m * 3 + k] = s + p.head_b[k];
                         }
                     }
                 }
             }
             if (band + 1 < WM) __syncthreads();
         }
+        PAFUSE_STAMP(2);
     }
 }
 

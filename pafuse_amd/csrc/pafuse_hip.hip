@@ -39,7 +39,7 @@ template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
     constexpr size_t stage_bytes = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
-    constexpr size_t ytile_bytes = EPI == EPI_ROWLN ? (size_t)32 * (T::BN + 4) * sizeof(float) : 0;
+    constexpr size_t ytile_bytes = EPI == EPI_ROWLN ? (size_t)(32 * (T::BN + 4) + 5 * T::BN) * sizeof(float) : 0;
     constexpr size_t lds = stage_bytes > ytile_bytes ? stage_bytes : ytile_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;

@@ -16,7 +16,7 @@ float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
     if (const char* r = getenv("GB_REPS")) reps = atoi(r);
     size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * 4;
-    if (EPI == EPI_ROWLN && (size_t)32 * (T::BN + 4) * 4 > lds) lds = (size_t)32 * (T::BN + 4) * 4;
+    if (EPI == EPI_ROWLN && (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4 > lds) lds = (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4;
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);

@@ -1,0 +1,78 @@
+// gemm_life.hip - wave lifetimes of the production linear-layer kernels (diagnostic build with stamps).
+#define PAFUSE_STAMPS 1
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../pafuse_amd/csrc/kernels.hpp"
+using namespace pafuse;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
+void life(const char* tag, GemmParams p) {
+    using T = GemmTile<WM, WN, NT>;
+    size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * 4;
+    if (EPI == EPI_ROWLN && (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4 > lds) lds = (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4;
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    size_t nw = tiles * (T::NTHR / 64);
+    unsigned long long* st; CK(hipMalloc(&st, nw * 32));
+    p.stamps = st;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(nw * 4);
+    CK(hipMemcpy(h.data(), st, nw * 32, hipMemcpyDeviceToHost));
+    double loop = 0, epi = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < nw; ++w) {
+        loop += h[w * 4 + 1] - h[w * 4]; epi += h[w * 4 + 2] - h[w * 4 + 1];
+        t0 = std::min(t0, h[w * 4]); t1 = std::max(t1, h[w * 4 + 2]);
+    }
+    // concurrency profile: how many waves are alive over time (20 bins)
+    const int NB = 20; double alive[NB] = {0};
+    for (size_t w = 0; w < nw; ++w) {
+        double a = (double)(h[w * 4] - t0) / (t1 - t0) * NB, b = (double)(h[w * 4 + 2] - t0) / (t1 - t0) * NB;
+        for (int i = 0; i < NB; ++i) { double lo = std::max(a, (double)i), hi = std::min(b, (double)i + 1); if (hi > lo) alive[i] += hi - lo; }
+    }
+    double mfma = (double)(p.K / 32) * 16 * NT * 64;
+    printf("%s: tiles=%ld waves=%zu span=%.0f cyc | per wave: prologue+loop %.0f  epilogue %.0f  (own MFMA issue %.0f) | MFMA-pipe busy over span: %.1f%%\n  waves alive per CU over time:", tag, (long)tiles, nw,
+           (double)(t1 - t0), loop / nw, epi / nw, mfma, mfma * nw / 1024.0 / (double)(t1 - t0) * 100);
+    for (int i = 0; i < NB; ++i) printf(" %.1f", alive[i] / 256.0);
+    printf("\n");
+    CK(hipFree(st));
+}
+
+int main() {
+    const int64_t Mmax = 73440;
+    float *A, *W, *bias, *out, *x, *xn, *vec;
+    CK(hipMalloc(&A, Mmax * 768 * 4)); CK(hipMalloc(&W, 1152 * 768 * 4)); CK(hipMalloc(&bias, 1152 * 4));
+    CK(hipMalloc(&out, Mmax * 1152 * 4)); CK(hipMalloc(&x, Mmax * 384 * 4)); CK(hipMalloc(&xn, Mmax * 384 * 4));
+    CK(hipMalloc(&vec, 1152 * 4));
+    std::vector<float> h(Mmax * 768);
+    for (auto& v : h) v = (float)(rand() % 2001 - 1000) * 1e-3f;
+    CK(hipMemcpy(A, h.data(), Mmax * 768 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data() + 777, 1152 * 768 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(bias, h.data(), 1152 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(vec, h.data() + 5000, 1152 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(x, h.data(), Mmax * 384 * 4, hipMemcpyHostToDevice));
+    GemmParams p{};
+    p.A = A, p.W = W, p.bias = bias, p.out = out;
+    p.M = 25920, p.N = 1152, p.K = 384;
+    life<4, 1, 3, EPI_BIAS, 2>("body qkv <4,1,3> s2", p);
+    life<4, 1, 4, EPI_BIAS, 2>("body qkv <4,1,4> s2", p);
+    p.N = 768, p.act = 1;
+    life<4, 1, 3, EPI_BIAS, 2>("body fc1+gelu <4,1,3> s2", p);
+    GemmParams q{};
+    q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
+    q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
+    q.M = 25920, q.N = 384, q.K = 768;
+    life<2, 2, 6, EPI_ROWLN, 1, 2>("body fc2 rowln <2,2,6> s1", q);
+    q.K = 384;
+    life<2, 2, 6, EPI_ROWLN, 1, 2>("body proj rowln <2,2,6> s1", q);
+    q.M = 73440, q.N = 224, q.K = 448;
+    life<1, 7, 1, EPI_ROWLN, 1>("face fc2 rowln <1,7,1> s1", q);
+    return 0;
+}
