@@ -51,7 +51,7 @@ struct GemmParams {
     int64_t M;
     int N, K;
     int act;  // EPI_BIAS: 0 none, 1 GELU
-    // EPI_ROWLN (the workgroup owns whole rows, N == BN):  y = A W^T + bias + resid
+    // EPI_ROWLN (the workgroup owns whole rows, N == BN; row-per-lane form only):  y = A W^T + bias + resid
     //   z  = post_w ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;  out_x = z
     //   n  = next_w ? LN(z; next) : -  ;  out_n = n   |  out_head = n @ head_w^T + head_b
     const float* resid;
@@ -98,7 +98,11 @@ struct GemmTile {
 // global -> registers (issued before the MFMAs of the current chunk) -> LDS (after them), NSTAGE LDS buffers.
 // Fragment reads are ds_read_b128: lane (r = lane&31, h = lane>>5) takes k = 8g+4h..8g+4h+3 of row r, and MFMA
 // step (g, j) multiplies k = 8g+j (h = 0) and 8g+4+j (h = 1): a permutation of k shared by A and W.
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
+// TR = 1 ("row per lane"): the MFMA operand roles are swapped (W fragment as the A operand), so the accumulator of
+// lane (r, h) holds output ROW r of the strip and, per 32-column block, the 16 columns {8q+4h .. 8q+4h+3}: four
+// consecutive columns per register quad = one dwordx4, a whole row's statistics = in-lane adds + one
+// xor-32 shuffle.  Epilogues then need no LDS transposition.
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
@@ -196,7 +200,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
+                    acc[nt] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][j], af[j], acc[nt], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         if (NSTAGE == 1) __syncthreads();  // everyone done reading before the single buffer is refilled
@@ -208,6 +213,139 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     }
 
     PAFUSE_STAMP(1);
+    if constexpr (TR) {
+        // lane (r, h) owns row m = m0 + 32*wm + r; acc[nt][4q..4q+3] are columns 32*(wn*NT+nt) + 8q + 4h + {0,1,2,3}
+        const int64_t m = m0 + wm * 32 + r;
+        const bool live = m < p.M;
+        const int64_t mo = (live ? m : p.M - 1) * p.N;
+        const int nb = n0 + wn * NT * 32 + 4 * h;  // + 32*nt + 8*q
+        if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 32 * nt + 8 * q;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[nt][4 * q + e] + b4[e];
+                        if (p.act) v[e] = gelu_erf(v[e]);
+                    }
+                    if (live) *reinterpret_cast<f32x4*>(p.out + mo + n) = v;
+                }
+            PAFUSE_STAMP(2);
+            return;
+        } else {
+            float* red = smem;  // [slot][BM][WN] cross-wave partial sums (staging LDS is dead after the last barrier)
+            const float invC = 1.0f / (float)p.N;
+            auto row_total = [&](float s, int slot) {
+                s += __shfl_xor(s, 32);
+                if (WN > 1) {
+                    float* rs = red + slot * BM * WN + (wm * 32 + r) * WN;
+                    if (h == 0) rs[wn] = s;
+                    __syncthreads();
+                    s = rs[0];
+#pragma unroll
+                    for (int w = 1; w < WN; ++w) s += rs[w];
+                }
+                return s;
+            };
+            auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot) {
+                float s = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s += acc[nt][i];
+                const float mean = row_total(s, slot) * invC;
+                float qv = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = acc[nt][i] - mean;
+                        qv += d * d;
+                    }
+                const float rstd = 1.0f / sqrtf(row_total(qv, slot + 1) * invC + eps);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nb + 32 * nt + 8 * q;
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + n);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
+                    }
+            };
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 32 * nt + 8 * q;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.resid + mo + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] = (acc[nt][4 * q + e] + b4[e]) + r4[e];
+                }
+            if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
+            if (p.pos) {  // only the first spatial block of a pass
+                const int f = (int)(((live ? m : p.M - 1) / p.posJ) % p.posF);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * p.N + nb + 32 * nt + 8 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] += pe[e];
+                    }
+            }
+            if (p.out_x && live) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                        *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
+                    }
+            }
+            if (p.next_w) {
+                layer_norm(p.next_w, p.next_b, p.next_eps, 2);
+                if (p.out_n && live) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                            *reinterpret_cast<f32x4*>(p.out_n + mo + nb + 32 * nt + 8 * q) = v;
+                        }
+                }
+                if (p.out_head) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + nb + 32 * nt + 8 * q);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) s += acc[nt][4 * q + e] * hw[e];
+                            }
+                        s = row_total(s, 4 + k);
+                        if (live && h == 0 && wn == 0) p.out_head[m * 3 + k] = s + p.head_b[k];
+                    }
+                }
+            }
+            PAFUSE_STAMP(2);
+            return;
+        }
+    }
     // accumulator element (nt, reg) of this lane is  row = (reg&3) + 8*(reg>>2) + 4*h,  col = 32*nt + r  of the strip
     if constexpr (EPI == EPI_BIAS) {
         // Coalesced store: each wave transposes its strip through its own LDS slab, NTH 32-column blocks at a
@@ -252,148 +390,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
         PAFUSE_STAMP(2);
         return;
     } else {
-        // ---- whole-row epilogue: residual, LayerNorms, optional 3-wide head ---------------------------------
-        // The BM x N accumulator tile goes to LDS row-major (stride N+4); then each half-wave owns one row at a
-        // time, lane li holding float4 columns li, li+32, ...: LayerNorm statistics are 5-step xor-shuffle sums,
-        // and every global access (residual, positional row, x, xn) is a fully coalesced dwordx4.
-        constexpr int WAVES = WM * WN;
-        const int N = p.N, YS = N + 4, NQ = N / 4;  // NQ float4 per row
-        constexpr int NV = (BN / 4 + 31) / 32;       // float4 per lane per row
-        float* Y = smem;                             // [32][N+4]: one 32-row band (the rows of one wm) at a time
-        const int li = lane & 31, hh = lane >> 5;
-        const float invC = 1.0f / (float)N;
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        // column constants (bias, the two LayerNorms' gamma/beta) live in LDS behind the Y band: ds_read latency,
-        // no hoisted registers
-        float* Pc = smem + 32 * YS;  // [5][N]
-        for (int c = tid; c < N; c += NTHR) {
-            Pc[c] = p.bias[c];
-            Pc[N + c] = p.post_w ? p.post_w[c] : 0.f;
-            Pc[2 * N + c] = p.post_w ? p.post_b[c] : 0.f;
-            Pc[3 * N + c] = p.next_w ? p.next_w[c] : 0.f;
-            Pc[4 * N + c] = p.next_w ? p.next_b[c] : 0.f;
-        }
-        // LayerNorm of the row spread over this half-wave (two-pass: mean, then centred sum of squares)
-        auto row_norm = [&](f32x4 (&v)[NV], const float* g, const float* b, float eps) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (li + 32 * i < NQ) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            const float mean = half_wave_sum(s) * invC;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (li + 32 * i < NQ) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = v[i][e] - mean;
-                        q += d * d;
-                    }
-                }
-            const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invC + eps);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c4 = li + 32 * i;
-                if (c4 < NQ) {
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g + 4 * c4);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(b + 4 * c4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-                }
-            }
-        };
-        constexpr int RIT = (32 + 2 * WAVES - 1) / (2 * WAVES);  // row iterations per band
-#pragma unroll 1
-        for (int band = 0; band < WM; ++band) {
-            // residual rows (and positional rows) of this band: issue every global load up front
-            f32x4 rs[RIT][NV];
-#pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-                const int row = 2 * wave + hh + it * 2 * WAVES;
-                int64_t m = m0 + band * 32 + row;
-                m = m < p.M ? m : p.M - 1;
-#pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const int c4 = li + 32 * i;
-                    rs[it][i] = (c4 < NQ && row < 32) ? *reinterpret_cast<const f32x4*>(p.resid + m * N + 4 * c4) : z4;
-                }
-            }
-            if (wm == band) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = (wn * NT + nt) * 32 + r;
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) Y[((reg & 3) + 8 * (reg >> 2) + 4 * h) * YS + col] = acc[nt][reg];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < RIT; ++it) {
-                const int row = 2 * wave + hh + it * 2 * WAVES;  // uniform per half-wave
-                if (row < 32) {
-                    const int64_t m = m0 + band * 32 + row;
-                    const bool live = m < p.M;  // dead rows still take part in the shuffles
-                    const int64_t mo = (live ? m : p.M - 1) * N;
-                    f32x4 v[NV];
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        const int c4 = li + 32 * i;
-                        v[i] = z4;
-                        if (c4 < NQ) {
-                            const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * YS + 4 * c4);
-                            const f32x4 bs = *reinterpret_cast<const f32x4*>(Pc + 4 * c4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[i][e] = (y[e] + bs[e]) + rs[it][i][e];
-                        }
-                    }
-                    if (p.post_w) row_norm(v, Pc + N, Pc + 2 * N, p.post_eps);
-                    if (p.pos) {  // only the first spatial block of a pass
-                        const int f = (int)((m / p.posJ) % p.posF);
-#pragma unroll
-                        for (int i = 0; i < NV; ++i) {
-                            const int c4 = li + 32 * i;
-                            if (c4 < NQ) {
-                                const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * N + 4 * c4);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[i][e] += pe[e];
-                            }
-                        }
-                    }
-                    if (p.out_x && live) {
-#pragma unroll
-                        for (int i = 0; i < NV; ++i)
-                            if (li + 32 * i < NQ) *reinterpret_cast<f32x4*>(p.out_x + mo + 4 * (li + 32 * i)) = v[i];
-                    }
-                    if (p.next_w) {
-                        row_norm(v, Pc + 3 * N, Pc + 4 * N, p.next_eps);
-                        if (p.out_n && live) {
-#pragma unroll
-                            for (int i = 0; i < NV; ++i)
-                                if (li + 32 * i < NQ)
-                                    *reinterpret_cast<f32x4*>(p.out_n + mo + 4 * (li + 32 * i)) = v[i];
-                        }
-                        if (p.out_head) {
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) {
-                                float s = 0.f;
-#pragma unroll
-                                for (int i = 0; i < NV; ++i) {
-                                    const int c4 = li + 32 * i;
-                                    if (c4 < NQ) {
-                                        const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * N + 4 * c4);
-                                        s += (v[i][0] * hw[0] + v[i][1] * hw[1]) + (v[i][2] * hw[2] + v[i][3] * hw[3]);
-                                    }
-                                }
-                                s = half_wave_sum(s);
-                                if (li == 0 && live) p.out_head[m * 3 + k] = s + p.head_b[k];
-                            }
-                        }
-                    }
-                }
-            }
-            if (band + 1 < WM) __syncthreads();
-        }
-        PAFUSE_STAMP(2);
+        static_assert(TR, "the whole-row epilogue exists in row-per-lane (TR) form only");
     }
 }
 

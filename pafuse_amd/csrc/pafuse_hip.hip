@@ -35,14 +35,14 @@ int check_launch(const char* what) {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------ GEMM dispatch
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
     constexpr size_t stage_bytes = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
-    constexpr size_t ytile_bytes = EPI == EPI_ROWLN ? (size_t)(32 * (T::BN + 4) + 5 * T::BN) * sizeof(float) : 0;
-    constexpr size_t lds = stage_bytes > ytile_bytes ? stage_bytes : ytile_bytes;
+    static_assert(EPI != EPI_ROWLN || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
+    constexpr size_t lds = stage_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -59,24 +59,25 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
-    if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 2>(p, s);   // 1152, 768, 672: measured best
-    if (p.N % 128 == 0) return launch_gemm<4, 1, 4, EPI_BIAS, 2>(p, s);
-    if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 2>(p, s);
-    return launch_gemm<4, 1, 1, EPI_BIAS, 2>(p, s);
+    // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
+    // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
+    // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
+    if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1>(p, s);
+    if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>(p, s);  // row-per-lane epilogue wins at NT=3
+    return launch_gemm<4, 1, 1, EPI_BIAS, 1>(p, s);
 }
 
 int gemm_rowln(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
     switch (p.N) {
-        // 4-wave workgroups with wide per-wave strips, single LDS stage, 2-3 independent workgroups per CU that fill
-        // each other's barrier gaps (picked on MI355X with tools/gemm_bench.hip; 8-wave or 1-per-CU tiles idle
-        // the matrix pipe 40-60 %, 32-row tiles are bound by the per-CU load path)
-        case 384: return launch_gemm<2, 2, 6, EPI_ROWLN, 1, 2>(p, s);
-        case 256: return launch_gemm<2, 2, 4, EPI_ROWLN, 1, 3>(p, s);
-        case 224: return launch_gemm<1, 7, 1, EPI_ROWLN, 1>(p, s);
-        case 128: return launch_gemm<1, 4, 1, EPI_ROWLN, 1>(p, s);
-        case 64: return launch_gemm<1, 2, 1, EPI_ROWLN, 1>(p, s);
+        // row-per-lane accumulators (TR): LayerNorm statistics are in-lane sums + one shuffle + a tiny cross-wave
+        // exchange, all global traffic is dwordx4, no LDS transposition (picked with tools/gemm_bench.hip)
+        case 384: return launch_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>(p, s);
+        case 256: return launch_gemm<2, 2, 4, EPI_ROWLN, 1, 3, 1>(p, s);
+        case 224: return launch_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>(p, s);
+        case 128: return launch_gemm<1, 4, 1, EPI_ROWLN, 1, 1, 1>(p, s);
+        case 64: return launch_gemm<1, 2, 1, EPI_ROWLN, 1, 1, 1>(p, s);
         default: return fail(PAFUSE_E_SHAPE, "no whole-row kernel for channel width %d (have 64,128,224,256,384)", p.N);
     }
 }

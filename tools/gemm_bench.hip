@@ -10,14 +10,14 @@ using namespace pafuse;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
 float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     using T = GemmTile<WM, WN, NT>;
     if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
     if (const char* r = getenv("GB_REPS")) reps = atoi(r);
     size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * 4;
-    if (EPI == EPI_ROWLN && (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4 > lds) lds = (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4;
-    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    if (EPI == EPI_ROWLN && !TR && (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4 > lds) lds = (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4;
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     hipEvent_t e0, e1;
@@ -56,29 +56,57 @@ int main() {
     p.M = 25920, p.N = 1152, p.K = 384, p.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 2>("body qkv  <4,1,4> s2", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1>("body qkv  <4,1,4> s1", p);
     time_gemm<4, 1, 3, EPI_BIAS, 2>("body qkv  <4,1,3> s2", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 1>("body qkv  <4,1,3> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1>("body qkv  <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 1, 1>("body qkv  <4,1,2> s1 TR", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>("body qkv  <4,1,3> s1 TR", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 1, 1>("body qkv  <4,1,4> s1 TR", p);
+    time_gemm<4, 2, 2, EPI_BIAS, 1>("body qkv  <4,2,2> s1", p);
+    time_gemm<8, 1, 2, EPI_BIAS, 1>("body qkv  <8,1,2> s1", p);
+    time_gemm<2, 2, 2, EPI_BIAS, 1>("body qkv  <2,2,2> s1", p);
+    time_gemm<4, 1, 1, EPI_BIAS, 1>("body qkv  <4,1,1> s1", p);
+    time_gemm<2, 4, 2, EPI_BIAS, 1>("body qkv  <2,4,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body qkv  <4,1,2> s1 minw5", p);
     time_gemm<4, 1, 2, EPI_BIAS, 2>("body qkv  <4,1,2> s2", p);
     time_gemm<2, 2, 3, EPI_BIAS, 2>("body qkv  <2,2,3> s2", p);
     p.N = 768, p.act = 1; time_gemm<4, 1, 4, EPI_BIAS, 2>("body fc1+gelu <4,1,4> s2", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1>("body fc1+gelu <4,1,2> s1", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 2>("body fc1+gelu <4,1,3> s2", p);
     p.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 2>("body fc1 nogelu <4,1,4> s2", p);
     // face
     p.M = 73440, p.N = 672, p.K = 224, p.act = 0; time_gemm<4, 1, 7, EPI_BIAS, 1>("face qkv  <4,1,7> s1", p);
     time_gemm<4, 1, 7, EPI_BIAS, 2>("face qkv  <4,1,7> s2", p);
     time_gemm<4, 1, 3, EPI_BIAS, 2>("face qkv  <4,1,3> s2", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 1>("face qkv  <4,1,3> s1", p);
+    time_gemm<4, 1, 1, EPI_BIAS, 1>("face qkv  <4,1,1> s1", p);
     time_gemm<4, 1, 1, EPI_BIAS, 2>("face qkv  <4,1,1> s2", p);
     // hands
     p.M = 45360, p.N = 768, p.K = 256; time_gemm<4, 1, 4, EPI_BIAS, 2>("hands qkv <4,1,4> s2", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 2>("hands qkv <4,1,3> s2", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1>("hands qkv <4,1,2> s1", p);
     // rowln
     GemmParams q{};
     q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
     q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
     q.M = 25920, q.N = 384, q.K = 768;
     time_gemm<1, 4, 3, EPI_ROWLN, 1>("body fc2  rowln <1,4,3> s1", q);
+    time_gemm<2, 2, 6, EPI_ROWLN, 1, 2, 1>("body fc2  rowln <2,2,6> s1 TR", q);
+    time_gemm<2, 3, 4, EPI_ROWLN, 1, 2, 1>("body fc2  rowln <2,3,4> s1 TR", q);
+    time_gemm<2, 4, 3, EPI_ROWLN, 1, 2, 1>("body fc2  rowln <2,4,3> s1 TR", q);
+    time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,4,3> s1 TR", q);
+    time_gemm<1, 6, 2, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,6,2> s1 TR", q);
+    time_gemm<1, 3, 4, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,3,4> s1 TR", q);
+    time_gemm<1, 2, 6, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,2,6> s1 TR", q);
+    time_gemm<1, 4, 3, EPI_ROWLN, 2, 1, 1>("body fc2  rowln <1,4,3> s2 TR", q);
+    time_gemm<1, 12, 1, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,12,1> s1 TR", q);
     time_gemm<2, 4, 3, EPI_ROWLN, 1>("body fc2  rowln <2,4,3> s1", q);
     time_gemm<2, 4, 3, EPI_ROWLN, 1, 4>("body fc2  rowln <2,4,3> s1 minw4", q);
     time_gemm<2, 2, 6, EPI_ROWLN, 1, 2>("body fc2  rowln <2,2,6> s1 minw2", q);
     time_gemm<4, 2, 6, EPI_ROWLN, 1, 2>("body fc2  rowln <4,2,6> s1 minw2", q);
     time_gemm<4, 4, 3, EPI_ROWLN, 1, 4>("body fc2  rowln <4,4,3> s1 minw4", q);
     q.K = 384;
+    time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln <1,4,3> s1 TR", q);
+    time_gemm<2, 2, 6, EPI_ROWLN, 1, 2>("body proj rowln <2,2,6> s1 minw2", q);
     time_gemm<1, 4, 3, EPI_ROWLN, 1>("body proj rowln <1,4,3> s1", q);
     time_gemm<2, 4, 3, EPI_ROWLN, 1, 4>("body proj rowln <2,4,3> s1 minw4", q);
     q.M = 45360, q.N = 256, q.K = 512;
@@ -86,9 +114,19 @@ int main() {
     time_gemm<2, 4, 2, EPI_ROWLN, 1>("hands fc2  rowln <2,4,2> s1", q);
     time_gemm<2, 4, 2, EPI_ROWLN, 1, 4>("hands fc2  rowln <2,4,2> s1 minw4", q);
     time_gemm<2, 2, 4, EPI_ROWLN, 1, 3>("hands fc2  rowln <2,2,4> s1 minw3", q);
+    time_gemm<2, 2, 4, EPI_ROWLN, 1, 3, 1>("hands fc2  rowln <2,2,4> s1 TR", q);
+    time_gemm<1, 4, 2, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <1,4,2> s1 TR", q);
+    time_gemm<1, 8, 1, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <1,8,1> s1 TR", q);
+    time_gemm<1, 2, 4, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <1,2,4> s1 TR", q);
+    time_gemm<2, 4, 2, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <2,4,2> s1 TR", q);
+    time_gemm<4, 2, 4, EPI_ROWLN, 1, 2, 1>("hands fc2  rowln <4,2,4> s1 TR", q);
     time_gemm<4, 2, 4, EPI_ROWLN, 1, 2>("hands fc2  rowln <4,2,4> s1 minw2", q);
     q.M = 73440, q.N = 224, q.K = 448;
     time_gemm<1, 7, 1, EPI_ROWLN, 1>("face fc2  rowln <1,7,1> s1", q);
+    time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln <1,7,1> s1 TR", q);
+    time_gemm<2, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln <2,7,1> s1 TR", q);
+    time_gemm<4, 1, 7, EPI_ROWLN, 1, 2, 1>("face fc2  rowln <4,1,7> s1 TR", q);
+    time_gemm<2, 1, 7, EPI_ROWLN, 1, 2, 1>("face fc2  rowln <2,1,7> s1 TR", q);
     time_gemm<2, 7, 1, EPI_ROWLN, 1>("face fc2  rowln <2,7,1> s1", q);
     time_gemm<2, 7, 1, EPI_ROWLN, 1, 7>("face fc2  rowln <2,7,1> s1 minw7", q);
     time_gemm<4, 1, 7, EPI_ROWLN, 1, 2>("face fc2  rowln <4,1,7> s1 minw2", q);

@@ -25,6 +25,26 @@ __global__ void __launch_bounds__(256) k32(float* out, int iters, float seed, un
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
+// random fp32 operands (8 per lane, rotated) instead of one constant pair: what the chip sustains on real data
+template <int NACC>
+__global__ void __launch_bounds__(256) k32r(float* out, int iters, const float* rnd, unsigned long long* clk) {
+    f32x16 acc[NACC];
+    for (int n = 0; n < NACC; ++n) for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+    float a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = rnd[(threadIdx.x * 8 + i + blockIdx.x * 7) % 65536]; b[i] = rnd[(threadIdx.x * 8 + i + 32768 + blockIdx.x * 13) % 65536]; }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + n) & 7], acc[n], 0, 0, 0);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int n = 0; n < NACC; ++n) for (int i = 0; i < 16; ++i) s += acc[n][i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
 template <int NACC>
 __global__ void __launch_bounds__(256) k16(float* out, int iters, float seed) {
     f32x4 acc[NACC];
@@ -59,6 +79,25 @@ int main() {
         unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
         printf("32x32x2 f32, 4 acc, %d WG/CU: %.2f ms  %.1f TF/s   clock %.0f MHz (s_memtime/s_memrealtime)\n", wpc, ms,
                flops / ms / 1e9, (double)h[0] / h[1] * 100.0);
+    }
+    {
+        float* rnd; CK(hipMalloc(&rnd, 65536 * 4));
+        float* hr = (float*)malloc(65536 * 4);
+        for (int i = 0; i < 65536; ++i) hr[i] = (float)rand() / RAND_MAX * 2.f - 1.f;
+        CK(hipMemcpy(rnd, hr, 65536 * 4, hipMemcpyHostToDevice));
+        for (int wpc : {1, 2}) {
+            int blocks = 256 * wpc, iters = 40000;   // ~60 ms: long enough for DVFS to settle
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k32r<4>, dim3(blocks), dim3(256), 0, 0, out, iters, rnd, clk);
+                CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+            }
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            double flops = (double)blocks * 4 * iters * 8 * 4 * 4096.0;
+            unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+            printf("32x32x2 f32 RANDOM operands, 4 acc, %d WG/CU: %.2f ms  %.1f TF/s   clock %.0f MHz\n", wpc, ms,
+                   flops / ms / 1e9, (double)h[0] / h[1] * 100.0);
+        }
     }
     for (int wpc : {1, 2}) {
         int blocks = 256 * wpc, iters = 4000;
