@@ -89,7 +89,6 @@ int main() {
     q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
     q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
     q.M = 25920, q.N = 384, q.K = 768;
-    time_gemm<1, 4, 3, EPI_ROWLN, 1>("body fc2  rowln <1,4,3> s1", q);
     time_gemm<2, 2, 6, EPI_ROWLN, 1, 2, 1>("body fc2  rowln <2,2,6> s1 TR", q);
     time_gemm<2, 3, 4, EPI_ROWLN, 1, 2, 1>("body fc2  rowln <2,3,4> s1 TR", q);
     time_gemm<2, 4, 3, EPI_ROWLN, 1, 2, 1>("body fc2  rowln <2,4,3> s1 TR", q);
@@ -99,37 +98,20 @@ int main() {
     time_gemm<1, 2, 6, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,2,6> s1 TR", q);
     time_gemm<1, 4, 3, EPI_ROWLN, 2, 1, 1>("body fc2  rowln <1,4,3> s2 TR", q);
     time_gemm<1, 12, 1, EPI_ROWLN, 1, 1, 1>("body fc2  rowln <1,12,1> s1 TR", q);
-    time_gemm<2, 4, 3, EPI_ROWLN, 1>("body fc2  rowln <2,4,3> s1", q);
-    time_gemm<2, 4, 3, EPI_ROWLN, 1, 4>("body fc2  rowln <2,4,3> s1 minw4", q);
-    time_gemm<2, 2, 6, EPI_ROWLN, 1, 2>("body fc2  rowln <2,2,6> s1 minw2", q);
-    time_gemm<4, 2, 6, EPI_ROWLN, 1, 2>("body fc2  rowln <4,2,6> s1 minw2", q);
-    time_gemm<4, 4, 3, EPI_ROWLN, 1, 4>("body fc2  rowln <4,4,3> s1 minw4", q);
     q.K = 384;
     time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln <1,4,3> s1 TR", q);
-    time_gemm<2, 2, 6, EPI_ROWLN, 1, 2>("body proj rowln <2,2,6> s1 minw2", q);
-    time_gemm<1, 4, 3, EPI_ROWLN, 1>("body proj rowln <1,4,3> s1", q);
-    time_gemm<2, 4, 3, EPI_ROWLN, 1, 4>("body proj rowln <2,4,3> s1 minw4", q);
     q.M = 45360, q.N = 256, q.K = 512;
-    time_gemm<1, 8, 1, EPI_ROWLN, 1>("hands fc2  rowln <1,8,1> s1", q);
-    time_gemm<2, 4, 2, EPI_ROWLN, 1>("hands fc2  rowln <2,4,2> s1", q);
-    time_gemm<2, 4, 2, EPI_ROWLN, 1, 4>("hands fc2  rowln <2,4,2> s1 minw4", q);
-    time_gemm<2, 2, 4, EPI_ROWLN, 1, 3>("hands fc2  rowln <2,2,4> s1 minw3", q);
     time_gemm<2, 2, 4, EPI_ROWLN, 1, 3, 1>("hands fc2  rowln <2,2,4> s1 TR", q);
     time_gemm<1, 4, 2, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <1,4,2> s1 TR", q);
     time_gemm<1, 8, 1, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <1,8,1> s1 TR", q);
     time_gemm<1, 2, 4, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <1,2,4> s1 TR", q);
     time_gemm<2, 4, 2, EPI_ROWLN, 1, 1, 1>("hands fc2  rowln <2,4,2> s1 TR", q);
     time_gemm<4, 2, 4, EPI_ROWLN, 1, 2, 1>("hands fc2  rowln <4,2,4> s1 TR", q);
-    time_gemm<4, 2, 4, EPI_ROWLN, 1, 2>("hands fc2  rowln <4,2,4> s1 minw2", q);
     q.M = 73440, q.N = 224, q.K = 448;
-    time_gemm<1, 7, 1, EPI_ROWLN, 1>("face fc2  rowln <1,7,1> s1", q);
     time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln <1,7,1> s1 TR", q);
     time_gemm<2, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln <2,7,1> s1 TR", q);
     time_gemm<4, 1, 7, EPI_ROWLN, 1, 2, 1>("face fc2  rowln <4,1,7> s1 TR", q);
     time_gemm<2, 1, 7, EPI_ROWLN, 1, 2, 1>("face fc2  rowln <2,1,7> s1 TR", q);
-    time_gemm<2, 7, 1, EPI_ROWLN, 1>("face fc2  rowln <2,7,1> s1", q);
-    time_gemm<2, 7, 1, EPI_ROWLN, 1, 7>("face fc2  rowln <2,7,1> s1 minw7", q);
-    time_gemm<4, 1, 7, EPI_ROWLN, 1, 2>("face fc2  rowln <4,1,7> s1 minw2", q);
     // same shapes as plain-bias kernels: what the whole-row epilogue costs
     p.M = 25920, p.N = 384, p.K = 768, p.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 2>("body fc2 as plain <4,1,4> s2", p);
     p.M = 73440, p.N = 224, p.K = 448; time_gemm<4, 1, 7, EPI_BIAS, 1>("face fc2 as plain <4,1,7> s1", p);

@@ -10,12 +10,11 @@
 using namespace pafuse;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
 void life(const char* tag, GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
     size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * 4;
-    if (EPI == EPI_ROWLN && (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4 > lds) lds = (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4;
-    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     size_t nw = tiles * (T::NTHR / 64);
@@ -61,18 +60,18 @@ int main() {
     GemmParams p{};
     p.A = A, p.W = W, p.bias = bias, p.out = out;
     p.M = 25920, p.N = 1152, p.K = 384;
-    life<4, 1, 3, EPI_BIAS, 2>("body qkv <4,1,3> s2", p);
-    life<4, 1, 4, EPI_BIAS, 2>("body qkv <4,1,4> s2", p);
+    life<4, 1, 2, EPI_BIAS, 1>("body qkv <4,1,2> s1", p);
+    life<4, 1, 3, EPI_BIAS, 1, 1, 1>("body qkv <4,1,3> s1 TR", p);
     p.N = 768, p.act = 1;
-    life<4, 1, 3, EPI_BIAS, 2>("body fc1+gelu <4,1,3> s2", p);
+    life<4, 1, 2, EPI_BIAS, 1>("body fc1+gelu <4,1,2> s1", p);
     GemmParams q{};
     q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
     q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
     q.M = 25920, q.N = 384, q.K = 768;
-    life<2, 2, 6, EPI_ROWLN, 1, 2>("body fc2 rowln <2,2,6> s1", q);
+    life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2 rowln <1,4,3> s1 TR", q);
     q.K = 384;
-    life<2, 2, 6, EPI_ROWLN, 1, 2>("body proj rowln <2,2,6> s1", q);
+    life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln <1,4,3> s1 TR", q);
     q.M = 73440, q.N = 224, q.K = 448;
-    life<1, 7, 1, EPI_ROWLN, 1>("face fc2 rowln <1,7,1> s1", q);
+    life<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2 rowln <1,7,1> s1 TR", q);
     return 0;
 }
