@@ -17,6 +17,7 @@
  *   pafuse_mixste2_forward   MixSTE2.forward (is_train=False), common/mixste.py:278-298
  *   pafuse_d3dp_sample       D3DP.ddim_sample_flip / ddim_sample, common/diffusionpose.py:227-316
  *                            (with model_predictions[_fliping] :174-225, pred_parts/split_data :163-172,328-335)
+ *   pafuse_hypothesis_errors the per-joint part of evaluate()'s aggregation, main_h3wb.py:327-362
  */
 #ifndef PAFUSE_HIP_H
 #define PAFUSE_HIP_H
@@ -134,6 +135,17 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *st
                        const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,
                        int32_t P, float *out, void *workspace, size_t workspace_bytes, void *stream,
                        void *const *aux_streams, int32_t n_aux);
+
+/* Hypothesis aggregation on the gathered predictions - the caller-side step of main_h3wb.py:327-362
+ * (wb_pose_from_parts common/utils.py:113-126, project_to_2d common/camera.py:30-60, the per-joint parts of
+ * mpjpe_diffusion* common/loss.py:36-168).  pred [B,T,P,F,J,3] and gt [B,F,J,3] are part-centred; x2d [B,F,J,2];
+ * traj [B,F,3]; cam [9]; conn/pbroot int32 [J] (connection joint / part root of every joint).
+ * Outputs: e3, epb [B,T,P,F,J] (per-hypothesis whole-body / part-re-centred errors), jbest, pagg, jagg,
+ * paggpb [B,T,F,J].  The means over (b,f,j) and the P-Best argmin are left to the caller (a few tiny reductions). */
+int pafuse_hypothesis_errors(const float *pred, const float *gt, const float *x2d, const float *traj, const float *cam,
+                             const int32_t *conn, const int32_t *pbroot, int32_t B, int32_t T, int32_t P, int32_t F,
+                             int32_t J, float *e3, float *epb, float *jbest, float *pagg, float *jagg, float *paggpb,
+                             void *stream);
 
 /* Replays the GEMM launches of one flip-TTA denoiser pass (all three parts) back to back on `stream`, for
  * bench.py's per-kernel roofline measurement: returns the number of launches, adds their algorithmic FLOPs to

@@ -347,3 +347,36 @@ def j_agg(pred: Tensor, target: Tensor, reproj_2d: Tensor, target_2d: Tensor) ->
     sel = torch.gather(e3, 2, e2.min(dim=2, keepdim=True).indices)
     sel = sel.permute(1, 2, 0, 3, 4)
     return sel.reshape(sel.shape[0], -1).mean(dim=-1)
+
+
+def _part_means(err: Tensor, part_joints) -> Dict[str, Tensor]:
+    """err [T, ..., J] -> per-part mean over everything but T."""
+    return {part: err[..., idx].reshape(err.shape[0], -1).mean(dim=-1) for part, idx in part_joints.items()}
+
+
+def evaluate_accumulators(pred_parts: Tensor, gt_parts: Tensor, inputs_2d: Tensor, traj: Tensor, cam: Tensor,
+                          part_joints=None) -> Dict[str, Tensor]:
+    """The 14 per-step error vectors evaluate() accumulates per batch (reference main_h3wb.py:327-362):
+    whole-body poses from parts, 2-D reprojection for J-Agg, J-Best / P-Best / P-Agg / J-Agg, and the part-based
+    P-Best / P-Agg with their per-part break-down (common/loss.py:36-168).  Inputs are part-centred, metres."""
+    part_joints = part_joints or DATASET_PART_JOINTS
+    pred = wb_pose_from_parts(pred_parts.clone())
+    gt = wb_pose_from_parts(gt_parts.clone())
+    B, T, P, Fr = pred.shape[:4]
+    absolute = (pred + traj[:, None, None]).reshape(B * T * P * Fr, pred.shape[-2], 3)
+    reproj = project_to_2d(absolute, cam.reshape(1, 9).repeat(B * T * P * Fr, 1)).reshape(B, T, P, Fr, -1, 2)
+    out = {"j_best": j_best(pred, gt), "p_best": p_best(pred, gt), "p_agg": p_agg(pred, gt),
+           "j_agg": j_agg(pred, gt, reproj, inputs_2d)}
+    cp, cg = center_pose_parts(pred), center_pose_parts(gt)
+    e = _errors(cp, cg).permute(1, 2, 0, 3, 4)                               # t h b f n
+    per_h = e.reshape(e.shape[0], e.shape[1], -1).mean(dim=-1)
+    best = per_h.argmin(dim=1)                                               # common/loss.py:145
+    out["p_best_pb"] = per_h.min(dim=1).values
+    for part, idx in part_joints.items():
+        ph = e[..., idx].reshape(e.shape[0], e.shape[1], -1).mean(dim=-1)
+        out["p_best_pb_" + part] = ph.gather(1, best.view(-1, 1)).squeeze(1)
+    em = torch.norm(cp.mean(dim=2) - cg[:, None], dim=-1).permute(1, 0, 2, 3)  # t b f n
+    out["p_agg_pb"] = em.reshape(em.shape[0], -1).mean(dim=-1)
+    for part, v in _part_means(em, part_joints).items():
+        out["p_agg_pb_" + part] = v
+    return out

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pafuse_d3dp_sample": (C.c_int, [C.POINTER(D3DPConfig), C.POINTER(DDIMStep), C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
+    "pafuse_hypothesis_errors": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 7),
     "pafuse_d3dp_replay_gemms": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.POINTER(C.c_double)]),
 }

@@ -752,4 +752,90 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Hypothesis aggregation behind the all-gather (caller side of the path: main_h3wb.py:327-362 with
+// common/utils.py:113-126, common/camera.py:30-60, common/loss.py:36-168).  One thread per (b, t, f, joint) walks
+// the P hypotheses once: whole-body pose from parts, per-joint errors, J-Best minimum, P-Agg mean pose, the 2-D
+// reprojection argmin of J-Agg, and the part-re-centred variants.  The per-hypothesis errors go to scratch so
+// that the (tiny) P-Best means/argmin over (b, f, j) are formed afterwards in a fixed order.
+// ----------------------------------------------------------------------------------------------------------------
+struct MetricsParams {
+    const float* pred;  // [B,T,P,F,J,3] part-centred predictions
+    const float* gt;    // [B,F,J,3] part-centred ground truth
+    const float* x2d;   // [B,F,J,2]
+    const float* traj;  // [B,F,3] root trajectory
+    const float* cam;   // [9] f(2) c(2) k(3) p(2)
+    const int32_t *conn, *pbroot;  // [J]: connection joint (wb_pose_from_parts), part root (center_pose_parts)
+    float *e3, *epb;                       // [B,T,P,F,J] per-hypothesis errors (whole-body / part-centred)
+    float *jbest, *pagg, *jagg, *paggpb;   // [B,T,F,J]
+    int B, T, P, F, J;
+};
+
+__device__ __forceinline__ void wb_joint(const float* pose /*[J,3]*/, const int32_t* conn, int j, float (&o)[3]) {
+    // out[j] = pose[j] + pose[conn[j]], joint 0 forced to 0 (the net effect of wb_pose_from_parts' in-place pass)
+    if (j == 0) {
+        o[0] = o[1] = o[2] = 0.f;
+        return;
+    }
+    const float* a = pose + j * 3;
+    const float* c = pose + conn[j] * 3;
+    o[0] = a[0] + c[0], o[1] = a[1] + c[1], o[2] = a[2] + c[2];
+}
+
+__global__ void __launch_bounds__(256) metrics_kernel(const MetricsParams p) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)p.B * p.T * p.F * p.J;
+    if (e >= total) return;
+    const int j = (int)(e % p.J);
+    const int f = (int)((e / p.J) % p.F);
+    const int t = (int)((e / ((int64_t)p.J * p.F)) % p.T);
+    const int b = (int)(e / ((int64_t)p.J * p.F * p.T));
+    const int jr = p.pbroot[j];
+    const float* gpose = p.gt + ((int64_t)b * p.F + f) * p.J * 3;
+    float g[3], gr[3];
+    wb_joint(gpose, p.conn, j, g);
+    wb_joint(gpose, p.conn, jr, gr);
+    const float gc[3] = {g[0] - gr[0], g[1] - gr[1], g[2] - gr[2]};
+    const float* tr = p.traj + ((int64_t)b * p.F + f) * 3;
+    const float* x2 = p.x2d + (((int64_t)b * p.F + f) * p.J + j) * 2;
+    const float fx = p.cam[0], fy = p.cam[1], cx = p.cam[2], cy = p.cam[3];
+    const float k1 = p.cam[4], k2 = p.cam[5], k3 = p.cam[6], p1 = p.cam[7], p2 = p.cam[8];
+    float best3 = INFINITY, best2 = INFINITY, sel3 = 0.f;
+    float sm[3] = {0.f, 0.f, 0.f}, smr[3] = {0.f, 0.f, 0.f};
+    for (int h = 0; h < p.P; ++h) {
+        const float* pose = p.pred + ((((int64_t)b * p.T + t) * p.P + h) * p.F + f) * p.J * 3;
+        float w[3], wr[3];
+        wb_joint(pose, p.conn, j, w);
+        wb_joint(pose, p.conn, jr, wr);
+        const float d0 = w[0] - g[0], d1 = w[1] - g[1], d2 = w[2] - g[2];
+        const float e3 = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+        const float c0 = (w[0] - wr[0]) - gc[0], c1 = (w[1] - wr[1]) - gc[1], c2 = (w[2] - wr[2]) - gc[2];
+        const float epb = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+        const int64_t o = ((((int64_t)b * p.T + t) * p.P + h) * p.F + f) * p.J + j;
+        p.e3[o] = e3;
+        p.epb[o] = epb;
+        best3 = fminf(best3, e3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sm[k] += w[k], smr[k] += wr[k];
+        // 2-D reprojection of the absolute pose (common/camera.py:30-60)
+        const float X = w[0] + tr[0], Y = w[1] + tr[1], Z = w[2] + tr[2];
+        const float xx = fminf(fmaxf(X / Z, -1.f), 1.f), yy = fminf(fmaxf(Y / Z, -1.f), 1.f);
+        const float r2 = xx * xx + yy * yy;
+        const float radial = 1.f + (k1 * r2 + k2 * (r2 * r2) + k3 * (r2 * r2 * r2));
+        const float tan = p1 * xx + p2 * yy;
+        const float u = fx * (xx * (radial + tan) + p1 * r2) + cx, v = fy * (yy * (radial + tan) + p2 * r2) + cy;
+        const float q0 = u - x2[0], q1 = v - x2[1];
+        const float e2 = sqrtf(q0 * q0 + q1 * q1);
+        if (e2 < best2) best2 = e2, sel3 = e3;  // first minimum wins, like torch.min(...).indices
+    }
+    const float invP = 1.0f / (float)p.P;
+    const float m0 = sm[0] * invP - g[0], m1 = sm[1] * invP - g[1], m2 = sm[2] * invP - g[2];
+    const float n0 = (sm[0] - smr[0]) * invP - gc[0], n1 = (sm[1] - smr[1]) * invP - gc[1],
+                n2 = (sm[2] - smr[2]) * invP - gc[2];
+    p.jbest[e] = best3;
+    p.jagg[e] = sel3;
+    p.pagg[e] = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+    p.paggpb[e] = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+}
+
 }  // namespace pafuse

@@ -460,6 +460,22 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     return rc;
 }
 
+int pafuse_hypothesis_errors(const float* pred, const float* gt, const float* x2d, const float* traj, const float* cam,
+                             const int32_t* conn, const int32_t* pbroot, int32_t B, int32_t T, int32_t P, int32_t F,
+                             int32_t J, float* e3, float* epb, float* jbest, float* pagg, float* jagg, float* paggpb,
+                             void* stream) {
+    if (!pred || !gt || !x2d || !traj || !cam || !conn || !pbroot || !e3 || !epb || !jbest || !pagg || !jagg || !paggpb)
+        return fail(PAFUSE_E_ARG, "hypothesis_errors: null pointer");
+    if (B <= 0 || T <= 0 || P <= 0 || F <= 0 || J <= 0) return fail(PAFUSE_E_ARG, "hypothesis_errors: bad size");
+    MetricsParams m{};
+    m.pred = pred, m.gt = gt, m.x2d = x2d, m.traj = traj, m.cam = cam, m.conn = conn, m.pbroot = pbroot;
+    m.e3 = e3, m.epb = epb, m.jbest = jbest, m.pagg = pagg, m.jagg = jagg, m.paggpb = paggpb;
+    m.B = B, m.T = T, m.P = P, m.F = F, m.J = J;
+    const int64_t n = (int64_t)B * T * F * J;
+    hipLaunchKernelGGL(metrics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, m);
+    return check_launch("metrics_kernel");
+}
+
 int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, void* workspace,
                              size_t workspace_bytes, void* stream, double* flops) {
     int rc = d3dp_check(cfg, B, P);

@@ -284,6 +284,40 @@ def g7_metrics():
          j_agg=mpjpe_diffusion_reproj(pred, target, reproj, target_2d))
 
 
+# -------------------------------------------------------------------------------------------------- G9
+def g9_evaluate_accumulators():
+    """the 14 per-step error vectors evaluate() accumulates (main_h3wb.py:327-362) on random part-centred inputs."""
+    from common.utils import center_pose_parts, wb_pose_from_parts
+    from common.loss import mpjpe_diffusion, mpjpe_diffusion_all_min, mpjpe_diffusion_reproj
+    from common.camera import project_to_2d
+    ds = FakeDataset()
+    ds.parts_connection_indices = dict(gu.CONNECTION_INDICES)
+    g = torch.Generator().manual_seed(91)
+    B, T, P, Fr = 2, 3, 5, 27
+    pred_parts = center_pose_parts(torch.randn(B, T, P, Fr, 134, 3, generator=g) * 0.3, ds)
+    gt_parts = center_pose_parts(torch.randn(B, Fr, 134, 3, generator=g) * 0.3, ds)
+    x2d = torch.rand(B, Fr, 134, 2, generator=g) * 2 - 1
+    traj = torch.randn(B, Fr, 1, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, 4.0])
+    cam = torch.tensor([[2.29, 2.287, 0.025, 0.029, -0.207, 0.247, -0.003, -0.0009, -0.001]])
+    pred = wb_pose_from_parts(pred_parts.clone(), ds)
+    gt = wb_pose_from_parts(gt_parts.clone(), ds)
+    absolute = (pred + traj.unsqueeze(1).unsqueeze(1)).reshape(B * T * P * Fr, 134, 3)
+    reproj = project_to_2d(absolute, cam.repeat(B * T * P * Fr, 1)).reshape(B, T, P, Fr, 134, 2)
+    out = {"j_best": mpjpe_diffusion_all_min(pred, gt), "p_best": mpjpe_diffusion(pred, gt)[0],
+           "p_agg": mpjpe_diffusion_all_min(pred, gt, mean_pos=True),
+           "j_agg": mpjpe_diffusion_reproj(pred, gt, reproj, x2d)}
+    e, parts = mpjpe_diffusion(pred.clone(), gt.clone(), part_based=True, dataset=ds)
+    out["p_best_pb"] = e
+    for k, v in parts.items():
+        out["p_best_pb_" + k] = v
+    e, parts = mpjpe_diffusion_all_min(pred.clone(), gt.clone(), mean_pos=True, part_based=True, dataset=ds)
+    out["p_agg_pb"] = e
+    for k, v in parts.items():
+        out["p_agg_pb_" + k] = v
+    assert len(out) == 14
+    save("g9_evaluate.npz", pred_parts=pred_parts, gt_parts=gt_parts, x2d=x2d, traj=traj, cam=cam, **out)
+
+
 # -------------------------------------------------------------------------------------------------- G8
 def g8_default_init():
     """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
@@ -297,8 +331,8 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
-                 g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init)
+                 g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators)
     for w in which:
         table[w]()

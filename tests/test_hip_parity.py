@@ -240,6 +240,21 @@ def test_hypothesis_axis_is_independent():
     assert torch.equal(full, torch.cat(halves, dim=2))
 
 
+def test_clip_axis_is_independent():
+    """a clip's result does not depend on what else is in the batch (rows never mix across clips): the B=3 run
+    equals three B=1 runs bit for bit - the size-independent property behind batching whole sequences."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(2, 2, seed=80)
+    x2d, x2f = gu.synthetic_inputs_2d(B=3)
+    noises = gu.synthetic_noises(B=3, P=2, n=2, seed=6)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    full = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    for b in range(3):
+        model.noise_fn = lambda k, shape, device, b=b: noises[k][b:b + 1]
+        one = model(x2d[b:b + 1].to(DEV), None, input_2d_flip=x2f[b:b + 1].to(DEV))
+        assert torch.equal(one, full[b:b + 1]), b
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
@@ -256,3 +271,20 @@ def test_errors_are_loud():
     with pytest.raises(_lib.PafuseError):       # CPU tensors: no CPU fallback
         pafuse_amd.MixSTE2(27, 24, 5, 384, 1, 8, drop_path_rate=0.0, is_train=False)(
             torch.zeros(1, 27, 24, 2), torch.zeros(1, 1, 27, 24, 3), torch.zeros(1, dtype=torch.long))
+
+
+def test_g9_evaluate_accumulators_golden():
+    """the aggregation kernel + reductions reproduce the reference's 14 accumulators."""
+    from types import SimpleNamespace
+    from pafuse_amd.evaluate import evaluate_accumulators
+    z = load_golden("g9_evaluate.npz")
+    ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES,
+                         parts_connection_indices=dict(gu.CONNECTION_INDICES))
+    got = evaluate_accumulators(z["pred_parts"].to(DEV), z["gt_parts"].to(DEV), z["x2d"].to(DEV), z["traj"].to(DEV),
+                                z["cam"].to(DEV), ds)
+    keys = [k for k in z if k not in ("pred_parts", "gt_parts", "x2d", "traj", "cam")]
+    assert len(keys) == 14 and set(keys) == set(got)
+    for k in keys:
+        # fp32 means of ~1.3 m synthetic errors: one ulp is 1.2e-7; device FMA contraction in the projection and a
+        # different summation order move the result by a few ulps
+        assert torch.allclose(got[k].cpu(), z[k], rtol=1e-6, atol=0), (k, (got[k].cpu() - z[k]).abs().max())

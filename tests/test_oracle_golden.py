@@ -126,3 +126,12 @@ def test_g7_metrics():
     assert torch.allclose(orc.p_best(pred, target), z["p_best"], rtol=0, atol=1e-7)
     assert torch.allclose(orc.p_agg(pred, target), z["p_agg"], rtol=0, atol=1e-7)
     assert torch.allclose(orc.j_agg(pred, target, z["reproj"], z["target_2d"]), z["j_agg"], rtol=0, atol=1e-7)
+
+
+def test_g9_evaluate_accumulators():
+    z = load_golden("g9_evaluate.npz")
+    got = orc.evaluate_accumulators(z["pred_parts"], z["gt_parts"], z["x2d"], z["traj"], z["cam"])
+    keys = [k for k in z if k not in ("pred_parts", "gt_parts", "x2d", "traj", "cam")]
+    assert len(keys) == 14 and set(keys) == set(got)
+    for k in keys:
+        assert torch.allclose(got[k], z[k], rtol=0, atol=1e-7), (k, got[k], z[k])
