@@ -409,6 +409,23 @@ struct AttnParams {
     float scale;
 };
 
+// Item -> (sequence, head).  The 8 heads of a sequence read interleaved 112..192-byte slices of the same qkv rows;
+// workgroups b and b+8 share an XCD (round-robin dispatch), so the heads of one sequence are given to workgroups of
+// one XCD and the partially used cache lines are L2 hits for 7 of them (speed only; plain order when nseq % 8 != 0).
+template <int ITEMS>
+__device__ __forceinline__ void attn_item(int64_t i, int64_t nseq, int heads, int64_t& seq, int& head) {
+    if (nseq % 8 == 0) {
+        const int64_t blk = i / ITEMS;
+        const int lo = (int)(blk % 8);
+        const int64_t u = (blk / 8) * ITEMS + (i % ITEMS);
+        head = (int)(u % heads);
+        seq = (u / heads) * 8 + lo;
+    } else {
+        seq = i / heads;
+        head = (int)(i % heads);
+    }
+}
+
 template <int LP, int DP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
     constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16, ITEMS = NW / QT, LDV = DP + 4;
@@ -421,59 +438,67 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
     const int64_t nitems = p.nseq * p.heads;
     const int C3 = 3 * p.C;
 
-    // stage K and V of this workgroup's items (zero-padded to LP x DP)
-    for (int il = 0; il < ITEMS; ++il) {
-        const int64_t item = (int64_t)blockIdx.x * ITEMS + il;
-        const bool ok = item < nitems;
-        const int64_t seq = ok ? item / p.heads : 0;
-        const int head = ok ? (int)(item % p.heads) : 0;
-        const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
-        for (int idx = tid; idx < LP * C4; idx += NTHR) {
-            const int t = idx / C4, c4 = idx % C4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (ok && t < p.L && c4 * 4 < p.d) {
-                const float* src = p.qkv + (base + t * p.tok_stride) * C3 + head * p.d + c4 * 4;
-                kv = *reinterpret_cast<const f32x4*>(src + p.C);
-                vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
-            }
-            *reinterpret_cast<f32x4*>(Ks + (il * LP + t) * LDV + c4 * 4) = kv;
-            *reinterpret_cast<f32x4*>(Vs + (il * LP + t) * LDV + c4 * 4) = vv;
-        }
-    }
-    __syncthreads();
-
+    // this wave's item and Q fragments first (straight from global: query = 16*qt + l15, dk = 16*s + 4*g .. +3), so
+    // their latency overlaps the K/V staging below
     const int il = wave / QT, qt = wave % QT;
     const int64_t item = (int64_t)blockIdx.x * ITEMS + il;
-    if (item >= nitems) return;
-    const int64_t seq = item / p.heads;
-    const int head = (int)(item % p.heads);
+    const bool mine = item < nitems;
+    int64_t seq = 0;
+    int head = 0;
+    if (mine) attn_item<ITEMS>(item, p.nseq, p.heads, seq, head);
     const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
     const int l15 = lane & 15, g = lane >> 4;
-
-    // Q fragments straight from global: query = 16*qt + l15, dk = 16*s + 4*g .. +3
     f32x4 qf[SD];
     {
         const int q = qt * 16 + l15;
 #pragma unroll
         for (int s = 0; s < SD; ++s) {
             qf[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q < p.L && 16 * s + 4 * g < p.d)
+            if (mine && q < p.L && 16 * s + 4 * g < p.d)
                 qf[s] = *reinterpret_cast<const f32x4*>(p.qkv + (base + q * p.tok_stride) * C3 + head * p.d + 16 * s +
                                                         4 * g);
         }
     }
+    // stage K and V of this workgroup's items (zero-padded to LP x DP)
+    for (int sl = 0; sl < ITEMS; ++sl) {
+        const int64_t it2 = (int64_t)blockIdx.x * ITEMS + sl;
+        const bool ok = it2 < nitems;
+        int64_t seq2 = 0;
+        int head2 = 0;
+        if (ok) attn_item<ITEMS>(it2, p.nseq, p.heads, seq2, head2);
+        const int64_t base2 = (seq2 / p.group) * p.group_stride + (seq2 % p.group) * p.seq_stride;
+        for (int idx = tid; idx < LP * C4; idx += NTHR) {
+            const int t = idx / C4, c4 = idx % C4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (ok && t < p.L && c4 * 4 < p.d) {
+                const float* src = p.qkv + (base2 + t * p.tok_stride) * C3 + head2 * p.d + c4 * 4;
+                kv = *reinterpret_cast<const f32x4*>(src + p.C);
+                vv = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            }
+            *reinterpret_cast<f32x4*>(Ks + (sl * LP + t) * LDV + c4 * 4) = kv;
+            *reinterpret_cast<f32x4*>(Vs + (sl * LP + t) * LDV + c4 * 4) = vv;
+        }
+    }
+    __syncthreads();
+    if (!mine) return;
     const float* Kb = Ks + il * LP * LDV;
     const float* Vb = Vs + il * LP * LDV;
+    // key tiles innermost: KT independent accumulators back to back (a 16x16x4 MFMA has 40 cycles of dependent
+    // latency against 32 of issue)
     f32x4 sc[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < SD; ++s) {
-            const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + (kt * 16 + l15) * LDV + 16 * s + 4 * g);
+    for (int s = 0; s < SD; ++s) {
+        f32x4 kf[KT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j], qf[s][j], sc[kt], 0, 0, 0);
-        }
+        for (int kt = 0; kt < KT; ++kt)
+            kf[kt] = *reinterpret_cast<const f32x4*>(Kb + (kt * 16 + l15) * LDV + 16 * s + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j], qf[s][j], sc[kt], 0, 0, 0);
     }
     // sc[kt][reg] = <q, k> for query 16*qt + l15 and key 16*kt + 4*g + reg
     float mx = -INFINITY;
@@ -488,22 +513,28 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
         }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // exp((s - max)) as exp2 of a pre-scaled argument: |s - max| stays below ~30 here, so the fp32 product with
+    // log2(e) costs at most a few 1e-6 of RELATIVE error on terms that are themselves exponentially small, and the
+    // hardware v_exp_f32 is accurate to ~1 ulp; one reciprocal of the row sum replaces KT*4 divisions.
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const float e = expf(sc[kt][reg] - mx);
+            const float e = __builtin_amdgcn_exp2f((sc[kt][reg] - mx) * 1.44269504088896340736f);
             sc[kt][reg] = e;
             sum += e;
         }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) sc[kt][reg] = sc[kt][reg] / sum;
+        for (int reg = 0; reg < 4; ++reg) sc[kt][reg] *= inv;
 
+    // O^T = V^T P^T: the V element is the A operand (row = channel), the probability the B operand (column =
+    // query), so each lane ends with 4 consecutive channels of ONE query per 16-channel block: a dwordx4 store
     f32x4 oc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) oc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -514,17 +545,15 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
             const float* vrow = Vb + (kt * 16 + 4 * g + reg) * LDV + l15;
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
-                oc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(sc[kt][reg], vrow[ct * 16], oc[ct], 0, 0, 0);
+                oc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ct * 16], sc[kt][reg], oc[ct], 0, 0, 0);
         }
-    // oc[ct][reg] = O[query 16*qt + 4*g + reg][channel 16*ct + l15]
+    // oc[ct][reg] = O[query 16*qt + l15][channel 16*ct + 4*g + reg]
+    const int q = qt * 16 + l15;
+    if (q < p.L) {
+        float* orow = p.o + (base + q * p.tok_stride) * p.C + head * p.d + 4 * g;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int ch = ct * 16 + l15;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int q = qt * 16 + 4 * g + reg;
-            if (q < p.L && ch < p.d) p.o[(base + q * p.tok_stride) * p.C + head * p.d + ch] = oc[ct][reg];
-        }
+        for (int ct = 0; ct < CT; ++ct)
+            if (ct * 16 + 4 * g < p.d) *reinterpret_cast<f32x4*>(orow + ct * 16) = oc[ct];
     }
 }
 
