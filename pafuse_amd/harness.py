@@ -1,0 +1,88 @@
+"""Caller side of the hot path: what the reference's evaluate() does around ``model_eval(...)`` for one sequence
+(main_h3wb.py:261-379) - flip copy, cutting into 27-frame clips, part centring, batched sampling, the 14
+accumulators - with tensors kept on the HIP device.  SURVEY.md section 8f rows n1/n3 (partial: no dataset files
+or Hydra here; the caller hands in arrays).
+"""
+import torch
+
+from .evaluate import evaluate_accumulators
+from .parallel import ShardedSampler
+
+ACCUMULATORS = ("j_best", "p_best", "p_agg", "j_agg", "p_best_pb", "p_best_pb_body", "p_best_pb_face",
+                "p_best_pb_left_hand", "p_best_pb_right_hand", "p_agg_pb", "p_agg_pb_body", "p_agg_pb_face",
+                "p_agg_pb_left_hand", "p_agg_pb_right_hand")
+
+
+def flip_2d(inputs_2d, kps_left, kps_right):
+    """Test-time-augmentation copy of the 2-D input: negate x, swap left/right joints (main_h3wb.py:268-270)."""
+    out = inputs_2d.clone()
+    out[..., 0] *= -1
+    out[..., list(kps_left) + list(kps_right), :] = out[..., list(kps_right) + list(kps_left), :]
+    return out
+
+
+def cut_clips(seq, frames=27):
+    """[N, J, c] (or [1, N, J, c]) -> [ceil(N/frames), frames, J, c]: consecutive clips, the last one holding the LAST
+    `frames` frames (so it overlaps its predecessor), sequences shorter than a clip padded by repeating the final
+    frame (eval_data_prepare, main_h3wb.py:122-154)."""
+    if seq.dim() == 4:
+        seq = seq.squeeze(0)
+    n = seq.shape[0]
+    if n < frames:
+        seq = torch.cat([seq, seq[-1:].expand(frames - n, *seq.shape[1:])], dim=0)
+        n = frames
+    full = n // frames
+    clips = [seq[i * frames:(i + 1) * frames] for i in range(full - (1 if n % frames == 0 else 0))]
+    clips.append(seq[-frames:])
+    return torch.stack(clips)
+
+
+def center_pose_parts(pose, dataset):
+    """Every part translated so that its own root joint is the origin (common/utils.py:97-112)."""
+    out = torch.zeros_like(pose)
+    for part, idx in dataset.parts_joint_indices.items():
+        root = dataset.root_indices[part]
+        out[..., idx, :] = pose[..., idx, :] - pose[..., root:root + 1, :]
+    return out
+
+
+def load_checkpoint(model, checkpoint):
+    """Accept what the reference saves (common/logging.py:83-115): a dict with 'model_pos', DataParallel
+    ``module.``-prefixed keys, or a bare state dict."""
+    sd = checkpoint.get("model_pos", checkpoint) if isinstance(checkpoint, dict) else checkpoint
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    return model.load_state_dict(sd)
+
+
+@torch.no_grad()
+def evaluate_sequence(model, dataset, seq_2d, seq_3d, cam, kps_left, kps_right, batch_size=1024, group=None):
+    """One (camera, sequence) item of evaluate()'s loop (main_h3wb.py:261-396).
+
+    seq_2d [N,J,2] normalised 2-D input, seq_3d [N,J,3] camera-space ground truth (metres), cam [9] intrinsics.
+    Returns ``(sums, n)``: the 14 accumulators [T] already multiplied by the batch multiplier (clips x frames), and
+    the multiplier total - add them over sequences and report ``sums[k] / n * 1000`` mm, like :func:`report`.
+    With torch.distributed initialised the hypothesis axis is sharded and gathered (pafuse_amd.parallel)."""
+    dev = next(model.parameters()).device
+    seq_2d = torch.as_tensor(seq_2d, dtype=torch.float32)
+    seq_3d = torch.as_tensor(seq_3d, dtype=torch.float32)
+    x2d = cut_clips(seq_2d, model.frames).to(dev)
+    x2d_flip = cut_clips(flip_2d(seq_2d, kps_left, kps_right), model.frames).to(dev)
+    gt = cut_clips(seq_3d, model.frames).to(dev)
+    traj = gt[:, :, :1].clone()                                   # main_h3wb.py:300
+    gt_parts = center_pose_parts(gt, dataset)                     # main_h3wb.py:304
+    cam = torch.as_tensor(cam, dtype=torch.float32).to(dev)
+    sampler = ShardedSampler(model, group)
+    sums, n = None, 0
+    for lo in range(0, x2d.shape[0], batch_size):
+        hi = min(lo + batch_size, x2d.shape[0])
+        pred = sampler(x2d[lo:hi], gt_parts[lo:hi], input_2d_flip=x2d_flip[lo:hi])      # [b,T,P,F,J,3]
+        acc = evaluate_accumulators(pred, gt_parts[lo:hi], x2d[lo:hi], traj[lo:hi], cam, dataset)
+        mult = (hi - lo) * model.frames                           # main_h3wb.py:333
+        sums = {k: mult * v for k, v in acc.items()} if sums is None else {k: sums[k] + mult * acc[k] for k in acc}
+        n += mult
+    return sums, n
+
+
+def report(sums, n):
+    """mm per protocol and step, as evaluate() prints them (main_h3wb.py:415-509)."""
+    return {k: (v / n * 1000.0).tolist() for k, v in sums.items()}

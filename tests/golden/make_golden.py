@@ -318,6 +318,26 @@ def g9_evaluate_accumulators():
     save("g9_evaluate.npz", pred_parts=pred_parts, gt_parts=gt_parts, x2d=x2d, traj=traj, cam=cam, **out)
 
 
+# ------------------------------------------------------------------------------------------------- G10
+def g10_clip_cutting():
+    """eval_data_prepare (main_h3wb.py:122-154) on sequences shorter than / equal to / not a multiple of a clip.
+    main_h3wb.py is a script with heavy imports, so only that function's source is exec'd from it."""
+    import ast
+    src = open(os.path.join(REF, "main_h3wb.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "eval_data_prepare")
+    from einops import rearrange
+    ns = {"torch": torch, "rearrange": rearrange}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "eval_data_prepare", "exec"), ns)
+    g = torch.Generator().manual_seed(101)
+    arrays = {}
+    for n in (10, 27, 54, 60):
+        x2 = torch.randn(1, n, 6, 2, generator=g)
+        x3 = torch.randn(1, n, 6, 3, generator=g)
+        c2, c3 = ns["eval_data_prepare"](27, x2, x3)
+        arrays.update({f"x2.{n}": x2, f"x3.{n}": x3, f"c2.{n}": c2, f"c3.{n}": c3})
+    save("g10_clips.npz", **arrays)
+
+
 # -------------------------------------------------------------------------------------------------- G8
 def g8_default_init():
     """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
@@ -331,8 +351,9 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
-                 g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators)
+                 g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
+                 g10=g10_clip_cutting)
     for w in which:
         table[w]()

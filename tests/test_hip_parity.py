@@ -288,3 +288,32 @@ def test_g9_evaluate_accumulators_golden():
         # fp32 means of ~1.3 m synthetic errors: one ulp is 1.2e-7; device FMA contraction in the projection and a
         # different summation order move the result by a few ulps
         assert torch.allclose(got[k].cpu(), z[k], rtol=1e-6, atol=0), (k, (got[k].cpu() - z[k]).abs().max())
+
+
+def test_evaluate_sequence_vs_oracle():
+    """End to end on one synthetic sequence (60 frames -> 3 clips, the last overlapping): harness + HIP loop + device
+    accumulators against the oracle's loop + the oracle's accumulators (reference-pinned by G5/G9/G10)."""
+    from types import SimpleNamespace
+    from __graft_entry__ import make_model
+    from pafuse_amd import harness
+    P, T = 2, 2
+    model, sd = make_model(P, T, seed=81)
+    ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES,
+                         parts_connection_indices=dict(gu.CONNECTION_INDICES))
+    g = torch.Generator().manual_seed(82)
+    seq_2d = torch.rand(60, 134, 2, generator=g) * 2 - 1
+    seq_3d = torch.randn(60, 134, 3, generator=g) * 0.25 + torch.tensor([0.0, 0.0, 4.0])
+    cam = torch.tensor([2.29, 2.287, 0.025, 0.029, -0.207, 0.247, -0.003, -0.0009, -0.001])
+    noises = gu.synthetic_noises(B=3, P=P, n=T, seed=8)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    sums, n = harness.evaluate_sequence(model, ds, seq_2d, seq_3d, cam, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT)
+    assert n == 3 * 27 and set(sums) == set(harness.ACCUMULATORS)
+    # oracle side
+    x2d = harness.cut_clips(seq_2d)
+    x2f = harness.cut_clips(harness.flip_2d(seq_2d, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT))
+    gt = harness.cut_clips(seq_3d)
+    pred = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    want = orc.evaluate_accumulators(pred, orc.center_pose_parts(gt), x2d, gt[:, :, :1], cam)
+    for k in harness.ACCUMULATORS:
+        got = sums[k].cpu() / n
+        assert torch.allclose(got, want[k], rtol=2e-6, atol=0), (k, got, want[k])

@@ -88,3 +88,19 @@ def test_cpu_call_raises_not_falls_back():
     m = pafuse_amd.MixSTE2(27, 24, 5, 384, 1, 8, drop_path_rate=0.0, is_train=False)
     with pytest.raises(_lib.PafuseError):
         m(torch.zeros(1, 27, 24, 2), torch.zeros(1, 1, 27, 24, 3), torch.zeros(1, dtype=torch.long))
+
+
+def test_harness_host_logic_matches_reference():
+    """clip cutting (G10), flip copy and part centring (G6) of pafuse_amd.harness against reference outputs."""
+    from types import SimpleNamespace
+    from pafuse_amd import harness
+    z = load_golden("g10_clips.npz")
+    for n in (10, 27, 54, 60):
+        assert torch.equal(harness.cut_clips(z[f"x2.{n}"]), z[f"c2.{n}"]), n
+        assert torch.equal(harness.cut_clips(z[f"x3.{n}"][0]), z[f"c3.{n}"]), n
+    x2d, x2f = gu.synthetic_inputs_2d(B=2)
+    assert torch.equal(harness.flip_2d(x2d, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT), x2f)
+    g6 = load_golden("g6_index_ops.npz")
+    ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES)
+    assert torch.equal(harness.center_pose_parts(g6["pose"], ds), g6["centred"])
+    assert len(harness.ACCUMULATORS) == 14
