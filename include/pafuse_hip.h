@@ -128,8 +128,10 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights *w, const float *x2d, co
  *   noise [n_draws,B,P,F,J,3]: draw 0 is the initial img, draw k the randn_like of the k-th update
  *         (n_draws >= 1 + number of steps with last == 0)
  *   out   [B,nsteps,P,F,J,3]: x_start of every step (torch.stack(preds_all, dim=1))
- * `aux_streams` (may be NULL / n_aux 0): extra HIP streams the parts are spread over; events are created
- * and destroyed inside the call only when aux streams are given. */
+ * `aux_streams` (may be NULL / n_aux 0): extra HIP streams; a step's work is cut into (part, hypothesis-group) lanes,
+ * one stream each, groups = (n_aux + 1) / parts (>= 1): 2 aux streams = the three parts side by side (fastest
+ * measured; more lanes cost more in small launches than they gain in overlap).  Events are created and destroyed
+ * inside the call only when aux streams are given. */
 size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config *cfg, int32_t B, int32_t P);
 int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *steps, int32_t nsteps,
                        const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,

@@ -662,13 +662,14 @@ struct EmbedParams {
     int B, P, F, J, J3, C, nflip;
     int do_clamp;
     float scale;
+    int64_t row0, nrows;  // this launch embeds rows [row0, row0 + nrows) of the part's token matrix
 };
 
 __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t M = (int64_t)p.nflip * p.B * p.P * p.F * p.J;
-    if (row >= M) return;
+    const int64_t local = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (local >= p.nrows) return;
+    const int64_t row = p.row0 + local;
     const int j = (int)(row % p.J);
     const int f = (int)((row / p.J) % p.F);
     const int64_t rr = row / ((int64_t)p.J * p.F);

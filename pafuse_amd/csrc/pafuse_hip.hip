@@ -140,6 +140,15 @@ char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb) {
     return base;
 }
 
+// the rows [row0, ...) of a part's buffers (hypotheses are independent, so a part can be cut into hypothesis groups
+// that run on different streams; temb and the scratch behind `wide` stay shared / are offset like the rest)
+PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
+    PartBuffers o = pb;
+    o.x = pb.x + row0 * C, o.xn = pb.xn + row0 * C, o.o = pb.o + row0 * C, o.wide = pb.wide + row0 * 3 * C;
+    o.pred = pb.pred + row0 * 3;
+    return o;
+}
+
 int check_weights(const pafuse_mixste2_weights* w) {
     if (!w) return fail(PAFUSE_E_ARG, "null weights");
     if (w->in_chans != 5) return fail(PAFUSE_E_SHAPE, "in_chans must be 5, got %d", w->in_chans);
@@ -342,7 +351,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
     e.x = pb.x, e.xn = pb.xn;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
-    e.do_clamp = 0, e.scale = 1.f;
+    e.do_clamp = 0, e.scale = 1.f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, e);
     if ((rc = check_launch("embed_kernel"))) return rc;
     if ((rc = run_mixste_layers(w, pb, R, s))) return rc;
@@ -401,14 +410,25 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     for (int i = 0; i < NP; ++i)
         base = carve_part(base, R * F * cfg->part[i].joints, cfg->part[i].channels, B, pb[i]);
 
-    // parts are independent inside a step: spread them over the aux streams when given
-    hipStream_t ps[PAFUSE_MAX_PARTS];
-    for (int i = 0; i < NP; ++i) ps[i] = (n_aux > 0 && i > 0) ? (hipStream_t)aux_streams[(i - 1) % n_aux] : s0;
-    const bool multi = n_aux > 0 && NP > 1;
-    hipEvent_t ev_fork = nullptr, ev_join[PAFUSE_MAX_PARTS] = {};
+    // Parts are independent inside a step, and so are hypotheses: with aux streams the work of a step is cut into
+    // (part, hypothesis-group) lanes, each a chain of small launches on its own stream, so that the ramp-up and
+    // tail of one lane's kernels are filled by the other lanes (groups = (n_aux + 1) / parts, at least 1).
+    const int n_lanes_max = 1 + (n_aux > 0 ? n_aux : 0);
+    int groups = n_lanes_max / NP;
+    if (groups < 1) groups = 1;
+    if (groups > R) groups = (int)R;
+    const int lanes = NP * groups;
+    auto lane_stream = [&](int lane) -> hipStream_t {
+        if (n_aux <= 0 || lane == 0) return s0;
+        return (hipStream_t)aux_streams[(lane - 1) % n_aux];
+    };
+    const bool multi = n_aux > 0 && lanes > 1;
+    constexpr int MAX_LANES = 64;
+    if (lanes > MAX_LANES) return fail(PAFUSE_E_ARG, "too many stream lanes (%d)", lanes);
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
     if (multi) {
         hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-        for (int i = 1; i < NP; ++i) hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
+        for (int i = 1; i < lanes; ++i) hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
     }
 
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((img_elems + 255) / 256)), dim3(256), 0, s0, noise, img, img_elems);
@@ -416,29 +436,35 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     int draw = 1;
     for (int k = 0; k < nsteps && rc == PAFUSE_OK; ++k) {
         const pafuse_ddim_step& st = steps[k];
+        // the time embedding of every part once, on the main stream, before the fork
+        for (int i = 0; i < NP && rc == PAFUSE_OK; ++i)
+            rc = launch_time_embed(&cfg->part[i], nullptr, st.time, B, pb[i].temb, pb[i].wide, s0);
+        if (rc) break;
         if (multi) {
             hipEventRecord(ev_fork, s0);
-            for (int i = 1; i < NP; ++i) hipStreamWaitEvent(ps[i], ev_fork, 0);
+            for (int i = 1; i < lanes; ++i) hipStreamWaitEvent(lane_stream(i), ev_fork, 0);
         }
-        for (int i = 0; i < NP && rc == PAFUSE_OK; ++i) {
+        for (int lane = 0; lane < lanes && rc == PAFUSE_OK; ++lane) {
+            const int i = lane % NP, gi = lane / NP;
             const pafuse_mixste2_weights* w = &cfg->part[i];
-            if ((rc = launch_time_embed(w, nullptr, st.time, B, pb[i].temb, pb[i].wide, ps[i]))) break;
+            hipStream_t ls = lane_stream(lane);
+            const int64_t r0 = R * gi / groups, r1 = R * (gi + 1) / groups;
+            const int64_t rows_per_r = (int64_t)F * w->joints, row0 = r0 * rows_per_r, nrows = (r1 - r0) * rows_per_r;
             EmbedParams e{};
             e.x3d = img, e.x2d = x2d, e.x2d_flip = x2d_flip, e.joints = cfg->part_joints[i], e.perm = cfg->flip_perm;
             e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb[i].temb;
             e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
             e.x = pb[i].x, e.xn = pb[i].xn;
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
-            e.do_clamp = 1, e.scale = cfg->scale;
-            const int64_t M = R * F * w->joints;
-            hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, ps[i], e);
+            e.do_clamp = 1, e.scale = cfg->scale, e.row0 = row0, e.nrows = nrows;
+            hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ls, e);
             if ((rc = check_launch("embed_kernel"))) break;
-            rc = run_mixste_layers(w, pb[i], R, ps[i]);
+            rc = run_mixste_layers(w, offset_rows(pb[i], row0, w->channels), r1 - r0, ls);
         }
         if (rc) break;
         if (multi)
-            for (int i = 1; i < NP; ++i) {
-                hipEventRecord(ev_join[i], ps[i]);
+            for (int i = 1; i < lanes; ++i) {
+                hipEventRecord(ev_join[i], lane_stream(i));
                 hipStreamWaitEvent(s0, ev_join[i], 0);
             }
         FinalizeParams f{};
@@ -455,7 +481,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     }
     if (multi) {
         hipEventDestroy(ev_fork);
-        for (int i = 1; i < NP; ++i) hipEventDestroy(ev_join[i]);
+        for (int i = 1; i < lanes; ++i) hipEventDestroy(ev_join[i]);
     }
     return rc;
 }
