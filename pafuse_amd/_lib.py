@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpafuse_hip.so")
+LIB_PATH = os.environ.get("PAFUSE_HIP_LIB", os.path.join(_HERE, "libpafuse_hip.so"))   # override: A/B diagnostics
 
 MAX_DEPTH = 16
 MAX_PARTS = 4
