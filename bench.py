@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
+    ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
     args = ap.parse_args()
 
     import torch
@@ -71,6 +72,7 @@ def main():
     model, sd = ge.make_model(P_total, T, seed=51, device=dev)
     if args.streams > 0:
         model.aux_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+    model.use_graph = args.graph
     sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)
     x2d, x2f = x2d.to(dev), x2f.to(dev)

@@ -102,6 +102,8 @@ class D3DP(nn.Module):
         self.noise_fn = None           # callable(k, shape, device) -> draw k (tests inject recorded noise)
         self.proposal_shard = None     # (lo, hi): this rank's slice of the hypothesis axis (pafuse_amd.parallel)
         self.aux_streams = None        # list of torch.cuda.Stream the parts are spread over
+        self.use_graph = False         # replay the whole loop as one hipGraph (captured per input shape)
+        self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ schedule
     def time_pairs(self):
@@ -170,17 +172,42 @@ class D3DP(nn.Module):
         x2d = inputs_2d.contiguous().float()
         x2f = input_2d_flip.contiguous().float() if flip else x2d
         cfg = self.config_struct(flip)
-        out = torch.empty(B, len(steps), P, self.frames, self.num_kps, 3, device=dev, dtype=torch.float32)
         nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev)
         aux = self.aux_streams or []
-        for s in aux:
-            s.wait_stream(stream)
-        aux_arr = (C.c_void_p * max(1, len(aux)))(*[s.cuda_stream for s in aux])
-        _lib.check(lib.pafuse_d3dp_sample(C.byref(cfg), steps, len(steps), x2d.data_ptr(), x2f.data_ptr(),
-                                          noise.data_ptr(), n_draws, B, P, out.data_ptr(), ws.data_ptr(), nbytes,
-                                          stream.cuda_stream, aux_arr, len(aux)))
+
+        def launch(x2d_, x2f_, noise_, out_, ws_, stream_):
+            for s in aux:
+                s.wait_stream(stream_)
+            aux_arr = (C.c_void_p * max(1, len(aux)))(*[s.cuda_stream for s in aux])
+            _lib.check(lib.pafuse_d3dp_sample(C.byref(cfg), steps, len(steps), x2d_.data_ptr(), x2f_.data_ptr(),
+                                              noise_.data_ptr(), n_draws, B, P, out_.data_ptr(), ws_.data_ptr(), nbytes,
+                                              stream_.cuda_stream, aux_arr, len(aux)))
+
+        if self.use_graph:
+            # the C ABI neither allocates nor synchronises, so the whole T-step loop (~2 500 launches, fork/join
+            # events included) is captured once per (shape, weights) and replayed on static buffers
+            key = (B, P, len(steps), bool(flip), dev, tuple(cfg.part[i].patch_w for i in range(cfg.num_parts)))
+            g = self._graphs.get(key)
+            if g is None:
+                st = {"x2d": x2d.clone(), "x2f": x2f.clone(), "noise": noise.clone(),
+                      "out": torch.empty(B, len(steps), P, self.frames, self.num_kps, 3, device=dev),
+                      "ws": torch.empty(nbytes, dtype=torch.uint8, device=dev), "cfg": cfg, "steps": steps}
+                cap = torch.cuda.Stream(device=dev)
+                cap.wait_stream(stream)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=cap):
+                    launch(st["x2d"], st["x2f"], st["noise"], st["out"], st["ws"], torch.cuda.current_stream(dev))
+                stream.wait_stream(cap)
+                g = self._graphs[key] = (graph, st)
+            graph, st = g
+            st["x2d"].copy_(x2d), st["x2f"].copy_(x2f), st["noise"].copy_(noise)
+            graph.replay()
+            return st["out"].clone()
+
+        out = torch.empty(B, len(steps), P, self.frames, self.num_kps, 3, device=dev, dtype=torch.float32)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        launch(x2d, x2f, noise, out, ws, stream)
         for t in (ws, noise, x2d, x2f):
             for s in aux:
                 t.record_stream(s)

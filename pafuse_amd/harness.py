@@ -46,6 +46,37 @@ def center_pose_parts(pose, dataset):
     return out
 
 
+def wb_pose_from_parts(pose, dataset):
+    """Whole-body pose from part-centred poses: every joint shifted by its part's connection joint (face -> body
+    joint 1, hands -> 10 / 11, body -> 0, which pins joint 0 at the origin).  Closed form of the reference's
+    in-place pass (common/utils.py:113-126) - same values bit for bit, and the input is left untouched."""
+    conn = dict(dataset.parts_connection_indices)
+    conn["body"] = 0
+    out = torch.zeros_like(pose)
+    for part, idx in dataset.parts_joint_indices.items():
+        if part in conn:
+            out[..., idx, :] = pose[..., idx, :] + pose[..., conn[part]:conn[part] + 1, :]
+    out[..., 0, :] = 0
+    return out
+
+
+@torch.no_grad()
+def infer_sequence(model, dataset, seq_2d, kps_left, kps_right, batch_size=2, group=None):
+    """In-the-wild inference for one 2-D keypoint sequence [N,J,2] (already screen-normalised): flip copy, 27-frame
+    clips, batched sampling with ``input_3d=None``, whole-body poses (in_the_wild/utils.py:322-376).
+    Returns a CPU tensor [clips, T, P, F, J, 3]."""
+    dev = next(model.parameters()).device
+    seq_2d = torch.as_tensor(seq_2d, dtype=torch.float32)
+    x2d = cut_clips(seq_2d, model.frames).to(dev)
+    x2d_flip = cut_clips(flip_2d(seq_2d, kps_left, kps_right), model.frames).to(dev)
+    sampler = ShardedSampler(model, group)
+    outs = []
+    for lo in range(0, x2d.shape[0], batch_size):
+        pred = sampler(x2d[lo:lo + batch_size], None, input_2d_flip=x2d_flip[lo:lo + batch_size])
+        outs.append(wb_pose_from_parts(pred, dataset).cpu())
+    return torch.cat(outs)
+
+
 def load_checkpoint(model, checkpoint):
     """Accept what the reference saves (common/logging.py:83-115): a dict with 'model_pos', DataParallel
     ``module.``-prefixed keys, or a bare state dict."""

@@ -317,3 +317,43 @@ def test_evaluate_sequence_vs_oracle():
     for k in harness.ACCUMULATORS:
         got = sums[k].cpu() / n
         assert torch.allclose(got, want[k], rtol=2e-6, atol=0), (k, got, want[k])
+
+
+def test_infer_sequence_in_the_wild():
+    """n4: the in-the-wild caller (input_3d=None) returns whole-body poses equal to the oracle's."""
+    from types import SimpleNamespace
+    from __graft_entry__ import make_model
+    from pafuse_amd import harness
+    model, sd = make_model(2, 1, seed=83)
+    ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES,
+                         parts_connection_indices=dict(gu.CONNECTION_INDICES))
+    seq_2d = _seeded((40, 134, 2), 84).clamp(-1, 1)
+    noises = gu.synthetic_noises(B=2, P=2, n=1, seed=9)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = harness.infer_sequence(model, ds, seq_2d, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, batch_size=2)
+    x2d = harness.cut_clips(seq_2d)
+    x2f = harness.cut_clips(harness.flip_2d(seq_2d, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT))
+    ref = orc.wb_pose_from_parts(orc.ddim_sample(sd, x2d, noises, 1, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT,
+                                                 inputs_2d_flip=x2f))
+    assert out.shape == (2, 1, 2, 27, 134, 3)
+    assert torch.allclose(out, ref, rtol=0, atol=1e-5), (out - ref).abs().max()
+
+
+def test_graph_replay_equals_eager():
+    """the whole loop captured as one hipGraph (C ABI never allocates or synchronises) replays bit-identically,
+    also with the parts forked onto aux streams inside the capture, and with fresh inputs on the second replay."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(2, 3, seed=85)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    for aux in (None, 2):
+        model.aux_streams = [torch.cuda.Stream() for _ in range(aux)] if aux else None
+        for seed in (10, 11):
+            noises = gu.synthetic_noises(B=1, P=2, n=3, seed=seed)
+            model.noise_fn = lambda k, shape, device: noises[k]
+            model.use_graph = False
+            eager = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+            model.use_graph = True
+            graphed = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+            torch.cuda.synchronize()
+            assert torch.equal(eager, graphed), (aux, seed)
+        model._graphs.clear()

@@ -103,4 +103,7 @@ def test_harness_host_logic_matches_reference():
     g6 = load_golden("g6_index_ops.npz")
     ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES)
     assert torch.equal(harness.center_pose_parts(g6["pose"], ds), g6["centred"])
+    ds.parts_connection_indices = dict(gu.CONNECTION_INDICES)
+    pose = g6["pose"].clone()
+    assert torch.equal(harness.wb_pose_from_parts(pose, ds), g6["wb_out"]) and torch.equal(pose, g6["pose"])
     assert len(harness.ACCUMULATORS) == 14
