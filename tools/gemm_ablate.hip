@@ -26,6 +26,9 @@ __global__ void __launch_bounds__(WM* WN * 64) gemm_abl(const GemmParams p) {
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
     const int K = p.K;
+    if (ABL & 32) {  // de-phase the first residency round: workgroup b of the first 256*5 waits ((b/256)%5) * act * 64 clocks
+        if (blockIdx.x < 1280) for (int i = 0; i < (int)((blockIdx.x >> 8) % 5) * p.act; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     const float* a_src[A_LD]; int a_dst[A_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
@@ -155,6 +158,12 @@ int main() {
     run<4, 1, 4, 1, 0>("body qkv s1 baseline", p);
     run<4, 1, 4, 1, 1>("body qkv s1 no-epilogue-stores", p);
     run<4, 1, 4, 1, 1 | 2 | 4 | 8>("body qkv s1 MFMA+ds_read only", p);
+    {
+        GemmParams big = p; big.M = 73440; big.N = 1152; big.K = 384;   // 574 x 18 = 10332 tiles of 128x64: ~8 rounds
+        run<4, 1, 2, 1, 0>("big qkv <4,1,2> s1 baseline", big);
+        for (int d : {100, 200, 300, 400}) { big.act = d; char t[64]; snprintf(t, 64, "big qkv <4,1,2> s1 stagger %d", d); run<4, 1, 2, 1, 32>(t, big); }
+        big.act = 0;
+    }
     p.M = 25600;   // 200 M-tiles * 9 = 1800 tiles
     run<4, 1, 4, 2, 0>("M=25600 (1800 tiles) s2 baseline", p);
     p.M = 128 * 256 * 2 / 9 * 9;  // dummy
