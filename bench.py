@@ -193,6 +193,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()      # ranks > 0 wait here while rank 0 runs the roofline and CPU-baseline legs
         dist.destroy_process_group()
 
 
