@@ -284,6 +284,25 @@ def g7_metrics():
          j_agg=mpjpe_diffusion_reproj(pred, target, reproj, target_2d))
 
 
+# ------------------------------------------------------------------------------------------------- G11
+def g11_scale():
+    """flip loop with ft2d.scale = 2.0 (clamp bounds, /scale, *scale paths), P=2, T=2."""
+    from common.diffusionpose import D3DP
+    args = make_args()
+    args.ft2d.scale = 2.0
+    m = D3DP(args, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, FakeDataset(), is_train=False, num_proposals=2,
+             sampling_timesteps=2)
+    m.device = "cpu"
+    m.eval()
+    sd = gu.seeded_state_dict(m.state_dict(), seed=111)
+    m.load_state_dict(sd)
+    x2d, x2d_flip = gu.synthetic_inputs_2d(B=1)
+    noises = [n * 1.5 for n in gu.synthetic_noises(B=1, P=2, n=2, seed=12)]
+    with NoiseTape(noises), torch.no_grad():
+        out = m(x2d, None, input_2d_flip=x2d_flip)
+    save("g11_scale.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8), out=out)
+
+
 # -------------------------------------------------------------------------------------------------- G9
 def g9_evaluate_accumulators():
     """the 14 per-step error vectors evaluate() accumulates (main_h3wb.py:327-362) on random part-centred inputs."""
@@ -351,9 +370,9 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
-                 g10=g10_clip_cutting)
+                 g10=g10_clip_cutting, g11=g11_scale)
     for w in which:
         table[w]()

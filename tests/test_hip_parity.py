@@ -357,3 +357,16 @@ def test_graph_replay_equals_eager():
             torch.cuda.synchronize()
             assert torch.equal(eager, graphed), (aux, seed)
         model._graphs.clear()
+
+
+def test_g11_scale_golden():
+    """ft2d.scale != 1: clamp bounds, /scale on the way in, *scale and clamp on the way out."""
+    from __graft_entry__ import make_model
+    z = load_golden("g11_scale.npz")
+    model, sd = make_model(2, 2, seed=111, scale=2.0)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = [n * 1.5 for n in gu.synthetic_noises(B=1, P=2, n=2, seed=12)]
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    assert torch.allclose(out, z["out"], rtol=0, atol=2e-5), (out - z["out"]).abs().max()

@@ -135,3 +135,14 @@ def test_g9_evaluate_accumulators():
     assert len(keys) == 14 and set(keys) == set(got)
     for k in keys:
         assert torch.allclose(got[k], z[k], rtol=0, atol=1e-7), (k, got[k], z[k])
+
+
+def test_g11_scale():
+    from tests.golden.state_template import d3dp_template
+    z = load_golden("g11_scale.npz")
+    sd = gu.seeded_state_dict(d3dp_template(), seed=111)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = [n * 1.5 for n in gu.synthetic_noises(B=1, P=2, n=2, seed=12)]
+    out = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f, scale=2.0)
+    assert torch.allclose(out, z["out"], rtol=0, atol=2e-5), (out - z["out"]).abs().max()
