@@ -9,8 +9,8 @@ Plain-PyTorch fp32 restatement, written in functional style over a flat state di
   * the pose utilities / multi-hypothesis metrics the caller applies to the path's output
     (reference common/utils.py:79-126, common/loss.py:36-168, common/camera.py:30-60)
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module, and only as
-the checker.  Parity status: PINNED - tests/golden/*.npz hold outputs of the real reference, produced in
+Only tests/ (including tests/reports/), __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module, and only as the checker.  Parity status: PINNED - tests/golden/*.npz hold outputs of the real reference, produced in
 the build container by tests/golden/make_golden.py (which imports /root/reference on CPU); the oracle is
 checked against every one of them in tests/test_oracle_golden.py.
 

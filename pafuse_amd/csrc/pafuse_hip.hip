@@ -62,7 +62,7 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
-    if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1>(p, s);
+    if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 5>(p, s);   // pin 5 waves/SIMD (98 registers)
     if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>(p, s);  // row-per-lane epilogue wins at NT=3
     return launch_gemm<4, 1, 1, EPI_BIAS, 1>(p, s);
 }

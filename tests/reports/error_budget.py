@@ -7,7 +7,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import make_model  # noqa: E402
 from oracle import d3dp_oracle as orc  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print how far the HIP path is from the CPU oracle on seeded inputs (pointwise and MPJPE, fp64 metric math).
 
-Run on the GPU box:  python tools/parity_report.py [P T [B]]  ->  one JSON line.
+Run on the GPU box:  python tests/reports/parity_report.py [P T [B]]  ->  one JSON line.
 """
 import json
 import os
@@ -10,7 +10,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import make_model  # noqa: E402
 from oracle import d3dp_oracle as orc  # noqa: E402

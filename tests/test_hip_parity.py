@@ -5,9 +5,9 @@ Tolerances (fp32 path, model units are metres; x1000 = mm):
   * MPJPE aggregates: 1e-3 mm, and - the sharper statement - the HIP path is as close to an fp64 evaluation of
     the same function as the reference's own fp32 CPU arithmetic is (test_accuracy_equivalent_to_reference_fp32).
     The north star's 1e-4 mm sits below that floor: the reference's fp32 result itself is 2.1-2.6e-4 mm (mean
-    abs, with a coherent per-part bias up to 1.2e-4 mm) away from exact arithmetic (tools/error_budget.py), and
+    abs, with a coherent per-part bias up to 1.2e-4 mm) away from exact arithmetic (tests/reports/error_budget.py), and
     wb_pose_from_parts / root centring turn single-joint rounding into whole-part shifts that do not average
-    out in the MPJPE mean.  Measured |dMPJPE| is 1e-7 .. 3e-4 mm (tools/parity_report.py).
+    out in the MPJPE mean.  Measured |dMPJPE| is 1e-7 .. 3e-4 mm (tests/reports/parity_report.py).
 """
 import pytest
 import torch
