@@ -370,3 +370,20 @@ def test_g11_scale_golden():
     model.noise_fn = lambda k, shape, device: noises[k]
     out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     assert torch.allclose(out, z["out"], rtol=0, atol=2e-5), (out - z["out"]).abs().max()
+
+
+def test_c_abi_from_plain_c():
+    """the boundary is a C ABI: a C program with only the HIP runtime links the library and gets exact results."""
+    import os
+    import subprocess
+    from tests.conftest import ROOT
+    exe = os.path.join(ROOT, "build", "linear_smoke")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.join(ROOT, "pafuse_amd")
+    subprocess.check_call(["gcc", os.path.join(ROOT, "tests", "cabi", "linear_smoke.c"), "-D__HIP_PLATFORM_AMD__",
+                           "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lpafuse_hip",
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                           "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 mismatches" in out.stdout
