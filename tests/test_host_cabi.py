@@ -107,3 +107,23 @@ def test_harness_host_logic_matches_reference():
     pose = g6["pose"].clone()
     assert torch.equal(harness.wb_pose_from_parts(pose, ds), g6["wb_out"]) and torch.equal(pose, g6["pose"])
     assert len(harness.ACCUMULATORS) == 14
+
+
+def test_config_tree_and_overrides():
+    from pafuse_amd import config
+    args = config.load(overrides=["ft2d.num_proposals=20", "ft2d.sampling_timesteps=10", "model.test_time_augmentation=False",
+                                  "general.evaluate=pafuse_model.bin", "ft2d.scale=0.5"])
+    assert (args.ft2d.num_proposals, args.ft2d.sampling_timesteps, args.ft2d.scale) == (20, 10, 0.5)
+    assert args.model.test_time_augmentation is False and args.general.evaluate == "pafuse_model.bin"
+    assert args.model.number_of_frames == 27 and args.data.num_kps == 134 and args.data.merge_hands is True
+    with pytest.raises(ValueError):
+        config.load(overrides=["nonsense"])
+    ref_yaml = "/root/reference/config/config.yaml"
+    if os.path.exists(ref_yaml):                                 # build container only: defaults = the reference's file
+        ref = config.load(ref_yaml)
+        for section, values in config.DEFAULTS.items():
+            for k, v in values.items():
+                assert getattr(getattr(ref, section), k) == v, (section, k)
+        # the module mirror constructs from the tree exactly like from the reference's args
+        from __graft_entry__ import make_model
+        assert make_model(1, 1, device="cpu")[0].frames == ref.model.number_of_frames
