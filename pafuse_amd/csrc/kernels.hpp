@@ -665,11 +665,15 @@ struct EmbedParams {
     int64_t row0, nrows;  // this launch embeds rows [row0, row0 + nrows) of the part's token matrix
 };
 
+// one half-wave per token (8 tokens per 256-thread workgroup): lane li owns the channel quads li, li+32, li+64
+constexpr int EMBED_ROWS_PER_BLOCK = 8;
+constexpr int EMBED_NV = 3;  // C <= 384
+
 __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
-    const int lane = threadIdx.x & 63;
-    const int64_t local = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (local >= p.nrows) return;
-    const int64_t row = p.row0 + local;
+    const int lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+    const int64_t local = (int64_t)blockIdx.x * EMBED_ROWS_PER_BLOCK + (threadIdx.x >> 6) * 2 + hh;
+    const bool live = local < p.nrows;  // uniform per half-wave; dead halves still take part in the shuffles
+    const int64_t row = p.row0 + (live ? local : p.nrows - 1);
     const int j = (int)(row % p.J);
     const int f = (int)((row / p.J) % p.F);
     const int64_t rr = row / ((int64_t)p.J * p.F);
@@ -687,29 +691,63 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
         for (int i = 2; i < 5; ++i) in[i] = fminf(fmaxf(in[i], -lim), lim) / p.scale;
     }
     if (fl) in[2] = -in[2];
-    float v[LN_MAX_PER_LANE];
+    const int NQ = p.C / 4;
+    f32x4 v[EMBED_NV];
+    float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = 0.f;
-        if (c < p.C) {
-            const float* wr = p.pw + c * 5;
-            float a = in[0] * wr[0];
-            a += in[1] * wr[1];
-            a += in[2] * wr[2];
-            a += in[3] * wr[3];
-            a += in[4] * wr[4];
-            a += p.pb[c];
-            a += p.pos[j * p.C + c];
-            a += p.temb[(int64_t)b * p.C + c];
-            v[i] = a;
-            p.x[row * p.C + c] = a;
+    for (int i = 0; i < EMBED_NV; ++i) {
+        const int c4 = li + 32 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c4 < NQ) {
+            const float* wr = p.pw + c4 * 20;  // 4 channels x 5 inputs, contiguous
+            f32x4 w4[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) w4[q] = *reinterpret_cast<const f32x4*>(wr + 4 * q);
+            const float* wf = reinterpret_cast<const float*>(w4);
+            const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pb + 4 * c4);
+            const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + j * p.C + 4 * c4);
+            const f32x4 te = *reinterpret_cast<const f32x4*>(p.temb + (int64_t)b * p.C + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = in[0] * wf[5 * e + 0];
+                a += in[1] * wf[5 * e + 1];
+                a += in[2] * wf[5 * e + 2];
+                a += in[3] * wf[5 * e + 3];
+                a += in[4] * wf[5 * e + 4];
+                a += pb[e];
+                a += ps[e];
+                a += te[e];
+                v[i][e] = a;
+                s += a;
+            }
+            if (live) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
         }
     }
-    wave_layer_norm(v, p.C, lane, p.n_w, p.n_b, p.n_eps);
+    const float invC = 1.0f / (float)p.C;
+    const float mean = half_wave_sum(s) * invC;
+    float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i)
-        if (lane + 64 * i < p.C) p.xn[row * p.C + lane + 64 * i] = v[i];
+    for (int i = 0; i < EMBED_NV; ++i)
+        if (li + 32 * i < NQ) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invC + p.n_eps);
+#pragma unroll
+    for (int i = 0; i < EMBED_NV; ++i) {
+        const int c4 = li + 32 * i;
+        if (c4 < NQ) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.n_w + 4 * c4);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.n_b + 4 * c4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
+            if (live) *reinterpret_cast<f32x4*>(p.xn + row * p.C + 4 * c4) = o;
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -151,6 +151,7 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
 
 int check_weights(const pafuse_mixste2_weights* w) {
     if (!w) return fail(PAFUSE_E_ARG, "null weights");
+    static_assert(EMBED_NV * 128 >= 384, "embed kernel covers the widest part");
     if (w->in_chans != 5) return fail(PAFUSE_E_SHAPE, "in_chans must be 5, got %d", w->in_chans);
     if (w->depth < 1 || w->depth > PAFUSE_MAX_DEPTH) return fail(PAFUSE_E_SHAPE, "depth %d out of range", w->depth);
     if (!width_supported(w->channels)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", w->channels);
@@ -352,7 +353,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.x = pb.x, e.xn = pb.xn;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
     e.do_clamp = 0, e.scale = 1.f, e.row0 = 0, e.nrows = M;
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, e);
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
     if ((rc = check_launch("embed_kernel"))) return rc;
     if ((rc = run_mixste_layers(w, pb, R, s))) return rc;
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((M * 3 + 255) / 256)), dim3(256), 0, s, pb.pred, out, M * 3);
@@ -457,7 +458,8 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.x = pb[i].x, e.xn = pb[i].xn;
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
             e.do_clamp = 1, e.scale = cfg->scale, e.row0 = row0, e.nrows = nrows;
-            hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, ls, e);
+            hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)),
+                               dim3(256), 0, ls, e);
             if ((rc = check_launch("embed_kernel"))) break;
             rc = run_mixste_layers(w, offset_rows(pb[i], row0, w->channels), r1 - r0, ls);
         }
