@@ -103,6 +103,9 @@ class D3DP(nn.Module):
         self.proposal_shard = None     # (lo, hi): this rank's slice of the hypothesis axis (pafuse_amd.parallel)
         self.aux_streams = None        # list of torch.cuda.Stream the parts are spread over
         self.use_graph = False         # replay the whole loop as one hipGraph (captured per input shape)
+        self.max_rows_per_launch = 640  # nflip*B*P hypothesis passes per library call: larger batches are cut along
+        #                                 the clip axis (clips are independent, results are bit-identical); bounds the
+        #                                 workspace (0.9 GB per 40 rows) and keeps activations cache-resident
         self._graphs = {}
 
     # ------------------------------------------------------------------------------------------ schedule
@@ -167,8 +170,22 @@ class D3DP(nn.Module):
         shape = (B, self.num_proposals, self.frames, self.num_kps, 3)
         steps = self.ddim_steps()
         n_draws = 1 + sum(1 for s in steps if not s.last)
-        noise = self._draws(n_draws, shape, dev)
+        noise = self._draws(n_draws, shape, dev)       # full batch, in the reference's draw order
         P = noise.shape[2]
+        per_clip = (2 if flip else 1) * P
+        bc = max(1, self.max_rows_per_launch // per_clip)
+        if B > bc:                                      # cut along the (independent) clip axis
+            outs = []
+            for b0 in range(0, B, bc):
+                b1 = min(B, b0 + bc)
+                outs.append(self._sample_chunk(lib, inputs_2d[b0:b1], input_2d_flip[b0:b1] if flip else None,
+                                               noise[:, b0:b1].contiguous(), steps, n_draws, flip))
+            return torch.cat(outs, dim=0)
+        return self._sample_chunk(lib, inputs_2d, input_2d_flip, noise, steps, n_draws, flip)
+
+    def _sample_chunk(self, lib, inputs_2d, input_2d_flip, noise, steps, n_draws, flip):
+        dev = inputs_2d.device
+        B, P = inputs_2d.shape[0], noise.shape[2]
         x2d = inputs_2d.contiguous().float()
         x2f = input_2d_flip.contiguous().float() if flip else x2d
         cfg = self.config_struct(flip)

@@ -255,6 +255,19 @@ def test_clip_axis_is_independent():
         assert torch.equal(one, full[b:b + 1]), b
 
 
+def test_large_batches_are_cut_along_the_clip_axis():
+    """B beyond max_rows_per_launch runs as several library calls; same bits as one call."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(2, 2, seed=86)
+    x2d, x2f = gu.synthetic_inputs_2d(B=5)
+    noises = gu.synthetic_noises(B=5, P=2, n=2, seed=13)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    whole = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    model.max_rows_per_launch = 8                      # 2 clips per call at P=2 with flip-TTA -> chunks 2+2+1
+    cut = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    assert torch.equal(whole, cut)
+
+
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
