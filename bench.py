@@ -70,8 +70,7 @@ def main():
     B, T, P_local = args.batch, args.timesteps, args.proposals
     P_total = P_local * world
     model, sd = ge.make_model(P_total, T, seed=51, device=dev)
-    if args.streams > 0:
-        model.aux_streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+    model.n_aux_streams = args.streams
     model.use_graph = args.graph
     sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)

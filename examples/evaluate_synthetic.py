@@ -41,7 +41,6 @@ def main():
     if a.checkpoint:
         harness.load_checkpoint(model, torch.load(a.checkpoint, map_location="cpu"))
         model = model.to(f"cuda:{local}").eval()
-    model.aux_streams = [torch.cuda.Stream() for _ in range(2)]
     ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES,
                          parts_connection_indices=dict(gu.CONNECTION_INDICES))
     cam = torch.tensor([2.29, 2.287, 0.025, 0.029, -0.207, 0.247, -0.003, -0.0009, -0.001])   # normalised intrinsics

@@ -15,6 +15,10 @@ f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
 
 
+BLOCK_FIELDS = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
 class BlockWeights(C.Structure):
     _names = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
               "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")

@@ -101,7 +101,9 @@ class D3DP(nn.Module):
         # hooks that do not change the reference call signature
         self.noise_fn = None           # callable(k, shape, device) -> draw k (tests inject recorded noise)
         self.proposal_shard = None     # (lo, hi): this rank's slice of the hypothesis axis (pafuse_amd.parallel)
-        self.aux_streams = None        # list of torch.cuda.Stream the parts are spread over
+        self.aux_streams = None        # explicit list of torch.cuda.Stream the parts are spread over; None = two
+        self.n_aux_streams = 2         # streams per device made on first use (0: everything on the current stream)
+        self._aux_by_device = {}       # shared by DataParallel replicas, keyed by device index
         self.use_graph = False         # replay the whole loop as one hipGraph (captured per input shape)
         self.max_rows_per_launch = 640  # nflip*B*P hypothesis passes per library call: larger batches are cut along
         #                                 the clip axis (clips are independent, results are bit-identical); bounds the
@@ -183,6 +185,15 @@ class D3DP(nn.Module):
             return torch.cat(outs, dim=0)
         return self._sample_chunk(lib, inputs_2d, input_2d_flip, noise, steps, n_draws, flip)
 
+    def _aux_for(self, dev):
+        """Side streams on `dev` (replicas made by nn.DataParallel share this module's attributes, so never hand a
+        stream of another device to the library)."""
+        if self.aux_streams is not None:
+            return [s for s in self.aux_streams if s.device == dev]
+        if dev.index not in self._aux_by_device:
+            self._aux_by_device[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(self.n_aux_streams)]
+        return self._aux_by_device[dev.index]
+
     def _sample_chunk(self, lib, inputs_2d, input_2d_flip, noise, steps, n_draws, flip):
         dev = inputs_2d.device
         B, P = inputs_2d.shape[0], noise.shape[2]
@@ -191,7 +202,7 @@ class D3DP(nn.Module):
         cfg = self.config_struct(flip)
         nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P)
         stream = torch.cuda.current_stream(dev)
-        aux = self.aux_streams or []
+        aux = self._aux_for(dev)
 
         def launch(x2d_, x2f_, noise_, out_, ws_, stream_):
             for s in aux:

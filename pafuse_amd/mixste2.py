@@ -8,6 +8,7 @@ checkpoints), but has no per-layer Python forward: ``forward`` hands raw device 
 import ctypes as C
 import math
 from functools import partial
+from operator import attrgetter
 
 import torch
 import torch.nn as nn
@@ -85,33 +86,19 @@ class MixSTE2(nn.Module):
         self.head = nn.Sequential(nn.LayerNorm(C_), nn.Linear(C_, 3))
         self.register_buffer("_freqs", sinusoid_frequencies(C_), persistent=False)
         self._wcache = None
+        self._param_names = tuple(n for n, _ in self.named_parameters())
 
     # ------------------------------------------------------------------------------------------- C structs
     def weights_struct(self):
         """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes)."""
-        params = [p for p in self.parameters()] + [self._freqs]
-        key = tuple(p.data_ptr() for p in params)
+        # attribute access, not named_parameters(): nn.DataParallel replicas keep their copies as plain attributes
+        get = lambda name: attrgetter(name)(self)
+        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(),)
         if self._wcache is not None and self._wcache[0] == key:
             return self._wcache[1]
-        if self.block_depth > _lib.MAX_DEPTH:
-            raise _lib.PafuseError(f"depth {self.block_depth} > {_lib.MAX_DEPTH}")
         w = _lib.MixSTE2Weights()
-        w.frames, w.joints, w.channels = self.num_frame, self.num_joints, self.embed_dim
-        w.depth, w.heads, w.in_chans = self.block_depth, self.num_heads, self.in_chans
-        w.patch_w = _ptr(self.Spatial_patch_to_embedding.weight, "patch weight")
-        w.patch_b = _ptr(self.Spatial_patch_to_embedding.bias, "patch bias")
-        w.pos_spatial = _ptr(self.Spatial_pos_embed, "Spatial_pos_embed")
-        w.pos_temporal = _ptr(self.Temporal_pos_embed, "Temporal_pos_embed")
-        w.tm1_w, w.tm1_b = _ptr(self.time_mlp[1].weight, "time_mlp.1"), _ptr(self.time_mlp[1].bias, "time_mlp.1")
-        w.tm3_w, w.tm3_b = _ptr(self.time_mlp[3].weight, "time_mlp.3"), _ptr(self.time_mlp[3].bias, "time_mlp.3")
-        w.freqs = _ptr(self._freqs, "freqs")
-        w.snorm_w, w.snorm_b = _ptr(self.Spatial_norm.weight, "Spatial_norm"), _ptr(self.Spatial_norm.bias, "Spatial_norm")
-        w.tnorm_w, w.tnorm_b = _ptr(self.Temporal_norm.weight, "Temporal_norm"), _ptr(self.Temporal_norm.bias, "Temporal_norm")
-        w.hnorm_w, w.hnorm_b = _ptr(self.head[0].weight, "head.0"), _ptr(self.head[0].bias, "head.0")
-        w.head_w, w.head_b = _ptr(self.head[1].weight, "head.1"), _ptr(self.head[1].bias, "head.1")
-        for dst, blocks in ((w.ste, self.STEblocks), (w.tte, self.TTEblocks)):
-            for i, blk in enumerate(blocks):
-                fill_block_struct(dst[i], blk)
+        fill_weights_struct(w, get, self._freqs, self.num_frame, self.num_joints, self.embed_dim,
+                            self.block_depth, self.num_heads, self.in_chans)
         self._wcache = (key, w)
         return w
 
@@ -136,6 +123,32 @@ class MixSTE2(nn.Module):
         _lib.check(lib.pafuse_mixste2_forward(C.byref(w), x_2d.data_ptr(), x_3d.data_ptr(), t.data_ptr(), B, P,
                                               out.data_ptr(), ws.data_ptr(), nbytes, stream))
         return out
+
+
+BLOCK_PARAMS = (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
+                ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
+                ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
+                ("fc1_b", "mlp.fc1.bias"), ("fc2_w", "mlp.fc2.weight"), ("fc2_b", "mlp.fc2.bias"))
+MODEL_PARAMS = (("patch_w", "Spatial_patch_to_embedding.weight"), ("patch_b", "Spatial_patch_to_embedding.bias"),
+                ("pos_spatial", "Spatial_pos_embed"), ("pos_temporal", "Temporal_pos_embed"),
+                ("tm1_w", "time_mlp.1.weight"), ("tm1_b", "time_mlp.1.bias"), ("tm3_w", "time_mlp.3.weight"),
+                ("tm3_b", "time_mlp.3.bias"), ("snorm_w", "Spatial_norm.weight"), ("snorm_b", "Spatial_norm.bias"),
+                ("tnorm_w", "Temporal_norm.weight"), ("tnorm_b", "Temporal_norm.bias"), ("hnorm_w", "head.0.weight"),
+                ("hnorm_b", "head.0.bias"), ("head_w", "head.1.weight"), ("head_b", "head.1.bias"))
+
+
+def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, in_chans):
+    """Fill a pafuse_mixste2_weights from ``get(state-dict key) -> tensor`` (keys as in common/mixste.py)."""
+    if depth > _lib.MAX_DEPTH:
+        raise _lib.PafuseError(f"depth {depth} > {_lib.MAX_DEPTH}")
+    w.frames, w.joints, w.channels, w.depth, w.heads, w.in_chans = frames, joints, channels, depth, heads, in_chans
+    for field, key in MODEL_PARAMS:
+        setattr(w, field, _ptr(get(key), key))
+    w.freqs = _ptr(freqs, "freqs")
+    for dst, prefix in ((w.ste, "STEblocks"), (w.tte, "TTEblocks")):
+        for i in range(depth):
+            for field, key in BLOCK_PARAMS:
+                setattr(dst[i], field, _ptr(get(f"{prefix}.{i}.{key}"), f"{prefix}.{i}.{key}"))
 
 
 def fill_block_struct(dst, blk):

@@ -1,0 +1,239 @@
+"""PyTorch-ROCm custom ops over the C ABI: ``torch.ops.pafuse.*`` ("native surface").
+
+Importing this module registers, for the HIP device only (a CPU tensor gets torch's "no kernel for backend" error -
+there is no fallback), with fake-tensor shape functions so the ops trace under ``torch.export`` / ``torch.compile``:
+
+  pafuse::linear(x, weight, bias, gelu)                    nn.Linear (+ exact GELU)       common/mixste.py:30-43,54,57
+  pafuse::layer_norm(x, weight, bias, eps)                 nn.LayerNorm                   common/mixste.py:96,101
+  pafuse::attention(qkv, heads, seq_len, joints)           softmax(q k^T d^-1/2) v        common/mixste.py:65-79
+  pafuse::block(x, weights[12], heads)                     Block.forward on [S,L,C]       common/mixste.py:113-116
+  pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads)  MixSTE2.forward, eval          common/mixste.py:278-298
+  pafuse::ddim_loop(...)                                   D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
+
+``weights`` lists are in ``named_parameters()`` order of the corresponding module (= the reference's state-dict
+order), so ``list(model.parameters())`` is the argument.  The modules in pafuse_amd call the C ABI directly; these ops
+are the same entry points for callers that want schema'd operators instead of nn.Modules.
+"""
+import ctypes as C
+from functools import lru_cache
+from typing import List
+
+import torch
+
+from . import _lib
+from .mixste2 import MixSTE2, _ptr, fill_weights_struct, sinusoid_frequencies
+
+BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+              "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+@lru_cache(maxsize=None)
+def mixste_param_names(frames, joints, channels, depth, heads):
+    """named_parameters() order of a MixSTE2 of these dimensions (built on the meta device: no storage)."""
+    with torch.device("meta"):
+        m = MixSTE2(num_frame=frames, num_joints=joints, in_chans=5, embed_dim_ratio=channels, depth=depth,
+                    num_heads=heads, is_train=False)
+    return tuple(n for n, _ in m.named_parameters())
+
+
+_freq_cache = {}
+
+
+def _freqs(channels, device):
+    key = (channels, device)
+    if key not in _freq_cache:
+        _freq_cache[key] = sinusoid_frequencies(channels).to(device)
+    return _freq_cache[key]
+
+
+def mixste_struct(weights, frames, joints, depth, heads):
+    """pafuse_mixste2_weights from a flat parameter list; returns (struct, keep-alive)."""
+    channels = weights[0].shape[-1]                           # Spatial_pos_embed [1,J,C] comes first
+    names = mixste_param_names(frames, joints, channels, depth, heads)
+    if len(weights) != len(names):
+        raise _lib.PafuseError(f"expected {len(names)} weight tensors (named_parameters() order), got {len(weights)}")
+    table = dict(zip(names, weights))
+    for n, t in table.items():
+        _ptr(t, n)
+    fr = _freqs(channels, weights[0].device)
+    w = _lib.MixSTE2Weights()
+    fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5)
+    return w, (table, fr)
+
+
+# ------------------------------------------------------------------------------------------------ unit ops
+@torch.library.custom_op("pafuse::linear", mutates_args=(), device_types="cuda")
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    K, N = x.shape[-1], weight.shape[0]
+    x2 = x.contiguous().view(-1, K)
+    out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+    _lib.check(lib.pafuse_linear(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
+                                 x2.shape[0], N, K, int(gelu), _stream(x)))
+    return out.view(*x.shape[:-1], N)
+
+
+@linear.register_fake
+def _(x, weight, bias, gelu=False):
+    return x.new_empty(*x.shape[:-1], weight.shape[0])
+
+
+@torch.library.custom_op("pafuse::layer_norm", mutates_args=(), device_types="cuda")
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    x2 = x.contiguous().view(-1, Cc)
+    out = torch.empty_like(x2)
+    _lib.check(lib.pafuse_layernorm(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
+                                    x2.shape[0], Cc, eps, _stream(x)))
+    return out.view(x.shape)
+
+
+@layer_norm.register_fake
+def _(x, weight, bias, eps):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("pafuse::attention", mutates_args=(), device_types="cuda")
+def attention(qkv: torch.Tensor, heads: int, seq_len: int, joints: int = 0) -> torch.Tensor:
+    """qkv [M,3C] in the fixed (r,f,j) token order.  joints == 0: M/seq_len contiguous sequences (spatial,
+    seq_len = J); joints > 0: temporal sequences of seq_len = F tokens at stride `joints`."""
+    lib = _lib.load()
+    M, C3 = qkv.shape
+    Cc = C3 // 3
+    if M % seq_len or (joints and M % (seq_len * joints)):
+        raise _lib.PafuseError(f"attention: {M} rows do not split into sequences of {seq_len}")
+    o = torch.empty(M, Cc, device=qkv.device, dtype=torch.float32)
+    if joints:
+        args = (M // seq_len, seq_len, Cc, heads, joints, seq_len * joints, 1, joints)
+    else:
+        args = (M // seq_len, seq_len, Cc, heads, 1, seq_len, 0, 1)
+    _lib.check(lib.pafuse_attention(_ptr(qkv, "qkv"), o.data_ptr(), *args, _stream(qkv)))
+    return o
+
+
+@attention.register_fake
+def _(qkv, heads, seq_len, joints=0):
+    return qkv.new_empty(qkv.shape[0], qkv.shape[1] // 3)
+
+
+@torch.library.custom_op("pafuse::block", mutates_args=(), device_types="cuda")
+def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int) -> torch.Tensor:
+    """Block.forward on [S,L,C]: S sequences of L tokens (spatial: L = J; temporal: the caller passes [.., F, C])."""
+    lib = _lib.load()
+    if len(weights) != len(BLOCK_KEYS):
+        raise _lib.PafuseError(f"block: expected {len(BLOCK_KEYS)} tensors in order {BLOCK_KEYS}")
+    S, L, Cc = x.shape
+    y = x.contiguous().clone()
+    w = _lib.BlockWeights()
+    for field, t, name in zip(_lib.BLOCK_FIELDS, weights, BLOCK_KEYS):
+        setattr(w, field, _ptr(t, name))
+    nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.pafuse_block_forward(C.byref(w), _ptr(y, "x"), S, L, Cc, heads, ws.data_ptr(), nbytes, _stream(x)))
+    return y
+
+
+@block.register_fake
+def _(x, weights, heads):
+    return torch.empty_like(x)
+
+
+# ------------------------------------------------------------------------------------------- model-level ops
+@torch.library.custom_op("pafuse::mixste_eval", mutates_args=(), device_types="cuda")
+def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: List[torch.Tensor], depth: int,
+                heads: int) -> torch.Tensor:
+    lib = _lib.load()
+    B, P, F, J, _ = x3d.shape
+    w, keep = mixste_struct(weights, F, J, depth, heads)
+    x2d, x3d, t = x2d.contiguous().float(), x3d.contiguous().float(), t.contiguous().long()
+    out = torch.empty(B, P, F, J, 3, device=x3d.device, dtype=torch.float32)
+    nbytes = lib.pafuse_mixste2_workspace_bytes(C.byref(w), B, P)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x3d.device)
+    _lib.check(lib.pafuse_mixste2_forward(C.byref(w), _ptr(x2d, "x2d"), _ptr(x3d, "x3d"), t.data_ptr(), B, P,
+                                          out.data_ptr(), ws.data_ptr(), nbytes, _stream(x3d)))
+    return out
+
+
+@mixste_eval.register_fake
+def _(x2d, x3d, t, weights, depth, heads):
+    return torch.empty_like(x3d)
+
+
+@torch.library.custom_op("pafuse::ddim_loop", mutates_args=(), device_types="cuda")
+def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, weights: List[torch.Tensor],
+              part_joints: List[torch.Tensor], flip_perm: torch.Tensor, depth: int, heads: int, times: List[int],
+              sched: List[float], flip: bool, scale: float) -> torch.Tensor:
+    """The whole sampler.  noise [n_draws,B,P,F,J,3] in the reference's draw order; weights = the per-part
+    parameter lists concatenated in part order; part_joints[i] int32 joint indices of part i; flip_perm int32 [J];
+    times[k] the k-th timestep (the last one is the step whose time_next < 0); sched 5 doubles per step:
+    sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t], sqrt(alpha_next), c, sigma.  -> [B,T,P,F,J,3]"""
+    lib = _lib.load()
+    n_draws, B, P, F, J, _ = noise.shape
+    T = len(times)
+    if len(sched) != 5 * T or len(part_joints) > _lib.MAX_PARTS:
+        raise _lib.PafuseError("ddim_loop: sched needs 5 values per step; at most %d parts" % _lib.MAX_PARTS)
+    dev = noise.device
+    cfg = _lib.D3DPConfig()
+    cfg.num_parts, cfg.num_kps, cfg.frames, cfg.flip, cfg.scale = len(part_joints), J, F, int(flip), float(scale)
+    keep, at = [], 0
+    joint_part = torch.full((J,), -1, dtype=torch.int32)
+    joint_local = torch.zeros(J, dtype=torch.int32)
+    for i, idx in enumerate(part_joints):
+        Jp = idx.numel()
+        n = len(mixste_param_names(F, Jp, weights[at].shape[-1], depth, heads))
+        w, k = mixste_struct(weights[at:at + n], F, Jp, depth, heads)
+        at += n
+        idx32 = idx.to(device=dev, dtype=torch.int32).contiguous()
+        cfg.part[i], cfg.part_joints[i] = w, idx32.data_ptr()
+        host = idx.cpu().long()
+        joint_part[host] = i
+        joint_local[host] = torch.arange(Jp, dtype=torch.int32)
+        keep += [k, idx32]
+    if at != len(weights) or int(joint_part.min()) < 0:
+        raise _lib.PafuseError("ddim_loop: weights / part_joints do not cover the model")
+    joint_part, joint_local = joint_part.to(dev), joint_local.to(dev)
+    perm = flip_perm.to(device=dev, dtype=torch.int32).contiguous()
+    cfg.joint_part, cfg.joint_local, cfg.flip_perm = joint_part.data_ptr(), joint_local.data_ptr(), perm.data_ptr()
+    steps = (_lib.DDIMStep * T)()
+    for k in range(T):
+        st = steps[k]
+        st.time, st.last = int(times[k]), int(k == T - 1)
+        st.sqrt_recip_acp, st.sqrt_recipm1_acp, st.sqrt_alpha_next, st.c, st.sigma = sched[5 * k:5 * k + 5]
+    if n_draws < T:
+        raise _lib.PafuseError(f"ddim_loop: {T} steps need {T} noise draws, got {n_draws}")
+    x2d = x2d.contiguous().float()
+    x2f = x2d_flip.contiguous().float() if flip else x2d
+    noise = noise.contiguous().float()
+    out = torch.empty(B, T, P, F, J, 3, device=dev, dtype=torch.float32)
+    nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.pafuse_d3dp_sample(C.byref(cfg), steps, T, _ptr(x2d, "x2d"), _ptr(x2f, "x2d_flip"),
+                                      _ptr(noise, "noise"), n_draws, B, P, out.data_ptr(), ws.data_ptr(), nbytes,
+                                      _stream(noise), None, 0))
+    return out
+
+
+@ddim_loop.register_fake
+def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale):
+    n_draws, B, P, F, J, _ = noise.shape
+    return noise.new_empty(B, len(times), P, F, J, 3)
+
+
+def ddim_loop_args(model):
+    """The (weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale) tail of pafuse::ddim_loop for a
+    pafuse_amd.D3DP instance."""
+    weights, joints = [], []
+    for part, m in model.pose_estimator.items():
+        weights += list(m.parameters())
+        joints.append(getattr(model, f"_joints_{part}"))
+    first = next(iter(model.pose_estimator.values()))
+    steps = model.ddim_steps()
+    times = [int(s.time) for s in steps]
+    sched = [v for s in steps for v in (s.sqrt_recip_acp, s.sqrt_recipm1_acp, s.sqrt_alpha_next, s.c, s.sigma)]
+    return (weights, joints, model._flip_perm, first.block_depth, first.num_heads, times, sched, bool(model.flip),
+            float(model.scale))

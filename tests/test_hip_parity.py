@@ -359,7 +359,7 @@ def test_graph_replay_equals_eager():
     model, _ = make_model(2, 3, seed=85)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     for aux in (None, 2):
-        model.aux_streams = [torch.cuda.Stream() for _ in range(aux)] if aux else None
+        model.aux_streams = [torch.cuda.Stream() for _ in range(aux)] if aux else []
         for seed in (10, 11):
             noises = gu.synthetic_noises(B=1, P=2, n=3, seed=seed)
             model.noise_fn = lambda k, shape, device: noises[k]
@@ -370,6 +370,57 @@ def test_graph_replay_equals_eager():
             torch.cuda.synchronize()
             assert torch.equal(eager, graphed), (aux, seed)
         model._graphs.clear()
+
+
+def test_torch_custom_ops_equal_the_modules():
+    """torch.ops.pafuse.* (pafuse_amd/torch_ops.py) are the same entry points as the nn.Modules: bit-equal outputs."""
+    from __graft_entry__ import make_model
+    from pafuse_amd import torch_ops as to
+    ops = torch.ops.pafuse
+    x, w, b = _seeded((70, 256), 1).to(DEV), _seeded((512, 256), 2).to(DEV), _seeded((512,), 3).to(DEV)
+    from pafuse_amd import ops as wrap
+    assert torch.equal(ops.linear(x, w, b, True), wrap.linear(x, w, b, act="gelu"))
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(x.double(), w.double(), b.double()))
+    assert torch.allclose(ops.linear(x, w, b, True).double(), ref, rtol=1e-5, atol=2e-5)
+    g, be = _seeded((256,), 4).to(DEV), _seeded((256,), 5).to(DEV)
+    assert torch.equal(ops.layer_norm(x, g, be, 1e-6), wrap.layer_norm(x, g, be, 1e-6))
+    model, _ = make_model(3, 2, seed=91)
+    body = model.pose_estimator["body"]
+    x2d = _seeded((2, 27, 24, 2), 6).to(DEV)
+    x3d = _seeded((2, 3, 27, 24, 3), 7).to(DEV)
+    t = torch.tensor([999, 499], device=DEV)
+    assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads),
+                       body(x2d, x3d, t))
+    blk = body.STEblocks[0]
+    xs = _seeded((4, 24, 384), 8).to(DEV)
+    from pafuse_amd.ops import block_forward
+    assert torch.equal(ops.block(xs, list(blk.parameters()), 8), block_forward(blk, xs))
+    qkv = _seeded((2 * 27 * 24, 3 * 384), 9).to(DEV)
+    from pafuse_amd.ops import attention
+    assert torch.equal(ops.attention(qkv, 8, 24, 0), attention(qkv, 8, 2 * 27, 24))
+    assert torch.equal(ops.attention(qkv, 8, 27, 24),
+                       attention(qkv, 8, 2 * 24, 27, group=24, group_stride=27 * 24, seq_stride=1, tok_stride=24))
+    i2d, i2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=3, n=2, seed=12)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    want = model(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV))
+    got = ops.ddim_loop(i2d.to(DEV), i2f.to(DEV), torch.stack(noises).to(DEV), *to.ddim_loop_args(model))
+    assert torch.equal(got, want)
+
+
+def test_replicas_share_nothing_device_bound():
+    """nn.DataParallel replicates the module per device and calls forward from worker threads (main_h3wb.py:699-705):
+    a replica must build its own weight table and streams from its own parameters."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(2, 1, seed=93)
+    i2d, i2f = gu.synthetic_inputs_2d(B=2)
+    noises = gu.synthetic_noises(B=2, P=2, n=1, seed=13)
+    model.noise_fn = lambda k, shape, device: noises[k][:shape[0]]
+    want = model(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV))
+    dp = torch.nn.DataParallel(model, device_ids=[0])
+    assert torch.equal(dp(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV)), want)
+    replica = torch.nn.parallel.replicate(model, [0])[0]
+    assert torch.equal(replica(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV)), want)
 
 
 def test_g11_scale_golden():

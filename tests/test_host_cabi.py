@@ -127,3 +127,24 @@ def test_config_tree_and_overrides():
         # the module mirror constructs from the tree exactly like from the reference's args
         from __graft_entry__ import make_model
         assert make_model(1, 1, device="cpu")[0].frames == ref.model.number_of_frames
+
+
+def test_torch_custom_ops_are_registered_for_the_hip_device_only():
+    """pafuse::* ops exist with fake-tensor shape functions; a CPU tensor has no kernel (no fallback)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from pafuse_amd import torch_ops as to
+    for name in ("linear", "layer_norm", "attention", "block", "mixste_eval", "ddim_loop"):
+        assert hasattr(torch.ops.pafuse, name)
+    assert len(to.mixste_param_names(27, 24, 384, 8, 8)) == 208
+    with FakeTensorMode():
+        x = torch.empty(10, 384, device="cuda")
+        w, b = torch.empty(1152, 384, device="cuda"), torch.empty(1152, device="cuda")
+        assert torch.ops.pafuse.linear(x, w, b, True).shape == (10, 1152)
+        assert torch.ops.pafuse.attention(torch.empty(54, 1152, device="cuda"), 8, 27, 2).shape == (54, 384)
+        noise = torch.empty(2, 1, 3, 27, 134, 3, device="cuda")
+        out = torch.ops.pafuse.ddim_loop(torch.empty(1, 27, 134, 2, device="cuda"), torch.empty(1, 27, 134, 2, device="cuda"),
+                                         noise, [], [], torch.empty(134, device="cuda"), 8, 8, [999, 499], [0.0] * 10,
+                                         True, 1.0)
+        assert out.shape == (1, 2, 3, 27, 134, 3)
+    with pytest.raises(NotImplementedError):
+        torch.ops.pafuse.linear(torch.zeros(2, 32), torch.zeros(32, 32), torch.zeros(32))
