@@ -18,6 +18,8 @@
  *   pafuse_d3dp_sample       D3DP.ddim_sample_flip / ddim_sample, common/diffusionpose.py:227-316
  *                            (with model_predictions[_fliping] :174-225, pred_parts/split_data :163-172,328-335)
  *   pafuse_hypothesis_errors the per-joint part of evaluate()'s aggregation, main_h3wb.py:327-362
+ *   pafuse_mixste2_train_*   MixSTE2.forward (is_train=True) + autograd backward, common/mixste.py:215-225,260-298
+ *   pafuse_d3dp_qsample      D3DP.prepare_diffusion_concat / q_sample, common/diffusionpose.py:319-326,358-374
  */
 #ifndef PAFUSE_HIP_H
 #define PAFUSE_HIP_H
@@ -154,6 +156,32 @@ int pafuse_hypothesis_errors(const float *pred, const float *gt, const float *x2
  * *flops.  Uses (and overwrites) the workspace like pafuse_d3dp_sample does. */
 int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config *cfg, int32_t B, int32_t P, void *workspace,
                              size_t workspace_bytes, void *stream, double *flops);
+
+/* ---- Training: MixSTE2 in train mode and its backward -------------------------------------------
+ * Replaces MixSTE2.forward with is_train=True (common/mixste.py:215-225,260-298: no hypothesis axis, DropPath on
+ * both residual branches of every Block :113-116) and what autograd derives from it.
+ *   x2d [B,F,J,2], x3d [B,F,J,3] (the noised target), t [B] -> out [B,F,J,3]
+ *   drop_path: NULL (no DropPath) or float [2*depth][2][B*max(F,J)] - for block k in execution order (STE0, TTE0,
+ *              STE1, ...) and branch (0 attention, 1 MLP) the factor mask/keep_prob of every sequence (spatial
+ *              blocks: B*F sequences (b,f); temporal blocks: B*J sequences (b,j)), as timm's DropPath draws it.
+ *   saved:     pafuse_mixste2_train_bytes(w, B) bytes; the forward leaves the activations the backward needs there.
+ * Backward: dout [B,F,J,3] -> ADDS the gradient of every parameter into the buffer the like-named pointer of `grads`
+ * addresses (same struct as the weights; `freqs` and the dimensions are ignored).  All row reductions are two-stage
+ * in a fixed order: bit-reproducible, no atomics. */
+size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights *w, int32_t B);
+int pafuse_mixste2_train_forward(const pafuse_mixste2_weights *w, const float *x2d, const float *x3d, const int64_t *t,
+                                 int32_t B, const float *drop_path, float *out, void *saved, size_t saved_bytes,
+                                 void *stream);
+int pafuse_mixste2_train_backward(const pafuse_mixste2_weights *w, const pafuse_mixste2_weights *grads,
+                                  const float *dout, int32_t B, const float *drop_path, void *saved, size_t saved_bytes,
+                                  void *stream);
+
+/* D3DP.prepare_diffusion_concat + q_sample (common/diffusionpose.py:319-326,358-374) for B samples of per_sample
+ * floats: out = clamp(sqrt_acp[t_b] * (x0*scale) + sqrt_1m_acp[t_b] * noise, +-1.1 scale) / scale, in fp64 as the
+ * reference's fp64 buffers force, cast to fp32. */
+int pafuse_d3dp_qsample(const float *x0, const float *noise, const int64_t *t, const double *sqrt_alphas_cumprod,
+                        const double *sqrt_one_minus_alphas_cumprod, double scale, float *out, int32_t B,
+                        int64_t per_sample, void *stream);
 
 #ifdef __cplusplus
 }

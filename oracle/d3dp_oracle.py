@@ -3,6 +3,8 @@
 Plain-PyTorch fp32 restatement, written in functional style over a flat state dict, of
 
   * the per-part MixSTE denoiser, eval branch    (reference common/mixste.py:226-298)
+  * its train branch with DropPath, and D3DP's training forward (q_sample targets); torch autograd over these
+    functions is the gradient oracle            (reference common/mixste.py:215-225, common/diffusionpose.py:319-388)
   * the D3DP flip-TTA DDIM sampler               (reference common/diffusionpose.py:192-225, 272-316)
   * the no-TTA sampler                           (reference common/diffusionpose.py:174-190, 227-270)
   * the cosine schedule and its fp64 buffers     (reference common/diffusionpose.py:41-51, 86-132)
@@ -143,15 +145,46 @@ def _self_attention(sd, pre: str, x: Tensor, heads: int) -> Tensor:
     return F.linear(y, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
 
 
-def transformer_block(sd, pre: str, x: Tensor, heads: int, eps: float = 1e-6) -> Tensor:
-    """pre-norm block, DropPath = identity in eval (reference common/mixste.py:113-116)."""
-    x = x + _self_attention(sd, pre + "attn.", _layer_norm(sd, pre + "norm1", x, eps), heads)
+def transformer_block(sd, pre: str, x: Tensor, heads: int, eps: float = 1e-6, drop=None) -> Tensor:
+    """pre-norm block (reference common/mixste.py:113-116).  DropPath is the identity in eval; in training `drop` is
+    the pair of per-sequence factors (mask / keep_prob, shape [S]) timm's DropPath multiplies the two branches by."""
+    a = _self_attention(sd, pre + "attn.", _layer_norm(sd, pre + "norm1", x, eps), heads)
+    x = x + (a if drop is None or drop[0] is None else a * drop[0][:, None, None])
     h = F.linear(_layer_norm(sd, pre + "norm2", x, eps), sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
-    return x + F.linear(F.gelu(h), sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    m = F.linear(F.gelu(h), sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    return x + (m if drop is None or drop[1] is None else m * drop[1][:, None, None])
+
+
+def drop_path_rates(drop_path_rate: float, depth: int) -> List[float]:
+    """stochastic depth decay rule (reference common/mixste.py:187); STE block i and TTE block i share dpr[i]."""
+    return [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+
+
+def drop_path_factors(rate: float, nseq: int, like: Tensor) -> Optional[Tensor]:
+    """timm.models.layers.DropPath (absent third-party dependency, version unpinned by the reference's README; the
+    published algorithm of timm.layers.drop.drop_path, scale_by_keep=True): one Bernoulli(keep) draw per sample of
+    the block's batch axis, divided by keep.  rate == 0 builds nn.Identity (common/mixste.py:100): no draw at all."""
+    if rate <= 0.0:
+        return None
+    keep = 1.0 - rate
+    mask = like.new_empty((nseq, 1, 1)).bernoulli_(keep)
+    if keep > 0.0:
+        mask.div_(keep)
+    return mask.reshape(nseq)
+
+
+def draw_drop_path(drop_path_rate: float, depth: int, B: int, Fr: int, J: int, like: Tensor):
+    """The DropPath factors of one train-mode MixSTE2.forward in the reference's draw order: STE0 (attn, mlp), TTE0,
+    STE1, ...; spatial blocks see B*F sequences, temporal blocks B*J."""
+    out = []
+    for r in drop_path_rates(drop_path_rate, depth):
+        for nseq in (B * Fr, B * J):
+            out.append((drop_path_factors(r, nseq, like), drop_path_factors(r, nseq, like)))
+    return out
 
 
 def mixste2_eval(sd: Dict[str, Tensor], pre: str, x_2d: Tensor, x_3d: Tensor, t: Tensor,
-                 depth: int = 8, heads: int = 8, taps: Optional[dict] = None) -> Tensor:
+                 depth: int = 8, heads: int = 8, taps: Optional[dict] = None, drop=None) -> Tensor:
     """MixSTE2.forward with is_train=False (reference common/mixste.py:278-298).
 
     x_2d [B,F,J,2], x_3d [B,P,F,J,3], t [B] int64 -> [B,P,F,J,3].  The token matrix is kept in one fixed
@@ -169,13 +202,13 @@ def mixste2_eval(sd: Dict[str, Tensor], pre: str, x_2d: Tensor, x_3d: Tensor, t:
         taps["embed"] = x.clone()
     for i in range(depth):
         # spatial block: sequences are the J joints of one (b,p,f)             mixste.py:239-244 / 264-270
-        x = transformer_block(sd, f"{pre}STEblocks.{i}.", x, heads)
+        x = transformer_block(sd, f"{pre}STEblocks.{i}.", x, heads, drop=None if drop is None else drop[2 * i])
         x = _layer_norm(sd, pre + "Spatial_norm", x, 1e-6)
         x = x.reshape(R, Fr, J, C).permute(0, 2, 1, 3).reshape(R * J, Fr, C)            # (b n) f c
         if i == 0:
             x = x + sd[pre + "Temporal_pos_embed"]                                      # mixste.py:250
         # temporal block: sequences are the F frames of one (b,p,j)             mixste.py:252-257 / 272-274
-        x = transformer_block(sd, f"{pre}TTEblocks.{i}.", x, heads)
+        x = transformer_block(sd, f"{pre}TTEblocks.{i}.", x, heads, drop=None if drop is None else drop[2 * i + 1])
         x = _layer_norm(sd, pre + "Temporal_norm", x, 1e-6)
         x = x.reshape(R, J, Fr, C).permute(0, 2, 1, 3).reshape(R * Fr, J, C)            # back to (b f) n c
         if taps is not None:
@@ -183,6 +216,45 @@ def mixste2_eval(sd: Dict[str, Tensor], pre: str, x_2d: Tensor, x_3d: Tensor, t:
     x = _layer_norm(sd, pre + "head.0", x, 1e-5)                                        # mixste.py:207-210
     x = F.linear(x, sd[pre + "head.1.weight"], sd[pre + "head.1.bias"])
     return x.reshape(B, P, Fr, J, 3)
+
+
+def mixste2_train(sd: Dict[str, Tensor], pre: str, x_2d: Tensor, x_3d: Tensor, t: Tensor, depth: int = 8,
+                  heads: int = 8, drop=None) -> Tensor:
+    """MixSTE2.forward with is_train=True (reference common/mixste.py:215-225,260-298): the same network without a
+    hypothesis axis - x_3d [B,F,J,3] is the noised target - and DropPath on both residual branches of every block.
+    `drop`: list over blocks in execution order (STE0, TTE0, STE1, ...) of (attn, mlp) factor vectors or None
+    (see draw_drop_path).  Differentiable: torch autograd of this function is the gradient oracle."""
+    return mixste2_eval(sd, pre, x_2d, x_3d[:, None], t, depth, heads, drop=drop)[:, 0]
+
+
+def q_sample_targets(sd: Dict[str, Tensor], x0: Tensor, t: Tensor, noise: Tensor, scale: float = 1.0) -> Tensor:
+    """D3DP.prepare_targets / prepare_diffusion_concat / q_sample (reference common/diffusionpose.py:319-326,358-388)
+    with the draws made by the caller: x0 [B,F,J,3], t [B] int64, noise [B,F,J,3] -> the noised poses, fp32
+    (the fp64 schedule buffers promote the arithmetic to fp64; D3DP.forward casts back, :348)."""
+    x_start = x0 * scale
+    a = sd["sqrt_alphas_cumprod"][t].reshape(-1, 1, 1, 1)
+    b = sd["sqrt_one_minus_alphas_cumprod"][t].reshape(-1, 1, 1, 1)
+    x = a * x_start + b * noise
+    x = torch.clamp(x, min=-1.1 * scale, max=1.1 * scale)
+    return (x / scale).float()
+
+
+def train_forward(sd: Dict[str, Tensor], inputs_2d: Tensor, x_poses: Tensor, t: Tensor, part_joints=None, depth=8,
+                  heads=8, drops=None) -> Tensor:
+    """D3DP.forward with is_train=True after prepare_targets (reference common/diffusionpose.py:346-356 + pred_parts
+    :163-172): every part's denoiser on its joints of the noised pose, concatenated in part order."""
+    part_joints = PART_JOINTS if part_joints is None else part_joints
+    outs = []
+    for k, (part, idx) in enumerate(part_joints.items()):
+        pre = f"pose_estimator.{part}."
+        outs.append(mixste2_train(sd, pre, inputs_2d[..., idx, :], x_poses[..., idx, :], t, depth, heads,
+                                  drop=None if drops is None else drops[k]))
+    return torch.cat(outs, dim=-2)
+
+
+def mpjpe(predicted: Tensor, target: Tensor) -> Tensor:
+    """training loss (reference common/loss.py:27-34, unweighted branch): mean L2 distance over all joints."""
+    return torch.mean(torch.norm(predicted - target, dim=len(target.shape) - 1))
 
 
 # ----------------------------------------------------------------------------------------------------------

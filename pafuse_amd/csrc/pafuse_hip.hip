@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "kernels.hpp"
+#include "train_kernels.hpp"
 
 using namespace pafuse;
 
@@ -265,6 +266,8 @@ __global__ void copy_kernel(const float* src, float* dst, int64_t n) {
     if (i < n) dst[i] = src[i];
 }
 
+#include "train_host.inc"
+
 }  // namespace
 
 // ================================================================================================== C ABI
@@ -426,14 +429,27 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     const bool multi = n_aux > 0 && lanes > 1;
     constexpr int MAX_LANES = 64;
     if (lanes > MAX_LANES) return fail(PAFUSE_E_ARG, "too many stream lanes (%d)", lanes);
-    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
-    if (multi) {
-        hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-        for (int i = 1; i < lanes; ++i) hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
-    }
-
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((img_elems + 255) / 256)), dim3(256), 0, s0, noise, img, img_elems);
     if ((rc = check_launch("copy_kernel"))) return rc;
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_LANES] = {};
+    if (multi) {
+        hipError_t e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+        for (int i = 1; i < lanes && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (ev_fork) hipEventDestroy(ev_fork);
+            for (int i = 1; i < lanes; ++i)
+                if (ev_join[i]) hipEventDestroy(ev_join[i]);
+            return fail(PAFUSE_E_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    bool forked = false;  // lanes hold work the main stream has not waited for yet
+    auto join = [&]() {
+        for (int i = 1; i < lanes; ++i) {
+            hipEventRecord(ev_join[i], lane_stream(i));
+            hipStreamWaitEvent(s0, ev_join[i], 0);
+        }
+        forked = false;
+    };
     int draw = 1;
     for (int k = 0; k < nsteps && rc == PAFUSE_OK; ++k) {
         const pafuse_ddim_step& st = steps[k];
@@ -444,6 +460,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
         if (multi) {
             hipEventRecord(ev_fork, s0);
             for (int i = 1; i < lanes; ++i) hipStreamWaitEvent(lane_stream(i), ev_fork, 0);
+            forked = true;
         }
         for (int lane = 0; lane < lanes && rc == PAFUSE_OK; ++lane) {
             const int i = lane % NP, gi = lane / NP;
@@ -464,11 +481,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             rc = run_mixste_layers(w, offset_rows(pb[i], row0, w->channels), r1 - r0, ls);
         }
         if (rc) break;
-        if (multi)
-            for (int i = 1; i < lanes; ++i) {
-                hipEventRecord(ev_join[i], lane_stream(i));
-                hipStreamWaitEvent(s0, ev_join[i], 0);
-            }
+        if (multi) join();
         FinalizeParams f{};
         for (int i = 0; i < NP; ++i) f.pred[i] = pb[i].pred, f.Jp[i] = cfg->part[i].joints;
         f.joint_part = cfg->joint_part, f.joint_local = cfg->joint_local, f.perm = cfg->flip_perm;
@@ -482,6 +495,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
         if (!st.last) ++draw;
     }
     if (multi) {
+        if (forked) join();  // error exit mid-step: the caller's stream still orders after everything launched
         hipEventDestroy(ev_fork);
         for (int i = 1; i < lanes; ++i) hipEventDestroy(ev_join[i]);
     }
@@ -522,6 +536,46 @@ int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P
     }
     if (flops) *flops += fl;
     return launches;
+}
+
+// ------------------------------------------------------------------------------------------------- training
+size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights* w, int32_t B) {
+    if (!w || B <= 0 || check_weights(w)) return 0;
+    return train_bytes(w, B);
+}
+
+int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x2d, const float* x3d, const int64_t* t,
+                                 int32_t B, const float* drop_path, float* out, void* saved, size_t saved_bytes,
+                                 void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!x2d || !x3d || !t || !out || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_forward: bad argument");
+    if (saved_bytes < train_bytes(w, B)) return fail(PAFUSE_E_WORKSPACE, "mixste2_train_forward: buffer too small");
+    TrainBuffers tb;
+    carve_train((char*)saved, w, B, tb);
+    return train_forward(w, x2d, x3d, t, B, drop_path, out, tb, (hipStream_t)stream);
+}
+
+int pafuse_mixste2_train_backward(const pafuse_mixste2_weights* w, const pafuse_mixste2_weights* grads, const float* dout,
+                                  int32_t B, const float* drop_path, void* saved, size_t saved_bytes, void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!grads || !dout || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_backward: bad argument");
+    if (saved_bytes < train_bytes(w, B)) return fail(PAFUSE_E_WORKSPACE, "mixste2_train_backward: buffer too small");
+    TrainBuffers tb;
+    carve_train((char*)saved, w, B, tb);
+    return train_backward(w, grads, dout, B, drop_path, tb, (hipStream_t)stream);
+}
+
+int pafuse_d3dp_qsample(const float* x0, const float* noise, const int64_t* t, const double* sqrt_alphas_cumprod,
+                        const double* sqrt_one_minus_alphas_cumprod, double scale, float* out, int32_t B,
+                        int64_t per_sample, void* stream) {
+    if (!x0 || !noise || !t || !sqrt_alphas_cumprod || !sqrt_one_minus_alphas_cumprod || !out || B <= 0 || per_sample <= 0)
+        return fail(PAFUSE_E_ARG, "d3dp_qsample: bad argument");
+    const int64_t n = (int64_t)B * per_sample;
+    hipLaunchKernelGGL(qsample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
+                       sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod, scale, out, per_sample, n);
+    return check_launch("qsample_kernel");
 }
 
 }  // extern "C"

@@ -1,0 +1,514 @@
+// train_kernels.hpp - device code of the training path: the train-mode forward pieces that the
+// fused inference epilogues do not cover (DropPath, saved pre-norm sums) and the backward of every layer of MixSTE2.
+// gfx950 only.  All reductions over rows are two-stage (per-workgroup partials in a fixed order, then one summing
+// pass), so gradients are bit-reproducible run to run - no float atomics anywhere.
+//
+// Reference layers (common/mixste.py): Mlp :24-43, Attention :46-82, Block :84-125 (timm DropPath on both residual
+// branches), MixSTE2.forward train branch :215-225,260-298; nn.LayerNorm / nn.GELU / nn.Linear backward as autograd
+// derives them.
+#pragma once
+#include "kernels.hpp"
+
+namespace pafuse {
+
+// row of the [(b,f,j),C] token matrix -> index of the sequence DropPath draws its mask for
+//   spatial block: sequences are (b,f): row / J          temporal block: sequences are (b,j)
+struct SeqMap {
+    int temporal, J, FJ;
+};
+__device__ __forceinline__ int64_t seq_of(int64_t row, const SeqMap m) {
+    return m.temporal ? (row / m.FJ) * m.J + row % m.J : row / m.J;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Forward: x_sum = resid + drop[seq] * branch ; y = postLN(x_sum) (+ pos[f]) ; xn = nextLN(y).  One wave per row.
+// Every stage is optional (null pointer = skipped); this is the unfused form of the inference GEMM epilogue with
+// the two things training adds: the per-sequence DropPath factor and the pre-norm sum kept for the backward pass.
+// ----------------------------------------------------------------------------------------------------------------
+struct TrainRowParams {
+    const float *resid, *branch;  // [M,C]; branch may be null
+    const float* drop;            // [nseq] mask / keep_prob, or null (= 1)
+    SeqMap map;
+    float* out_sum;  // [M,C] or null
+    const float *post_w, *post_b;
+    float post_eps;
+    const float* pos;  // [posF,C] or null: added after the post norm (Temporal_pos_embed, first temporal block)
+    int posJ, posF;
+    float* out_y;  // [M,C] or null
+    const float *next_w, *next_b;
+    float next_eps;
+    float* out_n;  // [M,C] or null
+    int64_t M;
+    int C;
+};
+
+__global__ void __launch_bounds__(256) train_row_kernel(const TrainRowParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int C = p.C;
+    float v[LN_MAX_PER_LANE];
+    const float d = (p.branch && p.drop) ? p.drop[seq_of(row, p.map)] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = 0.f;
+        if (c < C) {
+            v[i] = p.resid[row * C + c];
+            if (p.branch) v[i] = v[i] + d * p.branch[row * C + c];  // x + drop_path(f(x)): one multiply, one add
+            if (p.out_sum) p.out_sum[row * C + c] = v[i];
+        }
+    }
+    if (p.post_w) wave_layer_norm(v, C, lane, p.post_w, p.post_b, p.post_eps);
+    if (p.pos) {
+        const int f = (int)((row / p.posJ) % p.posF);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+            if (lane + 64 * i < C) v[i] += p.pos[f * C + lane + 64 * i];
+    }
+    if (p.out_y) {
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+            if (lane + 64 * i < C) p.out_y[row * C + lane + 64 * i] = v[i];
+    }
+    if (p.out_n) {
+        wave_layer_norm(v, C, lane, p.next_w, p.next_b, p.next_eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+            if (lane + 64 * i < C) p.out_n[row * C + lane + 64 * i] = v[i];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  y = (x - mean) * rstd * w + b  =>  with g = dy * w, xh = (x - mean) * rstd:
+//   dx = rstd * (g - mean(g) - xh * mean(g * xh)),  dw = sum_rows dy * xh,  db = sum_rows dy.
+// dx_out = add + dx (add may be null: the residual gradient that bypasses the norm); out_scaled = drop[seq] * dx_out
+// (the gradient entering the DropPath-scaled branch below).  A wave walks LNB_ROWS_PER_WAVE rows and keeps its slice of
+// dw/db in registers; the four waves of a workgroup combine through LDS into partial[block][2][C].
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int LNB_ROWS_PER_WAVE = 16;
+constexpr int LNB_ROWS_PER_BLOCK = 4 * LNB_ROWS_PER_WAVE;
+
+struct LnBackwardParams {
+    const float *dy, *x, *w;  // [M,C], [M,C], [C]
+    float eps;
+    const float* add;  // [M,C] or null
+    float* dx;         // [M,C]
+    const float* drop;  // [nseq] or null
+    SeqMap map;
+    float* out_scaled;  // [M,C] or null
+    float* partial;     // [blocks][2][C]
+    int64_t M;
+    int C;
+};
+
+__global__ void __launch_bounds__(256) ln_backward_kernel(const LnBackwardParams p) {
+    __shared__ float red[4][2][64 * LN_MAX_PER_LANE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C = p.C;
+    const float invC = 1.0f / (float)C;
+    float dw[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE], wv[LN_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        dw[i] = db[i] = 0.f;
+        wv[i] = (lane + 64 * i < C) ? p.w[lane + 64 * i] : 0.f;
+    }
+    const int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS_PER_BLOCK + wave * LNB_ROWS_PER_WAVE;
+    for (int rr = 0; rr < LNB_ROWS_PER_WAVE; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= p.M) break;  // wave-uniform
+        float x[LN_MAX_PER_LANE], dy[LN_MAX_PER_LANE];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const bool in = lane + 64 * i < C;
+            x[i] = in ? p.x[row * C + lane + 64 * i] : 0.f;
+            dy[i] = in ? p.dy[row * C + lane + 64 * i] : 0.f;
+            s += x[i];
+        }
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+            if (lane + 64 * i < C) {
+                const float dlt = x[i] - mean;
+                q += dlt * dlt;
+            }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + p.eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
+            if (lane + 64 * i < C) {
+                x[i] = (x[i] - mean) * rstd;  // xh
+                const float g = dy[i] * wv[i];
+                sg += g;
+                sgx += g * x[i];
+                dw[i] += dy[i] * x[i];
+                db[i] += dy[i];
+            }
+        const float c1 = wave_sum(sg) * invC, c2 = wave_sum(sgx) * invC;
+        const float d = p.drop ? p.drop[seq_of(row, p.map)] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                float v = rstd * (dy[i] * wv[i] - c1 - x[i] * c2);
+                if (p.add) v += p.add[row * C + c];
+                p.dx[row * C + c] = v;
+                if (p.out_scaled) p.out_scaled[row * C + c] = d * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        red[wave][0][lane + 64 * i] = dw[i];
+        red[wave][1][lane + 64 * i] = db[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        p.partial[((int64_t)blockIdx.x * 2 + which) * C + c] =
+            ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
+    }
+}
+
+// out[i] = (accumulate ? out[i] : 0) + sum_s partial[s * stride + i], s ascending (fixed order)
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partial, float* out, int n, int nparts,
+                                                              int64_t stride, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += partial[(int64_t)k * stride + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Exact GELU forward / backward (nn.GELU(), approximate='none'):  d/du [u Phi(u)] = Phi(u) + u phi(u)
+// ----------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gelu_forward_kernel(const float* u, float* h, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(u)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    reinterpret_cast<f32x4*>(h)[i] = v;
+}
+
+__global__ void __launch_bounds__(256) gelu_backward_kernel(const float* u, const float* dh, float* du, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 uv = reinterpret_cast<const f32x4*>(u)[i], g = reinterpret_cast<const f32x4*>(dh)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = uv[e];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+        o[e] = g[e] * (cdf + x * pdf);
+    }
+    reinterpret_cast<f32x4*>(du)[i] = o;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM: dW[n][k] = sum_m dY[m][n] * X[m][k]  (nn.Linear: dY [M,N] output grad, X [M,K] its input).
+// Both operands are read as they lie in memory (rows = the contracted index m), staged in LDS in that natural [m][.]
+// layout, and fed to v_mfma_f32_32x32x2_f32 with scalar LDS reads: lane (r,h) needs Y[m=2s+h][n=r'] - 32 consecutive
+// floats per half-wave, and the +32 row padding puts the two halves on disjoint banks.  128(n) x 64(k) output tiles,
+// wave w owns the 32-row strip w.  The contraction is M = 25-70 k rows and the output is small, so M is cut into
+// `splits` ranges (grid.y) whose partial tiles are summed afterwards in a fixed order.
+// ----------------------------------------------------------------------------------------------------------------
+struct TnParams {
+    const float *Y, *X;  // [M,N], [M,K]
+    float* partial;      // [splits][N][K]
+    int64_t M, rows_per_split;
+    int N, K;
+};
+
+constexpr int TN_BN = 128, TN_BK = 64, TN_LDY = TN_BN + 32, TN_LDX = TN_BK + 32;
+
+__global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ys[32 * TN_LDY];
+    __shared__ __attribute__((aligned(16))) float Xs[32 * TN_LDX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_k = (p.K + TN_BK - 1) / TN_BK;
+    const int n0 = (blockIdx.x / tiles_k) * TN_BN, k0 = (blockIdx.x % tiles_k) * TN_BK;
+    const int64_t m_lo = (int64_t)blockIdx.y * p.rows_per_split;
+    const int64_t m_hi = m_lo + p.rows_per_split < p.M ? m_lo + p.rows_per_split : p.M;
+    // staging: Y chunk = 32 rows x 32 float4, X chunk = 32 rows x 16 float4
+    const int yrow = tid >> 5, yc4 = tid & 31;  // rows yrow + 8 i, i < 4
+    const int xrow = tid >> 4, xc4 = tid & 15;  // rows xrow + 16 i, i < 2
+    const bool y_in = n0 + 4 * yc4 < p.N, x_in = k0 + 4 * xc4 < p.K;  // N, K are multiples of 4
+    f32x4 yreg[4], xreg[2];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + yrow + 8 * i;
+            yreg[i] = (y_in && m < m_hi) ? *reinterpret_cast<const f32x4*>(p.Y + m * p.N + n0 + 4 * yc4) : zero;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t m = m0 + xrow + 16 * i;
+            xreg[i] = (x_in && m < m_hi) ? *reinterpret_cast<const f32x4*>(p.X + m * p.K + k0 + 4 * xc4) : zero;
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ys + (yrow + 8 * i) * TN_LDY + 4 * yc4) = yreg[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Xs + (xrow + 16 * i) * TN_LDX + 4 * xc4) = xreg[i];
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    if (m_lo < m_hi) {
+        load(m_lo);
+        store();
+        __syncthreads();
+        for (int64_t m0 = m_lo; m0 < m_hi; m0 += 32) {
+            const bool more = m0 + 32 < m_hi;
+            if (more) load(m0 + 32);
+            const float* ya = Ys + h * TN_LDY + wave * 32 + r;
+            const float* xb = Xs + h * TN_LDX + r;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float a = ya[2 * s * TN_LDY];
+                const float b0 = xb[2 * s * TN_LDX], b1 = xb[2 * s * TN_LDX + 32];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) store();
+            __syncthreads();
+        }
+    }
+    float* out = p.partial + (int64_t)blockIdx.y * p.N * p.K;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int k = k0 + 32 * b + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int n = n0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[b][reg];
+        }
+    }
+}
+
+// partial[chunk][n] = sum over the rows of the chunk of X[row][n]   (bias gradients)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* X, float* partial, int64_t M, int N,
+                                                     int64_t rows_per_chunk) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int64_t lo = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t hi = lo + rows_per_chunk < M ? lo + rows_per_chunk : M;
+    float s = 0.f;
+    for (int64_t m = lo; m < hi; ++m) s += X[m * N + n];
+    partial[(int64_t)blockIdx.y * N + n] = s;
+}
+
+// out[k][n] = in[n][k]  (weights, once per backward pass: the dX GEMMs reuse the inference kernel, which wants W^T rows)
+__global__ void __launch_bounds__(256) transpose_kernel(const float* in, float* out, int N, int K) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8)
+        if (n0 + i < N && k0 + tx < K) tile[i][tx] = in[(int64_t)(n0 + i) * K + k0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (k0 + i < K && n0 + tx < N) out[(int64_t)(k0 + i) * N + n0 + tx] = tile[tx][i];
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Attention backward for one (sequence, head) per workgroup.  With S = scale q k^T, P = softmax(S), O = P v:
+//   dV = P^T dO,  dP = dO v^T,  dS = P * (dP - rowsum(P * dP)),  dq = scale dS k,  dk = scale dS^T q.
+// P is recomputed from the saved qkv.  L <= 80, d <= 48: everything of one item lives in LDS; ~3 % of the FLOPs of a
+// training step, so plain FMA loops.
+// ----------------------------------------------------------------------------------------------------------------
+struct AttnBackwardParams {
+    const float* qkv;  // [M,3C]
+    const float* d_o;  // [M,C]
+    float* dqkv;       // [M,3C]
+    int64_t nseq, group, group_stride, seq_stride, tok_stride;  // addressing as in AttnParams
+    int L, C, heads, d;
+    float scale;
+};
+
+__global__ void __launch_bounds__(256) attn_backward_kernel(const AttnBackwardParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = p.L, d = p.d, ld = d + 1, lp = L + 1;
+    float* Q = smem;
+    float* Kk = Q + L * ld;
+    float* V = Kk + L * ld;
+    float* G = V + L * ld;  // dO
+    float* P = G + L * ld;  // [L][L+1]
+    float* D = P + L * lp;  // dP, then dS
+    const int tid = threadIdx.x;
+    const int64_t item = blockIdx.x;
+    const int64_t seq = item / p.heads;
+    const int head = (int)(item % p.heads);
+    const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
+    const int C3 = 3 * p.C;
+    for (int i = tid; i < L * d; i += 256) {
+        const int t = i / d, c = i % d;
+        const int64_t row = base + (int64_t)t * p.tok_stride;
+        const float* src = p.qkv + row * C3 + head * d + c;
+        Q[t * ld + c] = src[0];
+        Kk[t * ld + c] = src[p.C];
+        V[t * ld + c] = src[2 * p.C];
+        G[t * ld + c] = p.d_o[row * p.C + head * d + c];
+    }
+    __syncthreads();
+    for (int i = tid; i < L * L; i += 256) {
+        const int a = i / L, b = i % L;
+        float s = 0.f, g = 0.f;
+        for (int c = 0; c < d; ++c) {
+            s += Q[a * ld + c] * Kk[b * ld + c];
+            g += G[a * ld + c] * V[b * ld + c];
+        }
+        P[a * lp + b] = s * p.scale;
+        D[a * lp + b] = g;
+    }
+    __syncthreads();
+    if (tid < L) {  // softmax of row tid, then dS in place
+        float mx = -INFINITY;
+        for (int b = 0; b < L; ++b) mx = fmaxf(mx, P[tid * lp + b]);
+        float sum = 0.f;
+        for (int b = 0; b < L; ++b) {
+            const float e = expf(P[tid * lp + b] - mx);
+            P[tid * lp + b] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+        for (int b = 0; b < L; ++b) {
+            const float pr = P[tid * lp + b] * inv;
+            P[tid * lp + b] = pr;
+            dot += pr * D[tid * lp + b];
+        }
+        for (int b = 0; b < L; ++b) D[tid * lp + b] = P[tid * lp + b] * (D[tid * lp + b] - dot) * p.scale;
+    }
+    __syncthreads();
+    for (int i = tid; i < L * d; i += 256) {
+        const int t = i / d, c = i % d;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int b = 0; b < L; ++b) {
+            dq += D[t * lp + b] * Kk[b * ld + c];
+            dk += D[b * lp + t] * Q[b * ld + c];
+            dv += P[b * lp + t] * G[b * ld + c];
+        }
+        const int64_t row = base + (int64_t)t * p.tok_stride;
+        float* dst = p.dqkv + row * C3 + head * d + c;
+        dst[0] = dq;
+        dst[p.C] = dk;
+        dst[2 * p.C] = dv;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Small reductions of the first / last layers
+// ----------------------------------------------------------------------------------------------------------------
+// partial[chunk][g][c] = sum over the chunk's share of the rows of group g of x[row][c].  Groups over the (b,f,j) rows:
+//   mode 0: g = j (Spatial_pos_embed grad)   mode 1: g = f (Temporal_pos_embed grad)   mode 2: g = b (time embedding)
+__global__ void __launch_bounds__(256) group_sum_kernel(const float* x, float* partial, int mode, int B, int F, int J,
+                                                        int C, int G, int per_chunk) {
+    const int g = blockIdx.x, chunk = blockIdx.y;
+    const int count = mode == 0 ? B * F : (mode == 1 ? B * J : F * J);
+    const int lo = chunk * per_chunk, hi = lo + per_chunk < count ? lo + per_chunk : count;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int i = lo; i < hi; ++i) {
+            int64_t row;
+            if (mode == 0)
+                row = (int64_t)i * J + g;
+            else if (mode == 1)
+                row = ((int64_t)(i / J) * F + g) * J + i % J;
+            else
+                row = (int64_t)g * F * J + i;
+            s += x[row * C + c];
+        }
+        partial[((int64_t)chunk * G + g) * C + c] = s;
+    }
+}
+
+// partial[chunk][i][c] = sum over the chunk's rows of s[row][i] * x[row][c]   (i < NI <= 8):
+// head.1 weight grad (s = d_out [M,3], x = head-norm output) and the patch-embedding weight grad (s = the 5 inputs).
+__global__ void __launch_bounds__(256) outer_sum_kernel(const float* s, const float* x, float* partial, int64_t M, int NI,
+                                                        int C, int64_t rows_per_chunk) {
+    const int64_t lo = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t hi = lo + rows_per_chunk < M ? lo + rows_per_chunk : M;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t m = lo; m < hi; ++m) {
+            const float xv = x[m * C + c];
+            for (int i = 0; i < NI; ++i) acc[i] += s[m * NI + i] * xv;
+        }
+        for (int i = 0; i < NI; ++i) partial[((int64_t)blockIdx.x * NI + i) * C + c] = acc[i];
+    }
+}
+
+// head.1: out[row][i] = hn[row] . w[i] + b[i] (i < 3), one wave per row;  backward: dhn[row][c] = sum_i dout[row][i] w[i][c]
+__global__ void __launch_bounds__(256) head_forward_kernel(const float* hn, const float* w, const float* b, float* out,
+                                                           int64_t M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = hn[row * C + c];
+        s0 += v * w[c], s1 += v * w[C + c], s2 += v * w[2 * C + c];
+    }
+    s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
+    if (lane == 0) out[row * 3 + 0] = s0 + b[0], out[row * 3 + 1] = s1 + b[1], out[row * 3 + 2] = s2 + b[2];
+}
+
+__global__ void __launch_bounds__(256) head_backward_kernel(const float* dout, const float* w, float* dhn, int64_t M,
+                                                            int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * C) return;
+    const int64_t row = i / C;
+    const int c = (int)(i % C);
+    dhn[i] = (dout[row * 3] * w[c] + dout[row * 3 + 1] * w[C + c]) + dout[row * 3 + 2] * w[2 * C + c];
+}
+
+// in5[row] = (x2d[b,f,j,:], x3d[b,f,j,:]) - the input of Spatial_patch_to_embedding, kept for its weight gradient
+__global__ void __launch_bounds__(256) concat_inputs_kernel(const float* x2d, const float* x3d, float* in5, int64_t M) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    in5[row * 5 + 0] = x2d[row * 2], in5[row * 5 + 1] = x2d[row * 2 + 1];
+    in5[row * 5 + 2] = x3d[row * 3], in5[row * 5 + 3] = x3d[row * 3 + 1], in5[row * 5 + 4] = x3d[row * 3 + 2];
+}
+
+// sinusoid[b] = [sin(t_b w), cos(t_b w)]   (common/mixste.py:132-138)
+__global__ void __launch_bounds__(256) sinusoid_kernel(const int64_t* t, const float* freqs, float* out, int B, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x, half = C / 2;
+    if (i >= B * half) return;
+    const int b = i / half, k = i % half;
+    const float a = (float)t[b] * freqs[k];
+    out[b * C + k] = sinf(a);
+    out[b * C + half + k] = cosf(a);
+}
+
+// adds a small [NI][C] sum, transposed, into a [C][NI] weight gradient (Spatial_patch_to_embedding.weight is [C,5])
+__global__ void __launch_bounds__(256) transpose_small_kernel(const float* in, float* out, int NI, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NI * C) return;
+    out[(i % C) * NI + i / C] += in[i];
+}
+
+// D3DP.prepare_diffusion_concat + q_sample (common/diffusionpose.py:319-326,358-374): per sample b
+//   x = clamp(sqrt_acp[t_b] * (x0 * scale) + sqrt_1m_acp[t_b] * noise, +-1.1 scale) / scale, fp64 buffers, cast to fp32
+__global__ void __launch_bounds__(256) qsample_kernel(const float* x0, const float* noise, const int64_t* t,
+                                                      const double* sqrt_acp, const double* sqrt_1m_acp, double scale,
+                                                      float* out, int64_t per_sample, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t tb = t[i / per_sample];
+    const float xs = __fmul_rn(x0[i], (float)scale);  // fp32 tensor * python scalar stays fp32
+    double v = __dadd_rn(__dmul_rn(sqrt_acp[tb], (double)xs), __dmul_rn(sqrt_1m_acp[tb], (double)noise[i]));
+    const double lim = 1.1 * scale;
+    v = v < -lim ? -lim : (v > lim ? lim : v);
+    out[i] = (float)(v / scale);
+}
+
+}  // namespace pafuse

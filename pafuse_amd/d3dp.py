@@ -100,6 +100,7 @@ class D3DP(nn.Module):
         self.register_buffer("_flip_perm", perm, persistent=False)
         # hooks that do not change the reference call signature
         self.noise_fn = None           # callable(k, shape, device) -> draw k (tests inject recorded noise)
+        self.train_draw_fn = None      # callable(sample) -> (t [1] int64, noise [F,J,3]) (tests, training path)
         self.proposal_shard = None     # (lo, hi): this rank's slice of the hypothesis axis (pafuse_amd.parallel)
         self.aux_streams = None        # explicit list of torch.cuda.Stream the parts are spread over; None = two
         self.n_aux_streams = 2         # streams per device made on first use (0: everything on the current stream)
@@ -246,7 +247,48 @@ class D3DP(nn.Module):
         return self.ddim_sample(inputs_2d, inputs_3d, input_2d_flip=input_2d_flip, flip=True)
 
     def forward(self, input_2d, input_3d, input_2d_flip=None):
-        """eval: [B,T,P,F,J,3] (common/diffusionpose.py:337-344)."""
-        if self.is_train:
-            raise NotImplementedError("training forward/backward is a 'next' row (SURVEY.md section 8f n2)")
-        return self.ddim_sample(input_2d, input_3d, input_2d_flip=input_2d_flip, flip=self.flip)
+        """eval: [B,T,P,F,J,3] (common/diffusionpose.py:337-344); train: the parts' x0 predictions for the noised
+        target, [B,F,J,3], differentiable w.r.t. the parameters (:346-356)."""
+        if not self.is_train:
+            return self.ddim_sample(input_2d, input_3d, input_2d_flip=input_2d_flip, flip=self.flip)
+        x_poses, _noises, t = self.prepare_targets(input_3d)
+        return self.pred_parts(input_2d, x_poses, t.squeeze(-1))
+
+    # ------------------------------------------------------------------------------------------------ training
+    def prepare_targets(self, targets):
+        """common/diffusionpose.py:358-388: per sample one timestep and one noise draw (in that order, on the
+        device), then q_sample + clamp in the fp64 of the schedule buffers (pafuse_d3dp_qsample), cast to fp32."""
+        if not targets.is_cuda:
+            raise _lib.PafuseError("D3DP runs on the HIP device only (no CPU fallback)")
+        lib = _lib.load()
+        dev, B = targets.device, targets.shape[0]
+        ts, noises = [], []
+        for i in range(B):
+            if self.train_draw_fn is not None:
+                ti, ni = self.train_draw_fn(i)
+                ti, ni = ti.to(dev).long().reshape(1), ni.to(dev).float()
+            else:
+                ti = torch.randint(0, self.num_timesteps, (1,), device=dev).long()
+                ni = torch.randn(self.frames, self.num_kps, 3, device=dev)
+            ts.append(ti), noises.append(ni)
+        t, noise = torch.stack(ts), torch.stack(noises).contiguous()
+        x0 = targets.contiguous().float()
+        out = torch.empty_like(x0)
+        _lib.check(lib.pafuse_d3dp_qsample(x0.data_ptr(), noise.data_ptr(), t.data_ptr(),
+                                           self.sqrt_alphas_cumprod.data_ptr(),
+                                           self.sqrt_one_minus_alphas_cumprod.data_ptr(), float(self.scale),
+                                           out.data_ptr(), B, x0[0].numel(), torch.cuda.current_stream(dev).cuda_stream))
+        return out, noise, t
+
+    def split_data(self, input_2d, x_poses):
+        """common/diffusionpose.py:328-335"""
+        data_2d, data_3d = {}, {}
+        for part, idx in self.parts_joint_indices.items():
+            data_3d[part] = x_poses[..., idx, :]
+            data_2d[part] = input_2d[..., idx, :]
+        return data_2d, data_3d
+
+    def pred_parts(self, input_2d, x_poses, t):
+        """common/diffusionpose.py:163-172 (training caller: every part's MixSTE2 in train mode)."""
+        data_2d, data_3d = self.split_data(input_2d, x_poses)
+        return torch.cat([self.pose_estimator[p](data_2d[p], data_3d[p], t) for p in self.parts_joint_indices], dim=-2)

@@ -87,6 +87,7 @@ class MixSTE2(nn.Module):
         self.register_buffer("_freqs", sinusoid_frequencies(C_), persistent=False)
         self._wcache = None
         self._param_names = tuple(n for n, _ in self.named_parameters())
+        self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
 
     # ------------------------------------------------------------------------------------------- C structs
     def weights_struct(self):
@@ -104,12 +105,13 @@ class MixSTE2(nn.Module):
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, x_2d, x_3d, t):
-        """x_2d [B,F,J,2], x_3d [B,P,F,J,3], t [B] int64 -> [B,P,F,J,3]  (common/mixste.py:278-298, eval)."""
-        if self.is_train:
-            raise NotImplementedError("training forward/backward is a 'next' row (SURVEY.md section 8f n2)")
+        """eval: x_2d [B,F,J,2], x_3d [B,P,F,J,3], t [B] int64 -> [B,P,F,J,3]  (common/mixste.py:278-298);
+        train: x_3d [B,F,J,3] -> [B,F,J,3], differentiable w.r.t. the parameters (common/mixste.py:215-225)."""
         lib = _lib.load()
         if not x_3d.is_cuda:
             raise _lib.PafuseError("MixSTE2 runs on the HIP device only (no CPU fallback)")
+        if self.is_train:
+            return self._forward_train(x_2d, x_3d, t)
         B, P, F, J, _ = x_3d.shape
         assert (F, J) == (self.num_frame, self.num_joints) and x_2d.shape == (B, F, J, 2) and t.shape == (B,)
         x_2d = x_2d.contiguous().float()
@@ -123,6 +125,81 @@ class MixSTE2(nn.Module):
         _lib.check(lib.pafuse_mixste2_forward(C.byref(w), x_2d.data_ptr(), x_3d.data_ptr(), t.data_ptr(), B, P,
                                               out.data_ptr(), ws.data_ptr(), nbytes, stream))
         return out
+
+    # ------------------------------------------------------------------------------------------------ training
+    def drop_path_factors(self, B, device):
+        """DropPath factors (mask / keep) of one forward, [2*depth, 2, B*max(F,J)] or None, drawn as the reference's
+        blocks draw them: execution order STE0 (attn, mlp), TTE0, STE1, ...; one Bernoulli(keep) per sequence of the
+        block's batch axis ((b f) spatial, (b n) temporal); rate 0 is nn.Identity and draws nothing
+        (common/mixste.py:100,113-116,187; timm.layers.drop_path with scale_by_keep=True)."""
+        rates = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.block_depth)]
+        if not self.training or all(r <= 0.0 for r in rates):
+            return None
+        smax = B * max(self.num_frame, self.num_joints)
+        out = torch.ones(2 * self.block_depth, 2, smax, device=device, dtype=torch.float32)
+        for i, rate in enumerate(rates):
+            for k, nseq in ((2 * i, B * self.num_frame), (2 * i + 1, B * self.num_joints)):
+                for branch in range(2):
+                    if self.drop_fn is not None:
+                        m = self.drop_fn(k, branch, nseq, rate)
+                    elif rate > 0.0:
+                        keep = 1.0 - rate
+                        m = torch.empty((nseq, 1, 1), device=device, dtype=torch.float32).bernoulli_(keep)
+                        if keep > 0.0:
+                            m.div_(keep)
+                    else:
+                        m = None
+                    if m is not None:
+                        out[k, branch, :nseq] = m.reshape(nseq).to(device=device, dtype=torch.float32)
+        return out
+
+    def _forward_train(self, x_2d, x_3d, t):
+        B, F, J, _ = x_3d.shape
+        assert (F, J) == (self.num_frame, self.num_joints) and x_2d.shape == (B, F, J, 2) and t.shape == (B,)
+        drop = self.drop_path_factors(B, x_3d.device)
+        params = [attrgetter(n)(self) for n in self._param_names]
+        return _TrainFunction.apply(self, x_2d.contiguous().float(), x_3d.contiguous().float(), t.contiguous().long(),
+                                    drop, *params)
+
+
+class _TrainFunction(torch.autograd.Function):
+    """pafuse_mixste2_train_forward / _backward (include/pafuse_hip.h) as one autograd node: the forward leaves its
+    activations in a library-owned layout inside one byte tensor, the backward fills one gradient per parameter."""
+
+    @staticmethod
+    def forward(ctx, module, x_2d, x_3d, t, drop, *params):
+        lib = _lib.load()
+        w = module.weights_struct()
+        B, F, J, _ = x_3d.shape
+        nbytes = lib.pafuse_mixste2_train_bytes(C.byref(w), B)
+        if nbytes == 0:
+            raise _lib.PafuseError("pafuse_mixste2_train_bytes: unsupported configuration")
+        saved = torch.empty(nbytes, dtype=torch.uint8, device=x_3d.device)
+        out = torch.empty(B, F, J, 3, device=x_3d.device, dtype=torch.float32)
+        stream = torch.cuda.current_stream(x_3d.device).cuda_stream
+        _lib.check(lib.pafuse_mixste2_train_forward(C.byref(w), x_2d.data_ptr(), x_3d.data_ptr(), t.data_ptr(), B,
+                                                    drop.data_ptr() if drop is not None else None, out.data_ptr(),
+                                                    saved.data_ptr(), nbytes, stream))
+        ctx.module, ctx.saved, ctx.drop, ctx.B, ctx.nbytes = module, saved, drop, B, nbytes
+        ctx.keep = (x_2d, x_3d, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        module = ctx.module
+        w = module.weights_struct()
+        grads = {n: torch.zeros_like(attrgetter(n)(module)) for n in module._param_names}
+        gw = _lib.MixSTE2Weights()
+        fill_weights_struct(gw, grads.__getitem__, module._freqs, module.num_frame, module.num_joints,
+                            module.embed_dim, module.block_depth, module.num_heads, module.in_chans)
+        dout = dout.contiguous().float()
+        stream = torch.cuda.current_stream(dout.device).cuda_stream
+        _lib.check(lib.pafuse_mixste2_train_backward(C.byref(w), C.byref(gw), dout.data_ptr(), ctx.B,
+                                                     ctx.drop.data_ptr() if ctx.drop is not None else None,
+                                                     ctx.saved.data_ptr(), ctx.nbytes, stream))
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(grads[n] for n in module._param_names)
 
 
 BLOCK_PARAMS = (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),

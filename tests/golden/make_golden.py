@@ -31,16 +31,28 @@ REF = os.environ.get("PAFUSE_REFERENCE", "/root/reference")
 from tests.golden import golden_util as gu  # noqa: E402
 
 
+DROP_TAPE = []      # DropPath factors in the order the reference's blocks drew them
+
+
 # ------------------------------------------------------------------------------------------------- shims
 def install_shims():
-    class DropPath(torch.nn.Module):          # identity in eval; never exercised in train mode here
+    class DropPath(torch.nn.Module):
+        """timm.models.layers.DropPath is absent from this image (and unpinned by the reference): its published
+        algorithm (timm.layers.drop.drop_path, scale_by_keep=True).  The factors it draws are recorded in DROP_TAPE."""
+
         def __init__(self, p=0.0):
             super().__init__()
             self.p = p
 
         def forward(self, x):
-            assert not self.training or self.p == 0.0
-            return x
+            if self.p == 0.0 or not self.training:
+                return x
+            keep = 1 - self.p
+            mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+            if keep > 0.0:
+                mask.div_(keep)
+            DROP_TAPE.append(mask.reshape(-1).clone())
+            return x * mask
 
     def _mk(name, **attrs):
         m = types.ModuleType(name)
@@ -303,6 +315,86 @@ def g11_scale():
     save("g11_scale.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8), out=out)
 
 
+# ------------------------------------------------------------------------------------------------- G12
+def _grad_stats(g):
+    """compact pin of one gradient tensor: sum, L2 norm, first 8 entries"""
+    flat = g.reshape(-1).double()
+    head = torch.zeros(8, dtype=torch.float64)
+    head[:min(8, flat.numel())] = flat[:8]
+    return torch.cat([flat.sum()[None], flat.norm()[None], head])
+
+
+def g12_train_tiny():
+    """train-mode MixSTE2 (F=3, J=5, C=64, depth 2, DropPath 0.5): forward, DropPath factors as drawn, and the
+    gradient of every parameter for a seeded output gradient."""
+    from common.mixste import MixSTE2
+    torch.manual_seed(121)
+    m = MixSTE2(num_frame=3, num_joints=5, in_chans=5, embed_dim_ratio=64, depth=2, num_heads=8,
+                mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_path_rate=0.5, is_train=True).train()
+    with torch.no_grad():
+        m.Spatial_pos_embed.normal_(0, 0.2)
+        m.Temporal_pos_embed.normal_(0, 0.2)
+        for k, p in m.named_parameters():
+            if "norm" in k or k.startswith("head.0"):
+                p.add_(torch.randn_like(p) * 0.1)
+    g = torch.Generator().manual_seed(122)
+    x2d = torch.rand(4, 3, 5, 2, generator=g) * 2 - 1
+    x3d = torch.randn(4, 3, 5, 3, generator=g)
+    t = torch.tensor([999, 3, 500, 41])
+    dout = torch.randn(4, 3, 5, 3, generator=g)
+    DROP_TAPE.clear()
+    torch.manual_seed(123)
+    out = m(x2d, x3d, t)
+    out.backward(dout)
+    arrays = {"sd." + k: v for k, v in m.state_dict().items()}
+    arrays.update({"grad." + k: p.grad for k, p in m.named_parameters()})
+    arrays.update({f"drop.{i}": d for i, d in enumerate(DROP_TAPE)})
+    save("g12_train_tiny.npz", x2d=x2d, x3d=x3d, t=t, dout=dout, out=out.detach(), n_drop=torch.tensor(len(DROP_TAPE)),
+         **arrays)
+
+
+# ------------------------------------------------------------------------------------------------- G13
+def g13_d3dp_train():
+    """D3DP.forward in train mode at the real widths (depth 1 to keep the fixture small), B=2: the per-sample
+    (t, noise) draws, the noised poses, the prediction, the mpjpe loss and compact statistics of every gradient."""
+    from common.diffusionpose import D3DP
+    from common.loss import mpjpe
+    args = make_args()
+    args.model.dep = 1
+    m = D3DP(args, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, FakeDataset(), is_train=True)
+    m.device = "cpu"
+    m.train()
+    sd = gu.seeded_state_dict(m.state_dict(), seed=131)
+    m.load_state_dict(sd)
+    x2d, _ = gu.synthetic_inputs_2d(B=2)
+    target = gu.synthetic_target_3d(B=2)
+    g = torch.Generator().manual_seed(132)
+    ts = [torch.tensor([977]), torch.tensor([12])]
+    noises = [torch.randn(27, 134, 3, generator=g) for _ in range(2)]
+    real_randint, real_randn = torch.randint, torch.randn
+    it_t, it_n = iter(ts), iter(noises)
+    torch.randint = lambda *a, **k: next(it_t).clone()          # prepare_diffusion_concat asks for device='cuda'
+    torch.randn = lambda *a, **k: next(it_n).clone()
+    try:
+        x_poses, _, t = m.prepare_targets(target)
+    finally:
+        torch.randint, torch.randn = real_randint, real_randn
+    it_t, it_n = iter(ts), iter(noises)
+    torch.randint = lambda *a, **k: next(it_t).clone()
+    torch.randn = lambda *a, **k: next(it_n).clone()
+    DROP_TAPE.clear()
+    try:
+        pred = m(x2d, target)
+    finally:
+        torch.randint, torch.randn = real_randint, real_randn
+    loss = mpjpe(pred, target)
+    loss.backward()
+    stats = {"gstat." + k: _grad_stats(p.grad) for k, p in m.named_parameters()}
+    save("g13_d3dp_train.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8), t=torch.stack(ts),
+         noise=torch.stack(noises), x_poses=x_poses.float(), pred=pred.detach(), loss=loss.detach(),
+         n_drop=torch.tensor(len(DROP_TAPE)), **stats)
+
+
 # -------------------------------------------------------------------------------------------------- G9
 def g9_evaluate_accumulators():
     """the 14 per-step error vectors evaluate() accumulates (main_h3wb.py:327-362) on random part-centred inputs."""
@@ -370,9 +462,9 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
-                 g10=g10_clip_cutting, g11=g11_scale)
+                 g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train)
     for w in which:
         table[w]()

@@ -34,10 +34,10 @@ def mixste2_template(prefix, J, C, F=27, depth=8, in_chans=5):
     return t
 
 
-def d3dp_template(timesteps=1000):
+def d3dp_template(timesteps=1000, depth=8):
     """name -> tensor with the right shape/dtype; fp64 schedule buffers hold their real values."""
     from oracle.d3dp_oracle import schedule_buffers
     t = dict(schedule_buffers(timesteps))
     for part, C in gu.PART_WIDTH.items():
-        t.update(mixste2_template(f"pose_estimator.{part}.", len(gu.PART_JOINTS[part]), C))
+        t.update(mixste2_template(f"pose_estimator.{part}.", len(gu.PART_JOINTS[part]), C, depth=depth))
     return t

@@ -1,0 +1,150 @@
+"""GPU parity tests of the training path: train-mode MixSTE2 / D3DP forward and the
+gradient of every parameter, HIP kernels through the C ABI against the reference's autograd (golden G12, G13) and the
+oracle's autograd at other sizes.
+
+Tolerances: forward as in test_hip_parity (1e-5 pointwise); gradients are sums over 1e3-1e5 rows of fp32 products in
+a different (but fixed) order than ATen's, compared relative to the tensor's largest entry: 2e-4 * max|g|.
+"""
+import pytest
+import torch
+
+from oracle import d3dp_oracle as orc
+from tests.conftest import load_golden
+from tests.golden import golden_util as gu
+from tests.test_oracle_golden import _sub, drops_from_tape, grad_stats
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, want, what, rel=2e-4):
+    tol = rel * float(want.abs().max()) + 1e-7
+    err = float((got.cpu() - want).abs().max())
+    assert err <= tol, (what, err, tol)
+
+
+def _tiny(z, drop_rate=0.5):
+    import pafuse_amd
+    m = pafuse_amd.MixSTE2(num_frame=3, num_joints=5, in_chans=5, embed_dim_ratio=64, depth=2, num_heads=8,
+                           mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_path_rate=drop_rate, is_train=True)
+    m.load_state_dict(_sub(z, "sd."))
+    return m.to(DEV).train()
+
+
+def test_g12_train_tiny_golden():
+    """forward (with the DropPath factors the reference drew) and all 112 parameter gradients vs the reference."""
+    z = load_golden("g12_train_tiny.npz")
+    m = _tiny(z)
+    drops = drops_from_tape([z[f"drop.{i}"] for i in range(int(z["n_drop"]))], orc.drop_path_rates(0.5, 2))
+    m.drop_fn = lambda block, branch, nseq, rate: drops[block][branch]
+    out = m(z["x2d"].to(DEV), z["x3d"].to(DEV), z["t"].to(DEV))
+    assert torch.allclose(out.detach().cpu(), z["out"], rtol=0, atol=1e-5), (out.cpu() - z["out"]).abs().max()
+    out.backward(z["dout"].to(DEV))
+    ref = _sub(z, "grad.")
+    assert set(ref) == {n for n, _ in m.named_parameters()}
+    for n, p in m.named_parameters():
+        _close(p.grad, ref[n], n)
+
+
+def test_drop_path_draws_follow_the_reference_order():
+    """without a hook the module draws its own factors: nothing for rate-0 blocks, values in {0, 1/keep}, one per
+    sequence of the block's batch axis; eval() switches DropPath off."""
+    z = load_golden("g12_train_tiny.npz")
+    m = _tiny(z)
+    torch.manual_seed(3)
+    d = m.drop_path_factors(4, torch.device(DEV))
+    assert d.shape == (4, 2, 4 * 5)
+    assert torch.all(d[:2] == 1)                                          # dpr[0] = 0: nn.Identity
+    assert set(d[2, :, :12].unique().tolist()) <= {0.0, 2.0} and set(d[3].unique().tolist()) <= {0.0, 2.0}
+    assert torch.all(d[2, :, 12:] == 1)                                   # spatial blocks have B*F = 12 sequences
+    m.eval()
+    assert m.drop_path_factors(4, torch.device(DEV)) is None
+
+
+def test_g13_d3dp_train_golden():
+    """D3DP.forward in train mode at the real widths: q_sample bit-exact, prediction, loss, gradient statistics."""
+    from __graft_entry__ import make_model
+    z = load_golden("g13_d3dp_train.npz")
+    model, sd = make_model(1, 1, seed=131, is_train=True, depth=1)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    x2d, _ = gu.synthetic_inputs_2d(B=2)
+    target = gu.synthetic_target_3d(B=2)
+    model.train_draw_fn = lambda i: (z["t"][i], z["noise"][i])
+    x_poses, noise, t = model.prepare_targets(target.to(DEV))
+    assert torch.equal(x_poses.cpu(), z["x_poses"]) and torch.equal(t.cpu(), z["t"])
+    pred = model(x2d.to(DEV), target.to(DEV))
+    assert torch.allclose(pred.detach().cpu(), z["pred"], rtol=0, atol=1e-5), (pred.cpu() - z["pred"]).abs().max()
+    loss = orc.mpjpe(pred, target.to(DEV))                               # the caller's loss (main_h3wb.py:851)
+    assert torch.allclose(loss.detach().cpu(), z["loss"], rtol=1e-5, atol=0)
+    loss.backward()
+    ref = _sub(z, "gstat.")
+    params = dict(model.named_parameters())
+    assert set(ref) == set(params)
+    for k, want in ref.items():
+        got = grad_stats(params[k].grad.cpu())
+        scale = float(want[1]) + 1e-12
+        assert abs(float(got[1] - want[1])) <= 2e-4 * scale, (k, got[1], want[1])
+        assert torch.allclose(got[2:], want[2:], rtol=2e-3, atol=2e-4 * scale), k
+
+
+@pytest.mark.parametrize("part,B", [("body", 3), ("face", 2), ("hands", 2)])
+def test_train_gradients_vs_oracle_real_widths(part, B):
+    """one part at its real width, depth 2, DropPath active with seeded factors, against torch autograd over the
+    oracle on the CPU."""
+    import pafuse_amd
+    J, C = len(gu.PART_JOINTS[part]), gu.PART_WIDTH[part]
+    m = pafuse_amd.MixSTE2(num_frame=27, num_joints=J, in_chans=5, embed_dim_ratio=C, depth=2, num_heads=8,
+                           drop_path_rate=0.3, is_train=True)
+    sd = {k: gu.seeded_tensor(k, v.shape, 77) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(78)
+    drops = []
+    for r in orc.drop_path_rates(0.3, 2):
+        for nseq in (B * 27, B * J):
+            drops.append(tuple((torch.rand(nseq, generator=g) < 1 - r).float() / (1 - r) if r > 0 else None
+                               for _ in range(2)))
+    m.drop_fn = lambda block, branch, nseq, rate: drops[block][branch]
+    x2d = torch.rand(B, 27, J, 2, generator=g) * 2 - 1
+    x3d = torch.randn(B, 27, J, 3, generator=g)
+    t = torch.tensor([999, 250, 3][:B])
+    dout = torch.randn(B, 27, J, 3, generator=g)
+    out = m(x2d.to(DEV), x3d.to(DEV), t.to(DEV))
+    out.backward(dout.to(DEV))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = orc.mixste2_train(leaves, "", x2d, x3d, t, depth=2, heads=8, drop=drops)
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=0, atol=1e-5), (out.cpu() - ref).abs().max()
+    ref.backward(dout)
+    for n, p in m.named_parameters():
+        _close(p.grad, leaves[n].grad, n)
+
+
+def test_train_backward_is_bit_reproducible():
+    z = load_golden("g12_train_tiny.npz")
+    grads = []
+    for _ in range(2):
+        m = _tiny(z, drop_rate=0.0)
+        out = m(z["x2d"].to(DEV), z["x3d"].to(DEV), z["t"].to(DEV))
+        out.backward(z["dout"].to(DEV))
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    assert all(torch.equal(grads[0][n], grads[1][n]) for n in grads[0])
+
+
+def test_optimizer_step_reduces_the_loss():
+    """a few AdamW steps (lr 6e-5 * 10, the caller's optimiser: main_h3wb.py:761) on one batch lower the mpjpe."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(1, 1, seed=141, is_train=True, depth=1)
+    x2d, _ = gu.synthetic_inputs_2d(B=2)
+    target = gu.synthetic_target_3d(B=2).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    draws = [(torch.tensor([500]), torch.randn(27, 134, 3, generator=g)) for _ in range(2)]
+    model.train_draw_fn = lambda i: draws[i]
+    opt = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.1)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        loss = orc.mpjpe(model(x2d.to(DEV), target), target)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses

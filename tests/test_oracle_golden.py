@@ -146,3 +146,69 @@ def test_g11_scale():
     noises = [n * 1.5 for n in gu.synthetic_noises(B=1, P=2, n=2, seed=12)]
     out = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f, scale=2.0)
     assert torch.allclose(out, z["out"], rtol=0, atol=2e-5), (out - z["out"]).abs().max()
+
+
+# ------------------------------------------------------------------------------------------------ training (n2)
+def drops_from_tape(tape, rates):
+    """[(attn, mlp)] per block in execution order from the factors in the order the reference drew them."""
+    tape, out = list(tape), []
+    for r in rates:
+        for _ in range(2):                              # STE_i then TTE_i share dpr[i]
+            out.append((tape.pop(0), tape.pop(0)) if r > 0 else (None, None))
+    assert not tape
+    return out
+
+
+def grad_stats(g):
+    flat = g.reshape(-1).double()
+    head = torch.zeros(8, dtype=torch.float64)
+    head[:min(8, flat.numel())] = flat[:8]
+    return torch.cat([flat.sum()[None], flat.norm()[None], head])
+
+
+def test_g12_train_mode_forward_and_gradients():
+    """train-mode MixSTE2 with DropPath: forward and every parameter gradient of the oracle (torch autograd over the
+    functional restatement) against the reference's."""
+    z = load_golden("g12_train_tiny.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in _sub(z, "sd.").items()}
+    rates = orc.drop_path_rates(0.5, 2)
+    assert rates == [0.0, 0.5]
+    drops = drops_from_tape([z[f"drop.{i}"] for i in range(int(z["n_drop"]))], rates)
+    out = orc.mixste2_train(sd, "", z["x2d"], z["x3d"], z["t"], depth=2, heads=8, drop=drops)
+    assert torch.allclose(out, z["out"], rtol=0, atol=2e-6), (out - z["out"]).abs().max()
+    out.backward(z["dout"])
+    ref = _sub(z, "grad.")
+    assert set(ref) == set(sd)
+    for k, g in ref.items():
+        tol = 1e-5 * float(g.abs().max()) + 1e-7
+        assert torch.allclose(sd[k].grad, g, rtol=1e-4, atol=tol), (k, (sd[k].grad - g).abs().max())
+    # the factors themselves follow timm's rule: 0 or 1/keep
+    for i in range(int(z["n_drop"])):
+        assert set(z[f"drop.{i}"].tolist()) <= {0.0, 2.0}
+    torch.manual_seed(5)
+    drawn = orc.draw_drop_path(0.5, 2, B=4, Fr=3, J=5, like=torch.zeros(1))
+    assert [None if a is None else tuple(a.shape) for a, _ in drawn] == [None, None, (12,), (20,)]
+
+
+def test_g13_d3dp_train_forward_loss_and_gradient_statistics():
+    z = load_golden("g13_d3dp_train.npz")
+    from tests.golden.state_template import d3dp_template
+    sd = gu.seeded_state_dict(d3dp_template(depth=1), seed=131)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    x2d, _ = gu.synthetic_inputs_2d(B=2)
+    target = gu.synthetic_target_3d(B=2)
+    t = z["t"].reshape(-1)
+    x_poses = orc.q_sample_targets(sd, target, t, z["noise"], scale=1.0)
+    assert torch.equal(x_poses, z["x_poses"])
+    assert int(z["n_drop"]) == 0 and orc.drop_path_rates(0.1, 1) == [0.0]     # depth 1: linspace(0, 0.1, 1) = [0]
+    leaves = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    pred = orc.train_forward(leaves, x2d, x_poses, t, depth=1, heads=8)
+    assert torch.allclose(pred, z["pred"], rtol=0, atol=2e-6), (pred - z["pred"]).abs().max()
+    loss = orc.mpjpe(pred, target)
+    assert torch.allclose(loss, z["loss"], rtol=1e-6, atol=0)
+    loss.backward()
+    for k, ref in _sub(z, "gstat.").items():
+        got = grad_stats(leaves[k].grad)
+        scale = float(ref[1]) + 1e-12                     # the gradient's L2 norm
+        assert abs(float(got[1] - ref[1])) <= 1e-4 * scale, (k, got[1], ref[1])
+        assert torch.allclose(got[2:], ref[2:], rtol=1e-3, atol=1e-5 * scale), k
