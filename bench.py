@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
     ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
+    ap.add_argument("--train", action="store_true",
+                    help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
+                         "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
     args = ap.parse_args()
 
     import torch
@@ -63,6 +66,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     ge.build()
+    if args.train:
+        return train_bench(args, rank, local_rank, world, dev)
     from pafuse_amd import _lib
     from pafuse_amd.parallel import ShardedSampler
     import ctypes as C
@@ -193,6 +198,73 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()      # ranks > 0 wait here while rank 0 runs the roofline and CPU-baseline legs
+        dist.destroy_process_group()
+
+
+def train_bench(args, rank, local_rank, world, dev):
+    """One training step = D3DP.forward in train mode (per-sample q_sample targets, three per-part denoisers with
+    DropPath), the caller's mpjpe loss, backward through the HIP kernels, AdamW (lr 6e-5, wd 0.1, main_h3wb.py:761).
+    N > 1: torch DistributedDataParallel - one RCCL all-reduce of the 35 M fp32 gradients, bucketed and overlapped
+    with the backward pass.  Weak scaling: `--batch` clips per GPU."""
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from tests.golden import golden_util as gu
+
+    B = args.batch if args.batch > 1 else 37
+    model, _ = ge.make_model(1, 1, seed=51, device=dev, is_train=True)
+    model.n_aux_streams = args.streams
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    x2d, _ = gu.synthetic_inputs_2d(B=B, seed=1234 + rank)
+    target = gu.synthetic_target_3d(B=B, seed=1235 + rank).to(dev)
+    x2d = x2d.to(dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=6e-5, weight_decay=0.1)
+    torch.manual_seed(4321 + rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = net(x2d, target)
+        loss = torch.mean(torch.norm(pred - target, dim=-1))          # common/loss.py:27-34 (mpjpe)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    assert bool(torch.isfinite(loss.detach()))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    sec = elapsed / args.steps
+    tflops = B * 3 * GFLOP_PER_HYP_PASS / 1e3 / sec                  # per GPU: forward + 2x backward
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training clips/sec (H3WB 27x134 clips, fwd+bwd+AdamW)", "value": round(B * world / sec, 3),
+            "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"D3DP train step, B={B} clips/GPU, per-part MixSTE2 384/224/256 ch depth 8, "
+                                   f"DropPath 0.1, AdamW", "B_per_gpu": B,
+                       "parallelism": f"DDP x{world} (RCCL all-reduce of 35 M fp32 grads)" if world > 1 else "single GPU",
+                       "weights": "seeded synthetic", "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
+            "roofline_loop": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                              "note": "per GPU: B*3*69.3847 GFLOP (forward + 2x backward) / step time"}}), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -171,14 +171,34 @@ __global__ void __launch_bounds__(256) ln_backward_kernel(const LnBackwardParams
     }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s partial[s * stride + i], s ascending (fixed order)
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partial, float* out, int n, int nparts,
-                                                              int64_t stride, int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// out[i] = (accumulate ? out[i] : 0) + sum_s partial[s * stride + i], in a fixed order: a workgroup owns 256 / G
+// columns; its G lane groups each sum the parts s = g, g + G, ... in ascending order, then the G group sums are added
+// in ascending g.  G = 1 for wide outputs (plenty of columns to fill the chip), 16 for narrow ones with many parts
+// (LayerNorm / bias gradients: a few hundred columns, up to ~1000 parts).  Columns >= split go to out2[i - split]
+// (LayerNorm: dw and db partials lie side by side but their gradients are separate tensors).
+template <int G>
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partial, float* out, float* out2, int split,
+                                                              int n, int nparts, int64_t stride, int accumulate) {
+    constexpr int COLS = 256 / G;
+    __shared__ float red[G][COLS];
+    const int col = threadIdx.x % COLS, g = threadIdx.x / COLS;
+    const int i = blockIdx.x * COLS + col;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += partial[(int64_t)k * stride + i];
-    out[i] = accumulate ? out[i] + s : s;
+    if (i < n)
+        for (int k = g; k < nparts; k += G) s += partial[(int64_t)k * stride + i];
+    float* dst = i < split ? out + i : out2 + (i - split);
+    if (G == 1) {
+        if (i < n) *dst = accumulate ? *dst + s : s;
+        return;
+    }
+    red[g][col] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = red[0][col];
+#pragma unroll
+        for (int k = 1; k < G; ++k) t += red[k][col];
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -334,40 +354,65 @@ struct AttnBackwardParams {
     float scale;
 };
 
+// LDS row pitch of the [L][d] operands: a multiple of 4 floats (float4 reads) whose count of 16-byte granules is odd,
+// so that lanes reading different rows at the same column spread over the banks (36 for d = 28/32, 52 for d = 48)
+__host__ __device__ inline int attn_bwd_pitch(int d) {
+    int ld = d + 4;
+    if (((ld / 4) & 1) == 0) ld += 4;
+    return ld;
+}
+
 __global__ void __launch_bounds__(256) attn_backward_kernel(const AttnBackwardParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = p.L, d = p.d, ld = d + 1, lp = L + 1;
-    float* Q = smem;
-    float* Kk = Q + L * ld;
-    float* V = Kk + L * ld;
-    float* G = V + L * ld;  // dO
-    float* P = G + L * ld;  // [L][L+1]
-    float* D = P + L * lp;  // dP, then dS
+    const int L = p.L, d = p.d, d4 = d / 4, ld = attn_bwd_pitch(d), L4 = (L + 3) / 4 * 4, lp = L4 + 1;
+    float* Q = smem;  // [L4][ld] each, rows >= L zero
+    float* Kk = Q + L4 * ld;
+    float* V = Kk + L4 * ld;
+    float* G = V + L4 * ld;   // dO
+    float* P = G + L4 * ld;   // [L][lp]
+    float* D = P + L * lp;    // dP, then dS
     const int tid = threadIdx.x;
     const int64_t item = blockIdx.x;
     const int64_t seq = item / p.heads;
     const int head = (int)(item % p.heads);
     const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
     const int C3 = 3 * p.C;
-    for (int i = tid; i < L * d; i += 256) {
-        const int t = i / d, c = i % d;
-        const int64_t row = base + (int64_t)t * p.tok_stride;
-        const float* src = p.qkv + row * C3 + head * d + c;
-        Q[t * ld + c] = src[0];
-        Kk[t * ld + c] = src[p.C];
-        V[t * ld + c] = src[2 * p.C];
-        G[t * ld + c] = p.d_o[row * p.C + head * d + c];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < L4 * d4; i += 256) {
+        const int t = i / d4, c = 4 * (i % d4);
+        f32x4 q = zero, k = zero, v = zero, g = zero;
+        if (t < L) {
+            const int64_t row = base + (int64_t)t * p.tok_stride;
+            const float* src = p.qkv + row * C3 + head * d + c;
+            q = *reinterpret_cast<const f32x4*>(src);
+            k = *reinterpret_cast<const f32x4*>(src + p.C);
+            v = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            g = *reinterpret_cast<const f32x4*>(p.d_o + row * p.C + head * d + c);
+        }
+        *reinterpret_cast<f32x4*>(Q + t * ld + c) = q;
+        *reinterpret_cast<f32x4*>(Kk + t * ld + c) = k;
+        *reinterpret_cast<f32x4*>(V + t * ld + c) = v;
+        *reinterpret_cast<f32x4*>(G + t * ld + c) = g;
     }
     __syncthreads();
-    for (int i = tid; i < L * L; i += 256) {
-        const int a = i / L, b = i % L;
-        float s = 0.f, g = 0.f;
-        for (int c = 0; c < d; ++c) {
-            s += Q[a * ld + c] * Kk[b * ld + c];
-            g += G[a * ld + c] * V[b * ld + c];
+    // S = scale q k^T and dP = dO v^T: one query row x four keys per thread
+    for (int i = tid; i < L * (L4 / 4); i += 256) {
+        const int a = i / (L4 / 4), b0 = 4 * (i % (L4 / 4));
+        float sv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < d; c += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(Q + a * ld + c);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(G + a * ld + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 k = *reinterpret_cast<const f32x4*>(Kk + (b0 + j) * ld + c);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(V + (b0 + j) * ld + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[j] += q[e] * k[e], gv[j] += g[e] * v[e];
+            }
         }
-        P[a * lp + b] = s * p.scale;
-        D[a * lp + b] = g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (b0 + j < L) P[a * lp + b0 + j] = sv[j] * p.scale, D[a * lp + b0 + j] = gv[j];
     }
     __syncthreads();
     if (tid < L) {  // softmax of row tid, then dS in place
@@ -389,19 +434,23 @@ __global__ void __launch_bounds__(256) attn_backward_kernel(const AttnBackwardPa
         for (int b = 0; b < L; ++b) D[tid * lp + b] = P[tid * lp + b] * (D[tid * lp + b] - dot) * p.scale;
     }
     __syncthreads();
-    for (int i = tid; i < L * d; i += 256) {
-        const int t = i / d, c = i % d;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
+    // dq = dS k, dk = dS^T q, dv = P^T dO: one token x four channels per thread
+    for (int i = tid; i < L * d4; i += 256) {
+        const int t = i / d4, c = 4 * (i % d4);
+        f32x4 dq = zero, dk = zero, dv = zero;
         for (int b = 0; b < L; ++b) {
-            dq += D[t * lp + b] * Kk[b * ld + c];
-            dk += D[b * lp + t] * Q[b * ld + c];
-            dv += P[b * lp + t] * G[b * ld + c];
+            const float s_tb = D[t * lp + b], s_bt = D[b * lp + t], p_bt = P[b * lp + t];
+            const f32x4 k = *reinterpret_cast<const f32x4*>(Kk + b * ld + c);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(Q + b * ld + c);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(G + b * ld + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dq[e] += s_tb * k[e], dk[e] += s_bt * q[e], dv[e] += p_bt * g[e];
         }
         const int64_t row = base + (int64_t)t * p.tok_stride;
         float* dst = p.dqkv + row * C3 + head * d + c;
-        dst[0] = dq;
-        dst[p.C] = dk;
-        dst[2 * p.C] = dv;
+        *reinterpret_cast<f32x4*>(dst) = dq;
+        *reinterpret_cast<f32x4*>(dst + p.C) = dk;
+        *reinterpret_cast<f32x4*>(dst + 2 * p.C) = dv;
     }
 }
 

@@ -291,4 +291,23 @@ class D3DP(nn.Module):
     def pred_parts(self, input_2d, x_poses, t):
         """common/diffusionpose.py:163-172 (training caller: every part's MixSTE2 in train mode)."""
         data_2d, data_3d = self.split_data(input_2d, x_poses)
-        return torch.cat([self.pose_estimator[p](data_2d[p], data_3d[p], t) for p in self.parts_joint_indices], dim=-2)
+        dev = x_poses.device
+        cur = torch.cuda.current_stream(dev)
+        lanes = [cur] + self._aux_for(dev)
+        outs = []
+        # the parts are independent: each runs its forward (and, because autograd replays a node on the stream of its
+        # forward, its backward) on its own stream, so one part's launch gaps and kernel tails are filled by the others
+        for i, p in enumerate(self.parts_joint_indices):
+            s = lanes[i % len(lanes)]
+            x2, x3 = data_2d[p].contiguous(), data_3d[p].contiguous()
+            if s is not cur:
+                s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                out = self.pose_estimator[p](x2, x3, t)
+            if s is not cur:
+                for tensor in (x2, x3, t, out):
+                    tensor.record_stream(s)
+            outs.append(out)
+        for s in lanes[1:]:
+            cur.wait_stream(s)
+        return torch.cat(outs, dim=-2)

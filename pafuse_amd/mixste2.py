@@ -189,7 +189,13 @@ class _TrainFunction(torch.autograd.Function):
         lib = _lib.load()
         module = ctx.module
         w = module.weights_struct()
-        grads = {n: torch.zeros_like(attrgetter(n)(module)) for n in module._param_names}
+        shapes = [attrgetter(n)(module).shape for n in module._param_names]
+        sizes = [(s.numel() + 3) // 4 * 4 for s in shapes]               # keep every gradient 16-byte aligned
+        flat = torch.zeros(sum(sizes), device=dout.device, dtype=torch.float32)    # one fill instead of 208
+        grads, at = {}, 0
+        for n, shape, size in zip(module._param_names, shapes, sizes):
+            grads[n] = flat[at:at + shape.numel()].view(shape)
+            at += size
         gw = _lib.MixSTE2Weights()
         fill_weights_struct(gw, grads.__getitem__, module._freqs, module.num_frame, module.num_joints,
                             module.embed_dim, module.block_depth, module.num_heads, module.in_chans)

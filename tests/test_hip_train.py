@@ -148,3 +148,31 @@ def test_optimizer_step_reduces_the_loss():
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
+
+
+def test_ddp_wrapper_produces_the_same_gradients():
+    """torch DistributedDataParallel over RCCL (world size 1 on this box) around the train-mode module: the gradient
+    hooks fire for every parameter of the custom autograd node and the averaged gradients equal the plain ones."""
+    import os
+    import torch.distributed as dist
+    from __graft_entry__ import make_model
+    model, _ = make_model(1, 1, seed=151, is_train=True, depth=1)
+    x2d, _ = gu.synthetic_inputs_2d(B=2)
+    target = gu.synthetic_target_3d(B=2).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    draws = [(torch.tensor([300]), torch.randn(27, 134, 3, generator=g)) for _ in range(2)]
+    model.train_draw_fn = lambda i: draws[i]
+    orc.mpjpe(model(x2d.to(DEV), target), target).backward()
+    plain = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+        orc.mpjpe(ddp(x2d.to(DEV), target), target).backward()
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            assert p.grad is not None and torch.equal(p.grad, plain[n]), n
+    finally:
+        dist.destroy_process_group()
