@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) train_row_kernel(const TrainRowParams p) 
 //   dx = rstd * (g - mean(g) - xh * mean(g * xh)),  dw = sum_rows dy * xh,  db = sum_rows dy.
 // dx_out = add + dx (add may be null: the residual gradient that bypasses the norm); out_scaled = drop[seq] * dx_out
 // (the gradient entering the DropPath-scaled branch below).  A wave walks LNB_ROWS_PER_WAVE rows and keeps its slice of
-// dw/db in registers; the four waves of a workgroup combine through LDS into partial[block][2][C].
+// dw/db (and the column sums of out_scaled) in registers; the four waves of a workgroup combine through LDS into
+// partial[block][3][C].
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int LNB_ROWS_PER_WAVE = 16;
 constexpr int LNB_ROWS_PER_BLOCK = 4 * LNB_ROWS_PER_WAVE;
@@ -97,19 +98,19 @@ struct LnBackwardParams {
     const float* drop;  // [nseq] or null
     SeqMap map;
     float* out_scaled;  // [M,C] or null
-    float* partial;     // [blocks][2][C]
+    float* partial;     // [blocks][3][C]: dw, db, column sums of out_scaled (= bias gradient of the branch's last Linear)
     int64_t M;
     int C;
 };
 
 __global__ void __launch_bounds__(256) ln_backward_kernel(const LnBackwardParams p) {
-    __shared__ float red[4][2][64 * LN_MAX_PER_LANE];
+    __shared__ float red[4][3][64 * LN_MAX_PER_LANE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C = p.C;
     const float invC = 1.0f / (float)C;
-    float dw[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE], wv[LN_MAX_PER_LANE];
+    float dw[LN_MAX_PER_LANE], db[LN_MAX_PER_LANE], ds[LN_MAX_PER_LANE], wv[LN_MAX_PER_LANE];
 #pragma unroll
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        dw[i] = db[i] = 0.f;
+        dw[i] = db[i] = ds[i] = 0.f;
         wv[i] = (lane + 64 * i < C) ? p.w[lane + 64 * i] : 0.f;
     }
     const int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS_PER_BLOCK + wave * LNB_ROWS_PER_WAVE;
@@ -154,7 +155,10 @@ __global__ void __launch_bounds__(256) ln_backward_kernel(const LnBackwardParams
                 float v = rstd * (dy[i] * wv[i] - c1 - x[i] * c2);
                 if (p.add) v += p.add[row * C + c];
                 p.dx[row * C + c] = v;
-                if (p.out_scaled) p.out_scaled[row * C + c] = d * v;
+                if (p.out_scaled) {
+                    p.out_scaled[row * C + c] = d * v;
+                    ds[i] += d * v;
+                }
             }
         }
     }
@@ -162,11 +166,12 @@ __global__ void __launch_bounds__(256) ln_backward_kernel(const LnBackwardParams
     for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
         red[wave][0][lane + 64 * i] = dw[i];
         red[wave][1][lane + 64 * i] = db[i];
+        red[wave][2][lane + 64 * i] = ds[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    for (int i = threadIdx.x; i < 3 * C; i += 256) {
         const int which = i / C, c = i % C;
-        p.partial[((int64_t)blockIdx.x * 2 + which) * C + c] =
+        p.partial[((int64_t)blockIdx.x * 3 + which) * C + c] =
             ((red[0][which][c] + red[1][which][c]) + red[2][which][c]) + red[3][which][c];
     }
 }
@@ -213,19 +218,30 @@ __global__ void __launch_bounds__(256) gelu_forward_kernel(const float* u, float
     reinterpret_cast<f32x4*>(h)[i] = v;
 }
 
-__global__ void __launch_bounds__(256) gelu_backward_kernel(const float* u, const float* dh, float* du, int64_t n4) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const f32x4 uv = reinterpret_cast<const f32x4*>(u)[i], g = reinterpret_cast<const f32x4*>(dh)[i];
-    f32x4 o;
+// du = dh * gelu'(u) for the rows of one chunk, and the chunk's column sums of du (= partial bias gradient of fc1):
+// thread q owns the column quad q of every row of the chunk, so the sums stay in registers
+__global__ void __launch_bounds__(256) gelu_backward_kernel(const float* u, const float* dh, float* du, float* partial,
+                                                            int64_t M, int N, int64_t rows_per_chunk) {
+    const int64_t lo = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t hi = lo + rows_per_chunk < M ? lo + rows_per_chunk : M;
+    for (int q = threadIdx.x; q < N / 4; q += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t m = lo; m < hi; ++m) {
+            const f32x4 uv = *reinterpret_cast<const f32x4*>(u + m * N + 4 * q);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dh + m * N + 4 * q);
+            f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = uv[e];
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-        o[e] = g[e] * (cdf + x * pdf);
+            for (int e = 0; e < 4; ++e) {
+                const float x = uv[e];
+                const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+                const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+                o[e] = g[e] * (cdf + x * pdf);
+                acc[e] += o[e];
+            }
+            *reinterpret_cast<f32x4*>(du + m * N + 4 * q) = o;
+        }
+        *reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * N + 4 * q) = acc;
     }
-    reinterpret_cast<f32x4*>(du)[i] = o;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
