@@ -11,7 +11,9 @@ from types import SimpleNamespace
 # values of the reference configuration
 DEFAULTS = {
     "general": {"part_based_model": True, "evaluate": "best_epoch.bin", "checkpoint": ""},
-    "data": {"dataset": "h3wb", "num_kps": 134, "merge_hands": True},
+    "data": {"dataset": "h3wb", "num_kps": 134, "merge_hands": True, "subjects_train": "S1,S5,S6,S7",
+             "subjects_test": "S8", "actions": "*"},
+    "experiment": {"downsample": 1, "gpu": "0"},
     "model": {"diff_model": "MixSTE2", "number_of_frames": 27, "stride": 27, "batch_size": 1024,
               "test_time_augmentation": True, "input_size": 5, "dep": 8, "cs": 288},
     "ft2d": {"scale": 1.0, "timestep": 1000, "sampling_timesteps": 5, "num_proposals": 10, "debug": False, "p2": False},

@@ -449,6 +449,84 @@ def g10_clip_cutting():
     save("g10_clips.npz", **arrays)
 
 
+# ------------------------------------------------------------------------------------------------- G14
+def write_synthetic_h3wb(dirname, seed=141):
+    """A tiny dataset with the H3WB npz schema the reference loader expects (common/h3wb_dataset.py:18-26,124-133):
+    2 training subjects + the S8 test file, one or two actions, 4 cameras, 133 keypoints, a few frames."""
+    rng = np.random.default_rng(seed)
+    cams = ["54138969", "55011271", "58860488", "60457274"]
+    meta = {"body": list(range(0, 17)), "left_foot": [17, 18, 19], "right_foot": [20, 21, 22],
+            "face": list(range(23, 91)), "left_hand": list(range(91, 112)), "right_hand": list(range(112, 133)),
+            # 0-based sides; keypoint 0 listed on both sides exercises the duplicate filter (h3wb_dataset.py:30-38)
+            "left_side": [0] + [j for j in (list(range(1, 16, 2)) + [17, 18, 19] + list(range(91, 112)))],
+            "right_side": [0] + [j for j in (list(range(2, 17, 2)) + [20, 21, 22] + list(range(112, 133)))]}
+
+    def action(n):
+        rec = {"global_3d": rng.normal(0, 500, (n, 133, 3)).astype(np.float32), "frame_id": np.arange(n)}
+        for c in cams:
+            rec[c] = {"sample_id": np.arange(n),
+                      "camera_3d": (rng.normal(0, 400, (n, 133, 3)) + [0, 0, 4000]).astype(np.float32),
+                      "pose_2d": rng.uniform(0, 1000, (n, 133, 2)).astype(np.float32)}
+        return rec
+
+    train = {"S1": {"Directions": action(8), "Walking 1": action(5)}, "S5": {"Directions": action(7)}}
+    test = {"S8": {"Directions": action(6)}}
+    for s in ("S1", "S5", "S8"):
+        meta[s] = {c: {"id": c, "subject": s} for c in cams}
+    os.makedirs(dirname, exist_ok=True)
+    np.savez_compressed(os.path.join(dirname, "train_h3wb.npz"), metadata=np.array(meta, dtype=object),
+                        train_data=np.array(train, dtype=object))
+    np.savez_compressed(os.path.join(dirname, "task1_test_3d.npz"), data=np.array(test, dtype=object))
+
+
+def g14_h3wb_loader():
+    """The reference's Human3WBDataset + the data preparation and fetch() of main_h3wb.py:57-119,621-648 on the synthetic
+    H3WB files of tests/golden/h3wb_synth/ (written here too)."""
+    import ast
+    from common.h3wb_dataset import Human3WBDataset
+    from common.camera import normalize_screen_coordinates
+    d = os.path.join(HERE, "h3wb_synth")
+    write_synthetic_h3wb(d)
+    ds = Human3WBDataset(os.path.join(d, "train_h3wb.npz"))
+    for subject in ds.subjects():                                   # main_h3wb.py:621-648
+        for act in ds[subject].keys():
+            anim = ds[subject][act]
+            anim["positions_3d"] = [p / 1000. for p in anim["positions_3d"]]
+    keypoints = {}
+    for subject in ds.subjects():
+        keypoints[subject] = {}
+        for act in ds[subject].keys():
+            keypoints[subject][act] = []
+            for cam_idx, kps in enumerate(ds[subject][act]["pose_2d"]):
+                cam = ds.cameras()[subject][cam_idx]
+                kps[..., :2] = normalize_screen_coordinates(kps[..., :2], w=cam["res_w"], h=cam["res_h"])
+                keypoints[subject][act].append(kps)
+    src = open(os.path.join(REF, "main_h3wb.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "fetch")
+    ns = {}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "fetch", "exec"), ns)
+    arrays = {"joints_left": torch.tensor(ds.skeleton().joints_left()),
+              "joints_right": torch.tensor(ds.skeleton().joints_right()),
+              "kps_left": torch.tensor(ds.keypoints_metadata["keypoints_symmetry"][0]),
+              "parents": torch.tensor(np.asarray(ds.skeleton().parents())),
+              "num_kps": torch.tensor(ds.num_kps)}
+    for part, idx in ds.parts_joint_indices.items():
+        arrays["part." + part] = torch.tensor(idx)
+    for subject in ("S1", "S8"):
+        for i, cam in enumerate(ds.cameras()[subject]):
+            arrays[f"cam.{subject}.{i}.intrinsic"] = torch.from_numpy(cam["intrinsic"])
+            arrays[f"cam.{subject}.{i}.translation"] = torch.from_numpy(cam["translation"])
+    arrays["positions.S1.Walking 1"] = torch.from_numpy(ds["S1"]["Walking 1"]["positions"])
+    for tag, (subjects, stride, filt) in {"test": (["S8"], 1, None), "train2": (["S1", "S5"], 2, ["Dir"])}.items():
+        cams, p3, p2 = ns["fetch"](subjects, keypoints, ds, stride, filt)
+        arrays[f"fetch.{tag}.n"] = torch.tensor(len(p2))
+        for i in range(len(p2)):
+            arrays[f"fetch.{tag}.{i}.cam"] = torch.from_numpy(cams[i])
+            arrays[f"fetch.{tag}.{i}.p3"] = torch.from_numpy(p3[i])
+            arrays[f"fetch.{tag}.{i}.p2"] = torch.from_numpy(p2[i])
+    save("g14_h3wb_loader.npz", **arrays)
+
+
 # -------------------------------------------------------------------------------------------------- G8
 def g8_default_init():
     """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
@@ -462,9 +540,10 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
-                 g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train)
+                 g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train,
+                 g14=g14_h3wb_loader)
     for w in which:
         table[w]()

@@ -332,6 +332,39 @@ def test_evaluate_sequence_vs_oracle():
         assert torch.allclose(got, want[k], rtol=2e-6, atol=0), (k, got, want[k])
 
 
+def test_h3wb_files_to_protocol_numbers():
+    """the whole evaluate() flow from files: synthetic H3WB npz -> loader -> fetch -> every test video through the HIP
+    loop -> frame-weighted protocol means, against the oracle's loop + accumulators on the same sequences."""
+    import os
+    from __graft_entry__ import make_model
+    from pafuse_amd import h3wb, harness
+    from tests.conftest import ROOT
+    ds = h3wb.Human3WBDataset(os.path.join(ROOT, "tests", "golden", "h3wb_synth", "train_h3wb.npz"))
+    keypoints = h3wb.prepare_keypoints(ds)
+    kps_left, kps_right = ds.keypoints_metadata["keypoints_symmetry"]
+    cams, p3, p2 = h3wb.fetch(["S8"], keypoints, ds)
+    P, T = 2, 1
+    model, sd = make_model(P, T, seed=87)
+    assert (list(kps_left), list(kps_right)) == (gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT)   # the synthetic sides
+    noises = gu.synthetic_noises(B=1, P=P, n=T, seed=14)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    rep = h3wb.evaluate(model, ds, cams, p3, p2, kps_left, kps_right, log=lambda *a: None)
+    total, n = None, 0
+    for cam, s3, s2 in zip(cams, p3, p2):
+        s2, s3 = torch.as_tensor(s2, dtype=torch.float32), torch.as_tensor(s3, dtype=torch.float32)
+        x2d, gt = harness.cut_clips(s2), harness.cut_clips(s3)
+        x2f = harness.cut_clips(harness.flip_2d(s2, kps_left, kps_right))
+        pred = orc.ddim_sample(sd, x2d, noises, T, model.joints_left, model.joints_right, inputs_2d_flip=x2f)
+        acc = orc.evaluate_accumulators(pred, orc.center_pose_parts(gt), x2d, gt[:, :, :1],
+                                        torch.as_tensor(cam, dtype=torch.float32))
+        mult = x2d.shape[0] * 27
+        total = {k: mult * v for k, v in acc.items()} if total is None else {k: total[k] + mult * acc[k] for k in acc}
+        n += mult
+    for k in harness.ACCUMULATORS:
+        want = total[k] / n * 1000.0
+        assert torch.allclose(torch.tensor(rep[k]), want, rtol=5e-6, atol=0), (k, rep[k], want)
+
+
 def test_infer_sequence_in_the_wild():
     """n4: the in-the-wild caller (input_3d=None) returns whole-body poses equal to the oracle's."""
     from types import SimpleNamespace

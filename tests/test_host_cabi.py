@@ -148,3 +148,35 @@ def test_torch_custom_ops_are_registered_for_the_hip_device_only():
         assert out.shape == (1, 2, 3, 27, 134, 3)
     with pytest.raises(NotImplementedError):
         torch.ops.pafuse.linear(torch.zeros(2, 32), torch.zeros(32, 32), torch.zeros(32))
+
+
+def test_h3wb_loader_matches_reference_on_synthetic_files():
+    """pafuse_amd.h3wb (npz loader, root-joint insertion, camera normalisation, mm->m, screen normalisation, fetch)
+    against the reference's loader on the synthetic H3WB files of tests/golden/h3wb_synth (golden G14), bit for bit."""
+    import numpy as np
+    from pafuse_amd import h3wb
+    z = load_golden("g14_h3wb_loader.npz")
+    ds = h3wb.Human3WBDataset(os.path.join(ROOT, "tests", "golden", "h3wb_synth", "train_h3wb.npz"))
+    assert ds.num_kps == int(z["num_kps"]) == 134
+    assert ds.skeleton().joints_left() == z["joints_left"].tolist()
+    assert ds.skeleton().joints_right() == z["joints_right"].tolist()
+    assert ds.keypoints_metadata["keypoints_symmetry"][0] == z["kps_left"].tolist()
+    assert list(ds.skeleton().parents()) == z["parents"].tolist()
+    assert ds.root_indices == gu.ROOT_INDICES and ds.parts_connection_indices == gu.CONNECTION_INDICES
+    for part, idx in ds.parts_joint_indices.items():
+        assert idx == z["part." + part].tolist() == list(gu.DATASET_PART_JOINTS[part])
+    for subject in ("S1", "S8"):
+        for i, cam in enumerate(ds.cameras()[subject]):
+            assert np.array_equal(cam["intrinsic"], z[f"cam.{subject}.{i}.intrinsic"].numpy())
+            assert np.array_equal(cam["translation"], z[f"cam.{subject}.{i}.translation"].numpy())
+    assert np.array_equal(ds["S1"]["Walking 1"]["positions"], z["positions.S1.Walking 1"].numpy())
+    keypoints = h3wb.prepare_keypoints(ds)
+    for tag, (subjects, stride, filt) in {"test": (["S8"], 1, None), "train2": (["S1", "S5"], 2, ["Dir"])}.items():
+        cams, p3, p2 = h3wb.fetch(subjects, keypoints, ds, stride, filt)
+        assert len(p2) == int(z[f"fetch.{tag}.n"]) == len(cams) == len(p3)
+        for i in range(len(p2)):
+            assert np.array_equal(cams[i], z[f"fetch.{tag}.{i}.cam"].numpy())
+            assert np.array_equal(p3[i], z[f"fetch.{tag}.{i}.p3"].numpy())
+            assert np.array_equal(p2[i], z[f"fetch.{tag}.{i}.p2"].numpy())
+    seqs = list(h3wb.iter_sequences(cams, p3, p2))
+    assert len(seqs) == len(p2) and seqs[0][0].shape == (1, 9) and seqs[0][2].shape == (1,) + p2[0].shape
