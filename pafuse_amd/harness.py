@@ -77,6 +77,51 @@ def infer_sequence(model, dataset, seq_2d, kps_left, kps_right, batch_size=2, gr
     return torch.cat(outs)
 
 
+def load_pifpaf_keypoints(path, num_kps=134):
+    """OpenPifPaf whole-body detections, one JSON object per line and frame, first person of each frame
+    (in_the_wild/h3wb_diffusion.py:57-70): -> float32 [frames, num_kps, 2] in pixels with the root joint (midpoint of
+    the shifted hip joints 12 and 13) inserted at index 0.  Confidences are dropped, as in the reference."""
+    import json
+    import numpy as np
+    frames = []
+    with open(path) as f:
+        for line in f:
+            if line.strip():
+                frames.append(json.loads(line))
+    kps = np.zeros((len(frames), num_kps, 2), dtype=np.float32)
+    for i, frame in enumerate(frames):
+        flat = frame["predictions"][0]["keypoints"]
+        kps[i, 1:, 0] = flat[::3]
+        kps[i, 1:, 1] = flat[1::3]
+        kps[i, :1, :] = (kps[i, 12:13, :] + kps[i, 13:14, :]) / 2.
+    return kps
+
+
+def stitch_clips(prediction, total_frames, frames=27):
+    """[clips, T, P, frames, J, 3] (clips cut by :func:`cut_clips`) -> [T, P, total_frames, J, 3]: consecutive clips laid
+    end to end, the last one contributing only its final `total_frames - frames * (clips - 1)` frames
+    (in_the_wild/h3wb_diffusion.py:118-131).  Sequences shorter than one clip keep their first total_frames frames."""
+    clips, T, P, _, J, c = prediction.shape
+    out = prediction.new_empty(T, P, total_frames, J, c)
+    if total_frames <= frames:
+        return prediction[0, :, :, :total_frames].clone()
+    for i in range(clips - 1):
+        out[:, :, i * frames:(i + 1) * frames] = prediction[i]
+    left = total_frames - (clips - 1) * frames
+    out[:, :, -left:] = prediction[-1, :, :, -left:]
+    return out
+
+
+def camera_to_world(X, R, t=0.0):
+    """Rotate points [..., 3] by the unit quaternion R (w, x, y, z) and translate (common/camera.py:27-28,
+    common/quaternion.py:3-17: v + 2 (w (q x v) + q x (q x v)))."""
+    R = torch.as_tensor(R, dtype=X.dtype, device=X.device)
+    q = R[1:].expand(X.shape)
+    uv = torch.cross(q, X, dim=-1)
+    uuv = torch.cross(q, uv, dim=-1)
+    return X + 2 * (R[0] * uv + uuv) + t
+
+
 def load_checkpoint(model, checkpoint):
     """Accept what the reference saves (common/logging.py:83-115): a dict with 'model_pos', DataParallel
     ``module.``-prefixed keys, or a bare state dict."""

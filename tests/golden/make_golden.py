@@ -527,6 +527,16 @@ def g14_h3wb_loader():
     save("g14_h3wb_loader.npz", **arrays)
 
 
+# ------------------------------------------------------------------------------------------------- G15
+def g15_camera_to_world():
+    """camera_to_world (common/camera.py:27-28) with the in-the-wild script's fixed camera rotation."""
+    from common.camera import camera_to_world
+    g = torch.Generator().manual_seed(151)
+    X = torch.randn(2, 3, 7, 134, 3, generator=g).numpy()
+    rot = np.array([0.14070565, -0.15007018, -0.7552408, 0.62232804], dtype=np.float32)
+    save("g15_camera_to_world.npz", X=X, rot=rot, out=camera_to_world(X, R=rot, t=0))
+
+
 # -------------------------------------------------------------------------------------------------- G8
 def g8_default_init():
     """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
@@ -540,10 +550,10 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
                  g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train,
-                 g14=g14_h3wb_loader)
+                 g14=g14_h3wb_loader, g15=g15_camera_to_world)
     for w in which:
         table[w]()

@@ -180,3 +180,29 @@ def test_h3wb_loader_matches_reference_on_synthetic_files():
             assert np.array_equal(p2[i], z[f"fetch.{tag}.{i}.p2"].numpy())
     seqs = list(h3wb.iter_sequences(cams, p3, p2))
     assert len(seqs) == len(p2) and seqs[0][0].shape == (1, 9) and seqs[0][2].shape == (1,) + p2[0].shape
+
+
+def test_in_the_wild_host_helpers(tmp_path):
+    """OpenPifPaf JSON reader, clip stitching and the camera-to-world rotation of the in-the-wild caller
+    (in_the_wild/h3wb_diffusion.py:57-70,118-140)."""
+    import json
+    import numpy as np
+    from pafuse_amd import harness
+    rng = np.random.default_rng(3)
+    flat = rng.uniform(0, 1000, (5, 133 * 3)).astype(np.float32)
+    path = tmp_path / "clip.openpifpaf.json"
+    with open(path, "w") as f:
+        for row in flat:
+            f.write(json.dumps({"predictions": [{"keypoints": row.tolist()}, {"keypoints": [0.0] * 399}]}) + "\n")
+    kps = harness.load_pifpaf_keypoints(str(path))
+    assert kps.shape == (5, 134, 2) and kps.dtype == np.float32
+    assert np.array_equal(kps[:, 1:, 0], flat[:, ::3]) and np.array_equal(kps[:, 1:, 1], flat[:, 1::3])
+    assert np.array_equal(kps[:, 0], (kps[:, 12] + kps[:, 13]) / 2.)
+    # stitching inverts cut_clips for every length class
+    for n in (10, 27, 54, 60):
+        seq = torch.arange(n, dtype=torch.float32).reshape(n, 1, 1).expand(n, 4, 3)
+        clips = harness.cut_clips(seq)[:, None, None]                       # [clips, T=1, P=1, 27, J, 3]
+        assert torch.equal(harness.stitch_clips(clips, n)[0, 0], seq), n
+    z = load_golden("g15_camera_to_world.npz")
+    out = harness.camera_to_world(z["X"], z["rot"])
+    assert torch.allclose(out, z["out"], rtol=0, atol=1e-6)
