@@ -167,14 +167,15 @@ int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config *cfg, int32_t B, int32_t P
  *   saved:     pafuse_mixste2_train_bytes(w, B) bytes; the forward leaves the activations the backward needs there.
  * Backward: dout [B,F,J,3] -> ADDS the gradient of every parameter into the buffer the like-named pointer of `grads`
  * addresses (same struct as the weights; `freqs` and the dimensions are ignored).  All row reductions are two-stage
- * in a fixed order: bit-reproducible, no atomics. */
+ * in a fixed order: bit-reproducible, no atomics.  `side_stream` (may be NULL): a second HIP stream the weight-gradient
+ * GEMMs run on next to the input-gradient chain (forked and joined with events inside the call; results identical). */
 size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights *w, int32_t B);
 int pafuse_mixste2_train_forward(const pafuse_mixste2_weights *w, const float *x2d, const float *x3d, const int64_t *t,
                                  int32_t B, const float *drop_path, float *out, void *saved, size_t saved_bytes,
                                  void *stream);
 int pafuse_mixste2_train_backward(const pafuse_mixste2_weights *w, const pafuse_mixste2_weights *grads,
                                   const float *dout, int32_t B, const float *drop_path, void *saved, size_t saved_bytes,
-                                  void *stream);
+                                  void *stream, void *side_stream);
 
 /* D3DP.prepare_diffusion_concat + q_sample (common/diffusionpose.py:319-326,358-374) for B samples of per_sample
  * floats: out = clamp(sqrt_acp[t_b] * (x0*scale) + sqrt_1m_acp[t_b] * noise, +-1.1 scale) / scale, in fp64 as the

@@ -78,7 +78,7 @@ SIGNATURES = {
                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                                C.c_void_p]),
     "pafuse_mixste2_train_backward": (C.c_int, [C.POINTER(MixSTE2Weights), C.POINTER(MixSTE2Weights), C.c_void_p,
-                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "pafuse_d3dp_qsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                       C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
 }

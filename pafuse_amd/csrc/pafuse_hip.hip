@@ -557,14 +557,15 @@ int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x
 }
 
 int pafuse_mixste2_train_backward(const pafuse_mixste2_weights* w, const pafuse_mixste2_weights* grads, const float* dout,
-                                  int32_t B, const float* drop_path, void* saved, size_t saved_bytes, void* stream) {
+                                  int32_t B, const float* drop_path, void* saved, size_t saved_bytes, void* stream,
+                                  void* side_stream) {
     int rc = check_weights(w);
     if (rc) return rc;
     if (!grads || !dout || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_backward: bad argument");
     if (saved_bytes < train_bytes(w, B)) return fail(PAFUSE_E_WORKSPACE, "mixste2_train_backward: buffer too small");
     TrainBuffers tb;
     carve_train((char*)saved, w, B, tb);
-    return train_backward(w, grads, dout, B, drop_path, tb, (hipStream_t)stream);
+    return train_backward(w, grads, dout, B, drop_path, tb, (hipStream_t)stream, (hipStream_t)side_stream);
 }
 
 int pafuse_d3dp_qsample(const float* x0, const float* noise, const int64_t* t, const double* sqrt_alphas_cumprod,

@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(256) gelu_backward_kernel(const float* u, cons
 // Weight-gradient GEMM: dW[n][k] = sum_m dY[m][n] * X[m][k]  (nn.Linear: dY [M,N] output grad, X [M,K] its input).
 // Both operands are read as they lie in memory (rows = the contracted index m), staged in LDS in that natural [m][.]
 // layout, and fed to v_mfma_f32_32x32x2_f32 with scalar LDS reads: lane (r,h) needs Y[m=2s+h][n=r'] - 32 consecutive
-// floats per half-wave, and the +32 row padding puts the two halves on disjoint banks.  128(n) x 64(k) output tiles,
+// floats per half-wave, and the +32 row padding puts the two halves on disjoint banks.  128(n) x 128(k) output tiles
+// (64-wide ones re-read Y twice as often and ran into the per-CU load path),
 // wave w owns the 32-row strip w.  The contraction is M = 25-70 k rows and the output is small, so M is cut into
 // `splits` ranges (grid.y) whose partial tiles are summed afterwards in a fixed order.
 // ----------------------------------------------------------------------------------------------------------------
@@ -259,7 +260,8 @@ struct TnParams {
     int N, K;
 };
 
-constexpr int TN_BN = 128, TN_BK = 64, TN_LDY = TN_BN + 32, TN_LDX = TN_BK + 32;
+constexpr int TN_BN = 128, TN_BK = 128, TN_LDY = TN_BN + 32, TN_LDX = TN_BK + 32;
+constexpr int TN_KB = TN_BK / 32;  // 32-column blocks per wave strip
 
 __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
     __shared__ __attribute__((aligned(16))) float Ys[32 * TN_LDY];
@@ -269,33 +271,33 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
     const int n0 = (blockIdx.x / tiles_k) * TN_BN, k0 = (blockIdx.x % tiles_k) * TN_BK;
     const int64_t m_lo = (int64_t)blockIdx.y * p.rows_per_split;
     const int64_t m_hi = m_lo + p.rows_per_split < p.M ? m_lo + p.rows_per_split : p.M;
-    // staging: Y chunk = 32 rows x 32 float4, X chunk = 32 rows x 16 float4
-    const int yrow = tid >> 5, yc4 = tid & 31;  // rows yrow + 8 i, i < 4
-    const int xrow = tid >> 4, xc4 = tid & 15;  // rows xrow + 16 i, i < 2
+    // staging: a 32-row chunk of Y (TN_BN columns) and of X (TN_BK columns), one float4 per thread and row group
+    constexpr int YC4 = TN_BN / 4, XC4 = TN_BK / 4, YR = 256 / YC4, XR = 256 / XC4, YL = 32 / YR, XL = 32 / XR;
+    const int yrow = tid / YC4, yc4 = tid % YC4, xrow = tid / XC4, xc4 = tid % XC4;
     const bool y_in = n0 + 4 * yc4 < p.N, x_in = k0 + 4 * xc4 < p.K;  // N, K are multiples of 4
-    f32x4 yreg[4], xreg[2];
+    f32x4 yreg[YL], xreg[XL];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     auto load = [&](int64_t m0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + yrow + 8 * i;
+        for (int i = 0; i < YL; ++i) {
+            const int64_t m = m0 + yrow + YR * i;
             yreg[i] = (y_in && m < m_hi) ? *reinterpret_cast<const f32x4*>(p.Y + m * p.N + n0 + 4 * yc4) : zero;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int64_t m = m0 + xrow + 16 * i;
+        for (int i = 0; i < XL; ++i) {
+            const int64_t m = m0 + xrow + XR * i;
             xreg[i] = (x_in && m < m_hi) ? *reinterpret_cast<const f32x4*>(p.X + m * p.K + k0 + 4 * xc4) : zero;
         }
     };
     auto store = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ys + (yrow + 8 * i) * TN_LDY + 4 * yc4) = yreg[i];
+        for (int i = 0; i < YL; ++i) *reinterpret_cast<f32x4*>(Ys + (yrow + YR * i) * TN_LDY + 4 * yc4) = yreg[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(Xs + (xrow + 16 * i) * TN_LDX + 4 * xc4) = xreg[i];
+        for (int i = 0; i < XL; ++i) *reinterpret_cast<f32x4*>(Xs + (xrow + XR * i) * TN_LDX + 4 * xc4) = xreg[i];
     };
-    f32x16 acc[2];
+    f32x16 acc[TN_KB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN_KB; ++b)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
     if (m_lo < m_hi) {
@@ -310,9 +312,9 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const float a = ya[2 * s * TN_LDY];
-                const float b0 = xb[2 * s * TN_LDX], b1 = xb[2 * s * TN_LDX + 32];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < TN_KB; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[2 * s * TN_LDX + 32 * b], acc[b], 0, 0, 0);
             }
             __syncthreads();
             if (more) store();
@@ -321,7 +323,7 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
     }
     float* out = p.partial + (int64_t)blockIdx.y * p.N * p.K;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < TN_KB; ++b) {
         const int k = k0 + 32 * b + r;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {

@@ -88,6 +88,9 @@ class MixSTE2(nn.Module):
         self._wcache = None
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
+        self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
+        #                                results; measured 3 % slower than one stream per part at B=37, so off)
+        self._side_by_device = {}
 
     # ------------------------------------------------------------------------------------------- C structs
     def weights_struct(self):
@@ -127,6 +130,13 @@ class MixSTE2(nn.Module):
         return out
 
     # ------------------------------------------------------------------------------------------------ training
+    def side_stream(self, device):
+        if not self.use_side_stream:
+            return None
+        if device.index not in self._side_by_device:
+            self._side_by_device[device.index] = torch.cuda.Stream(device=device)
+        return self._side_by_device[device.index]
+
     def drop_path_factors(self, B, device):
         """DropPath factors (mask / keep) of one forward, [2*depth, 2, B*max(F,J)] or None, drawn as the reference's
         blocks draw them: execution order STE0 (attn, mlp), TTE0, STE1, ...; one Bernoulli(keep) per sequence of the
@@ -200,10 +210,15 @@ class _TrainFunction(torch.autograd.Function):
         fill_weights_struct(gw, grads.__getitem__, module._freqs, module.num_frame, module.num_joints,
                             module.embed_dim, module.block_depth, module.num_heads, module.in_chans)
         dout = dout.contiguous().float()
-        stream = torch.cuda.current_stream(dout.device).cuda_stream
+        stream = torch.cuda.current_stream(dout.device)
+        side = module.side_stream(dout.device)
         _lib.check(lib.pafuse_mixste2_train_backward(C.byref(w), C.byref(gw), dout.data_ptr(), ctx.B,
                                                      ctx.drop.data_ptr() if ctx.drop is not None else None,
-                                                     ctx.saved.data_ptr(), ctx.nbytes, stream))
+                                                     ctx.saved.data_ptr(), ctx.nbytes, stream.cuda_stream,
+                                                     side.cuda_stream if side is not None else None))
+        if side is not None:                     # the library joined the streams; tell the allocator about the use
+            for tensor in (flat, ctx.saved, dout):
+                tensor.record_stream(side)
         ctx.saved = None
         return (None, None, None, None, None) + tuple(grads[n] for n in module._param_names)
 

@@ -120,14 +120,17 @@ def test_train_gradients_vs_oracle_real_widths(part, B):
 
 
 def test_train_backward_is_bit_reproducible():
+    """run to run, and with the weight-gradient GEMMs forked onto a side stream"""
     z = load_golden("g12_train_tiny.npz")
     grads = []
-    for _ in range(2):
+    for side in (False, False, True):
         m = _tiny(z, drop_rate=0.0)
+        m.use_side_stream = side
         out = m(z["x2d"].to(DEV), z["x3d"].to(DEV), z["t"].to(DEV))
         out.backward(z["dout"].to(DEV))
         grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
-    assert all(torch.equal(grads[0][n], grads[1][n]) for n in grads[0])
+    torch.cuda.synchronize()
+    assert all(torch.equal(grads[0][n], grads[1][n]) and torch.equal(grads[0][n], grads[2][n]) for n in grads[0])
 
 
 def test_optimizer_step_reduces_the_loss():
