@@ -250,6 +250,29 @@ def train_bench(args, rank, local_rank, world, dev):
         elapsed = float(tmax.item())
     sec = elapsed / args.steps
     tflops = B * 3 * GFLOP_PER_HYP_PASS / 1e3 / sec                  # per GPU: forward + 2x backward
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle's train step (torch CPU autograd over the functional restatement) on one clip
+        from oracle import d3dp_oracle as orc
+        model.train_draw_fn = None
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        leaves = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in sd.items()}
+        xc, tc = x2d[:1].cpu(), target[:1].cpu()
+        g = torch.Generator().manual_seed(3)
+        tt, nz = torch.tensor([500]), torch.randn(1, 27, 134, 3, generator=g)
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+
+        def cpu_step():
+            t0 = time.perf_counter()
+            pred = orc.train_forward(leaves, xc, orc.q_sample_targets(sd, tc, tt, nz), tt)
+            orc.mpjpe(pred, tc).backward()
+            return time.perf_counter() - t0
+
+        cpu_step()
+        dt = min(cpu_step() for _ in range(2))
+        cpu = {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"oracle/d3dp_oracle.py train_forward + mpjpe + torch autograd backward, 1 clip, {dt:.2f} s "
+                         f"(no optimiser step)"}
     if rank == 0:
         print(json.dumps({
             "metric": "training clips/sec (H3WB 27x134 clips, fwd+bwd+AdamW)", "value": round(B * world / sec, 3),
@@ -262,7 +285,8 @@ def train_bench(args, rank, local_rank, world, dev):
                        "weights": "seeded synthetic", "peak_mem_GiB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)},
             "roofline_loop": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                              "note": "per GPU: B*3*69.3847 GFLOP (forward + 2x backward) / step time"}}), flush=True)
+                              "note": "per GPU: B*3*69.3847 GFLOP (forward + 2x backward) / step time"},
+            "cpu_baseline": cpu}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -179,3 +179,28 @@ def test_ddp_wrapper_produces_the_same_gradients():
             assert p.grad is not None and torch.equal(p.grad, plain[n]), n
     finally:
         dist.destroy_process_group()
+
+
+def test_training_errors_are_loud():
+    """unsupported width, CPU tensors and a short activation buffer are refused - nothing falls back"""
+    import ctypes as C
+    import pafuse_amd
+    from pafuse_amd import _lib
+    m = pafuse_amd.MixSTE2(3, 5, 5, 16, 2, 8, drop_path_rate=0.0, is_train=True).to(DEV)
+    args = (torch.zeros(1, 3, 5, 2, device=DEV), torch.zeros(1, 3, 5, 3, device=DEV),
+            torch.zeros(1, dtype=torch.long, device=DEV))
+    with pytest.raises(_lib.PafuseError):
+        m(*args)
+    z = load_golden("g12_train_tiny.npz")
+    m = _tiny(z)
+    with pytest.raises(_lib.PafuseError):
+        m(z["x2d"], z["x3d"], z["t"])                                    # CPU tensors
+    lib, w = _lib.load(), m.weights_struct()
+    need = lib.pafuse_mixste2_train_bytes(C.byref(w), 4)
+    assert need > 0
+    short = torch.empty(need // 2, dtype=torch.uint8, device=DEV)
+    out = torch.empty(4, 3, 5, 3, device=DEV)
+    rc = lib.pafuse_mixste2_train_forward(C.byref(w), z["x2d"].to(DEV).data_ptr(), z["x3d"].to(DEV).data_ptr(),
+                                          z["t"].to(DEV).data_ptr(), 4, None, out.data_ptr(), short.data_ptr(),
+                                          need // 2, torch.cuda.current_stream().cuda_stream)
+    assert rc == -3 and b"too small" in lib.pafuse_last_error()
