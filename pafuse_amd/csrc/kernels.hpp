@@ -41,7 +41,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ----------------------------------------------------------------------------------------------------------------
 // Linear layer:  out = epilogue(A[M,K] @ W[N,K]^T + bias)
 // ----------------------------------------------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_ROWLN = 1 };
+enum { EPI_BIAS = 0, EPI_ROWLN = 1, EPI_ROWLN_TRAIN = 2 };  // _TRAIN: + DropPath row factor, + pre-norm sum output
 
 struct GemmParams {
     const float* A;     // [M,K]
@@ -68,6 +68,10 @@ struct GemmParams {
     const float* head_w;
     const float* head_b;
     float* out_head;
+    // EPI_ROWLN_TRAIN only (training forward): y = resid + rowscale[seq(m)] * (A W^T + bias), out_pre = y
+    const float* rowscale;  // [nseq] DropPath factor of the row's sequence, or null (= 1)
+    int rs_temporal, rs_J, rs_FJ;  // seq(m) = rs_temporal ? (m / rs_FJ) * rs_J + m % rs_J : m / rs_J
+    float* out_pre;
     unsigned long long* stamps;  // diagnostic builds (-DPAFUSE_STAMPS) only: per wave {start, loop end, end}
 };
 
@@ -279,6 +283,13 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
                             acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
                     }
             };
+            float rs = 1.0f;
+            if constexpr (EPI == EPI_ROWLN_TRAIN) {
+                if (p.rowscale) {
+                    const int64_t mm = live ? m : p.M - 1;
+                    rs = p.rowscale[p.rs_temporal ? (mm / p.rs_FJ) * p.rs_J + mm % p.rs_J : mm / p.rs_J];
+                }
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -287,7 +298,20 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
                     const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.resid + mo + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] = (acc[nt][4 * q + e] + b4[e]) + r4[e];
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (EPI == EPI_ROWLN_TRAIN)
+                            acc[nt][4 * q + e] = r4[e] + rs * (acc[nt][4 * q + e] + b4[e]);
+                        else
+                            acc[nt][4 * q + e] = (acc[nt][4 * q + e] + b4[e]) + r4[e];
+                    }
+                    if constexpr (EPI == EPI_ROWLN_TRAIN) {
+                        if (p.out_pre && live) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                            *reinterpret_cast<f32x4*>(p.out_pre + mo + n) = v;
+                        }
+                    }
                 }
             if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
             if (p.pos) {  // only the first spatial block of a pass

@@ -40,7 +40,7 @@ template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
     constexpr size_t stage_bytes = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
-    static_assert(EPI != EPI_ROWLN || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
+    static_assert(EPI == EPI_BIAS || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
     constexpr size_t lds = stage_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR>;
@@ -68,20 +68,25 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     return launch_gemm<4, 1, 1, EPI_BIAS, 1>(p, s);
 }
 
-int gemm_rowln(const GemmParams& p, hipStream_t s) {
+template <int EPI>
+int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
     switch (p.N) {
         // row-per-lane accumulators (TR): LayerNorm statistics are in-lane sums + one shuffle + a tiny cross-wave
         // exchange, all global traffic is dwordx4, no LDS transposition (picked with tools/gemm_bench.hip)
-        case 384: return launch_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>(p, s);
-        case 256: return launch_gemm<2, 2, 4, EPI_ROWLN, 1, 3, 1>(p, s);
-        case 224: return launch_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>(p, s);
-        case 128: return launch_gemm<1, 4, 1, EPI_ROWLN, 1, 1, 1>(p, s);
-        case 64: return launch_gemm<1, 2, 1, EPI_ROWLN, 1, 1, 1>(p, s);
+        case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1>(p, s);
+        case 256: return launch_gemm<2, 2, 4, EPI, 1, 3, 1>(p, s);
+        case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1>(p, s);
+        case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1>(p, s);
+        case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1>(p, s);
         default: return fail(PAFUSE_E_SHAPE, "no whole-row kernel for channel width %d (have 64,128,224,256,384)", p.N);
     }
 }
+
+int gemm_rowln(const GemmParams& p, hipStream_t s) { return gemm_rowln_as<EPI_ROWLN>(p, s); }
+// training forward: the same kernels with the DropPath row factor and the pre-norm sum as an extra output
+int gemm_rowln_train(const GemmParams& p, hipStream_t s) { return gemm_rowln_as<EPI_ROWLN_TRAIN>(p, s); }
 
 bool width_supported(int C) { return C == 384 || C == 256 || C == 224 || C == 128 || C == 64; }
 

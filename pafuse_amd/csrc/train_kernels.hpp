@@ -1,5 +1,6 @@
-// train_kernels.hpp - device code of the training path: the train-mode forward pieces that the
-// fused inference epilogues do not cover (DropPath, saved pre-norm sums) and the backward of every layer of MixSTE2.
+// train_kernels.hpp - device code of the training path: the backward of every layer of MixSTE2
+// (the train-mode forward runs on the inference kernels; its DropPath factor and saved pre-norm sums are the
+// EPI_ROWLN_TRAIN form of the whole-row GEMM epilogue in kernels.hpp).
 // gfx950 only.  All reductions over rows are two-stage (per-workgroup partials in a fixed order, then one summing
 // pass), so gradients are bit-reproducible run to run - no float atomics anywhere.
 //
@@ -18,65 +19,6 @@ struct SeqMap {
 };
 __device__ __forceinline__ int64_t seq_of(int64_t row, const SeqMap m) {
     return m.temporal ? (row / m.FJ) * m.J + row % m.J : row / m.J;
-}
-
-// ----------------------------------------------------------------------------------------------------------------
-// Forward: x_sum = resid + drop[seq] * branch ; y = postLN(x_sum) (+ pos[f]) ; xn = nextLN(y).  One wave per row.
-// Every stage is optional (null pointer = skipped); this is the unfused form of the inference GEMM epilogue with
-// the two things training adds: the per-sequence DropPath factor and the pre-norm sum kept for the backward pass.
-// ----------------------------------------------------------------------------------------------------------------
-struct TrainRowParams {
-    const float *resid, *branch;  // [M,C]; branch may be null
-    const float* drop;            // [nseq] mask / keep_prob, or null (= 1)
-    SeqMap map;
-    float* out_sum;  // [M,C] or null
-    const float *post_w, *post_b;
-    float post_eps;
-    const float* pos;  // [posF,C] or null: added after the post norm (Temporal_pos_embed, first temporal block)
-    int posJ, posF;
-    float* out_y;  // [M,C] or null
-    const float *next_w, *next_b;
-    float next_eps;
-    float* out_n;  // [M,C] or null
-    int64_t M;
-    int C;
-};
-
-__global__ void __launch_bounds__(256) train_row_kernel(const TrainRowParams p) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    const int C = p.C;
-    float v[LN_MAX_PER_LANE];
-    const float d = (p.branch && p.drop) ? p.drop[seq_of(row, p.map)] : 1.0f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = 0.f;
-        if (c < C) {
-            v[i] = p.resid[row * C + c];
-            if (p.branch) v[i] = v[i] + d * p.branch[row * C + c];  // x + drop_path(f(x)): one multiply, one add
-            if (p.out_sum) p.out_sum[row * C + c] = v[i];
-        }
-    }
-    if (p.post_w) wave_layer_norm(v, C, lane, p.post_w, p.post_b, p.post_eps);
-    if (p.pos) {
-        const int f = (int)((row / p.posJ) % p.posF);
-#pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
-            if (lane + 64 * i < C) v[i] += p.pos[f * C + lane + 64 * i];
-    }
-    if (p.out_y) {
-#pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
-            if (lane + 64 * i < C) p.out_y[row * C + lane + 64 * i] = v[i];
-    }
-    if (p.out_n) {
-        wave_layer_norm(v, C, lane, p.next_w, p.next_b, p.next_eps);
-#pragma unroll
-        for (int i = 0; i < LN_MAX_PER_LANE; ++i)
-            if (lane + 64 * i < C) p.out_n[row * C + lane + 64 * i] = v[i];
-    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -514,21 +456,7 @@ __global__ void __launch_bounds__(256) outer_sum_kernel(const float* s, const fl
     }
 }
 
-// head.1: out[row][i] = hn[row] . w[i] + b[i] (i < 3), one wave per row;  backward: dhn[row][c] = sum_i dout[row][i] w[i][c]
-__global__ void __launch_bounds__(256) head_forward_kernel(const float* hn, const float* w, const float* b, float* out,
-                                                           int64_t M, int C) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float v = hn[row * C + c];
-        s0 += v * w[c], s1 += v * w[C + c], s2 += v * w[2 * C + c];
-    }
-    s0 = wave_sum(s0), s1 = wave_sum(s1), s2 = wave_sum(s2);
-    if (lane == 0) out[row * 3 + 0] = s0 + b[0], out[row * 3 + 1] = s1 + b[1], out[row * 3 + 2] = s2 + b[2];
-}
-
+// head.1 backward: dhn[row][c] = sum_i dout[row][i] w[i][c]   (the forward lives in the GEMM epilogue)
 __global__ void __launch_bounds__(256) head_backward_kernel(const float* dout, const float* w, float* dhn, int64_t M,
                                                             int C) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
