@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Groups a rocprofv3 kernel_trace.csv by (kernel, workgroup count): launches, min / median / max duration in us.
+    python tools/trace_by_grid.py gpurun_out/prof/x_kernel_trace.csv > profiles/r01_kernel_trace_by_grid.csv
+Also prints (stderr) the mean duration of the last N `gemm_kernel` launches (N = bench.py's replay leg, default 576),
+the number to hold against `roofline.avg_launch_us`."""
+import csv
+import statistics
+import sys
+from collections import defaultdict
+
+
+def main():
+    path = sys.argv[1]
+    last = int(sys.argv[2]) if len(sys.argv) > 2 else 576
+    groups, gemm = defaultdict(list), []
+    for r in csv.DictReader(open(path)):
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        wgs = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
+        name = r["Kernel_Name"]
+        groups[(name, wgs)].append(us)
+        if "gemm_kernel" in name and "tn_gemm" not in name:
+            gemm.append((int(r["Start_Timestamp"]), us))
+    w = csv.writer(sys.stdout)
+    w.writerow(["kernel", "workgroups", "calls", "min_us", "median_us", "max_us"])
+    for (name, wgs), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([name, wgs, len(v), f"{min(v):.2f}", f"{statistics.median(v):.2f}", f"{max(v):.2f}"])
+    gemm.sort()
+    tail = [us for _, us in gemm[-last:]]
+    if tail:
+        print(f"last {len(tail)} gemm_kernel launches: mean {sum(tail) / len(tail):.2f} us", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
