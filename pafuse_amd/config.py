@@ -10,12 +10,14 @@ from types import SimpleNamespace
 # the keys D3DP / the harness read (common/diffusionpose.py:62-103,140-153; main_h3wb.py:306,685-688) with the
 # values of the reference configuration
 DEFAULTS = {
-    "general": {"part_based_model": True, "evaluate": "best_epoch.bin", "checkpoint": ""},
+    "general": {"part_based_model": True, "evaluate": "best_epoch.bin", "checkpoint": "", "checkpoint_frequency": 20},
     "data": {"dataset": "h3wb", "num_kps": 134, "merge_hands": True, "subjects_train": "S1,S5,S6,S7",
              "subjects_test": "S8", "actions": "*"},
     "experiment": {"downsample": 1, "gpu": "0"},
     "model": {"diff_model": "MixSTE2", "number_of_frames": 27, "stride": 27, "batch_size": 1024,
-              "test_time_augmentation": True, "input_size": 5, "dep": 8, "cs": 288},
+              "test_time_augmentation": True, "input_size": 5, "dep": 8, "cs": 288, "epochs": 400,
+              "data_augmentation": True, "learning_rate": 0.00006, "lr_decay": 0.993, "wb_loss": False,
+              "mse_loss": False},
     "ft2d": {"scale": 1.0, "timestep": 1000, "sampling_timesteps": 5, "num_proposals": 10, "debug": False, "p2": False},
 }
 

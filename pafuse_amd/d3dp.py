@@ -170,11 +170,19 @@ class D3DP(nn.Module):
             raise ValueError("flip-TTA sampling needs input_2d_flip (common/diffusionpose.py:293)")
         dev = inputs_2d.device
         B = inputs_2d.shape[0]
+        want = (B, self.frames, self.num_kps, 2)           # the kernels index by these sizes: never launch on others
+        if tuple(inputs_2d.shape) != want or (flip and tuple(input_2d_flip.shape) != want):
+            raise ValueError(f"D3DP expects 2-D inputs of shape [B, {self.frames}, {self.num_kps}, 2], got "
+                             f"{tuple(inputs_2d.shape)}" + (f" / {tuple(input_2d_flip.shape)}" if flip else ""))
+        if flip and input_2d_flip.device != dev:
+            raise ValueError("input_2d_flip must live on the device of inputs_2d")
         shape = (B, self.num_proposals, self.frames, self.num_kps, 3)
         steps = self.ddim_steps()
         n_draws = 1 + sum(1 for s in steps if not s.last)
         noise = self._draws(n_draws, shape, dev)       # full batch, in the reference's draw order
         P = noise.shape[2]
+        if tuple(noise.shape) != (n_draws, B, P, self.frames, self.num_kps, 3):
+            raise ValueError(f"noise draws have shape {tuple(noise.shape)}")
         per_clip = (2 if flip else 1) * P
         bc = max(1, self.max_rows_per_launch // per_clip)
         if B > bc:                                      # cut along the (independent) clip axis
@@ -260,6 +268,9 @@ class D3DP(nn.Module):
         device), then q_sample + clamp in the fp64 of the schedule buffers (pafuse_d3dp_qsample), cast to fp32."""
         if not targets.is_cuda:
             raise _lib.PafuseError("D3DP runs on the HIP device only (no CPU fallback)")
+        if tuple(targets.shape[1:]) != (self.frames, self.num_kps, 3):
+            raise ValueError(f"D3DP expects 3-D targets of shape [B, {self.frames}, {self.num_kps}, 3], got "
+                             f"{tuple(targets.shape)}")
         lib = _lib.load()
         dev, B = targets.device, targets.shape[0]
         ts, noises = [], []
@@ -290,6 +301,8 @@ class D3DP(nn.Module):
 
     def pred_parts(self, input_2d, x_poses, t):
         """common/diffusionpose.py:163-172 (training caller: every part's MixSTE2 in train mode)."""
+        if tuple(input_2d.shape) != tuple(x_poses.shape[:-1]) + (2,) or input_2d.device != x_poses.device:
+            raise ValueError(f"2-D input {tuple(input_2d.shape)} does not match the poses {tuple(x_poses.shape)}")
         data_2d, data_3d = self.split_data(input_2d, x_poses)
         dev = x_poses.device
         cur = torch.cuda.current_stream(dev)

@@ -29,7 +29,19 @@ def evaluate_accumulators(pred_parts, gt_parts, inputs_2d, traj, cam, dataset):
     if not pred_parts.is_cuda:
         raise _lib.PafuseError("evaluate_accumulators runs on the HIP device only (no CPU fallback)")
     dev = pred_parts.device
+    if pred_parts.dim() != 6 or pred_parts.shape[-1] != 3:
+        raise ValueError(f"pred_parts must be [B,T,P,F,J,3], got {tuple(pred_parts.shape)}")
     B, T, P, F, J, _ = pred_parts.shape
+    # the kernel indexes every operand by (B, F, J): check before launching
+    if (tuple(gt_parts.shape) != (B, F, J, 3) or tuple(inputs_2d.shape) != (B, F, J, 2) or traj.numel() != B * F * 3
+            or cam.numel() < 9):
+        raise ValueError(f"evaluate_accumulators: operands do not match pred {tuple(pred_parts.shape)}: gt "
+                         f"{tuple(gt_parts.shape)}, 2d {tuple(inputs_2d.shape)}, traj {tuple(traj.shape)}, cam {tuple(cam.shape)}")
+    if any(t.device != dev for t in (gt_parts, inputs_2d, traj)):
+        raise ValueError("evaluate_accumulators: all tensors must live on the device of pred_parts")
+    covered = sorted(j for idx in dataset.parts_joint_indices.values() for j in idx)
+    if covered != list(range(J)):
+        raise ValueError("dataset.parts_joint_indices must cover every joint exactly once")
     pred = pred_parts.contiguous().float()
     gt = gt_parts.contiguous().float()
     x2d = inputs_2d.contiguous().float()

@@ -6,6 +6,9 @@ Mirrors, for a user who has ``data/train_h3wb.npz`` + ``data/task1_test_3d.npz``
   prepare_keypoints / fetch  reference main_h3wb.py:57-119,621-648 (mm -> m, screen normalisation, per-camera lists)
   iter_sequences             reference common/generators.py:174-249 (UnchunkedGenerator_Seq.next_epoch, no augmentation)
   evaluate                   reference main_h3wb.py:194-531 (the loop around model_eval + the mm report)
+  ChunkedClips               reference common/generators.py:5-172 (ChunkedGenerator_Seq: the shuffled, flip-augmented
+                             27-frame training clips)
+  train_epoch / save_state   reference main_h3wb.py:820-870,1018-1040, common/logging.py:83-115
 Host-side numpy; nothing here touches the device except through pafuse_amd.harness.evaluate_sequence.
 """
 import copy
@@ -229,3 +232,117 @@ def evaluate(model, dataset, cams, poses_3d, poses_2d, kps_left, kps_right, batc
     for k in harness.ACCUMULATORS:
         log(f"{k:>22s}: " + " ".join(f"{v:8.3f}" for v in rep[k]) + " mm")
     return rep
+
+
+class ChunkedClips:
+    """Training batches: every video cut into `chunk_length`-frame clips centred on the video (the overhang split
+    between both ends and filled by repeating the edge frame), each clip optionally a second time mirrored (x negated,
+    left/right keypoints swapped, camera centre/tangential x negated), all (video, start, end, flip) items shuffled
+    per epoch by a RandomState(1234) and served `batch_size` clips at a time.  Same item list, same permutation call,
+    same buffers' dtype (float64) as the reference's ChunkedGenerator_Seq."""
+
+    def __init__(self, batch_size, cameras, poses_3d, poses_2d, chunk_length, shuffle=True, random_seed=1234,
+                 augment=False, kps_left=None, kps_right=None, joints_left=None, joints_right=None):
+        assert poses_3d is None or len(poses_3d) == len(poses_2d)
+        assert cameras is None or len(cameras) == len(poses_2d)
+        items = []
+        for i, seq in enumerate(poses_2d):
+            n = seq.shape[0]
+            assert poses_3d is None or poses_3d[i].shape[0] == n
+            n_chunks = (n + chunk_length - 1) // chunk_length
+            offset = (n_chunks * chunk_length - n) // 2
+            bounds = np.arange(n_chunks + 1) * chunk_length - offset
+            # the reference zips len(bounds) flags with len(bounds) - 1 intervals: zip stops at the shorter list
+            plain = np.full(len(bounds), False, dtype=bool)
+            items += zip(np.repeat(i, len(bounds)), bounds[:-1], bounds[1:], plain)
+            if augment:
+                items += zip(np.repeat(i, len(bounds)), bounds[:-1], bounds[1:], ~plain)
+        self.pairs, self.batch_size, self.chunk_length = items, batch_size, chunk_length
+        self.num_batches = (len(items) + batch_size - 1) // batch_size
+        self.random = np.random.RandomState(random_seed)
+        self.shuffle, self.augment = shuffle, augment
+        self.cameras, self.poses_3d, self.poses_2d = cameras, poses_3d, poses_2d
+        self.kps_left, self.kps_right = kps_left, kps_right
+        self.joints_left, self.joints_right = joints_left, joints_right
+
+    def batch_num(self):
+        return self.num_batches
+
+    def num_frames(self):
+        return self.num_batches * self.batch_size
+
+    def random_state(self):
+        return self.random
+
+    def set_random_state(self, random):
+        self.random = random
+
+    def _clip(self, seq, start, end):
+        lo, hi = max(start, 0), min(end, seq.shape[0])
+        clip = seq[lo:hi]
+        if lo != start or hi != end:
+            clip = np.pad(clip, ((lo - start, end - hi), (0, 0), (0, 0)), "edge")
+        return clip
+
+    def next_epoch(self):
+        pairs = self.random.permutation(self.pairs) if self.shuffle else self.pairs
+        for b in range(self.num_batches):
+            chunk = pairs[b * self.batch_size:(b + 1) * self.batch_size]
+            n = len(chunk)
+            b2 = np.empty((n, self.chunk_length) + self.poses_2d[0].shape[-2:])
+            b3 = None if self.poses_3d is None else np.empty((n, self.chunk_length) + self.poses_3d[0].shape[-2:])
+            bc = None if self.cameras is None else np.empty((n, self.cameras[0].shape[-1]))
+            for i, (seq_i, start, end, flip) in enumerate(chunk):
+                seq_i, start, end = int(seq_i), int(start), int(end)
+                b2[i] = self._clip(self.poses_2d[seq_i], start, end)
+                if flip:
+                    b2[i, :, :, 0] *= -1
+                    b2[i, :, self.kps_left + self.kps_right] = b2[i, :, self.kps_right + self.kps_left]
+                if b3 is not None:
+                    b3[i] = self._clip(self.poses_3d[seq_i], start, end)
+                    if flip:
+                        b3[i, :, :, 0] *= -1
+                        b3[i, :, self.joints_left + self.joints_right] = b3[i, :, self.joints_right + self.joints_left]
+                if bc is not None:
+                    bc[i] = self.cameras[seq_i]
+                    if flip:
+                        bc[i, 2] *= -1
+                        bc[i, 7] *= -1
+            yield bc, b3, b2
+
+
+def train_epoch(model, optimizer, generator, dataset, device, wb_loss=False, log=None):
+    """One epoch of main_h3wb.py:820-870: part-centred targets, train-mode D3DP forward (HIP), mpjpe loss, backward
+    (HIP), optimizer step.  `model` may be wrapped in DistributedDataParallel.  Returns the frame-weighted mean loss (m)."""
+    import torch
+    from . import harness
+    total, frames = 0.0, 0
+    for it, (_, batch_3d, batch_2d) in enumerate(generator.next_epoch()):
+        inputs_3d = torch.from_numpy(batch_3d.astype("float32")).to(device)
+        inputs_2d = torch.from_numpy(batch_2d.astype("float32")).to(device)
+        inputs_3d = harness.center_pose_parts(inputs_3d, dataset)
+        optimizer.zero_grad()
+        pred = model(inputs_2d, inputs_3d)
+        target = inputs_3d
+        if wb_loss:
+            pred, target = harness.wb_pose_from_parts(pred, dataset), harness.wb_pose_from_parts(inputs_3d, dataset)
+        loss = torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))         # common/loss.py:27-34
+        loss.backward()
+        optimizer.step()
+        n = inputs_3d.shape[0] * inputs_3d.shape[1]
+        total, frames = total + n * float(loss.detach()), frames + n
+        if log is not None and it % 10 == 0:
+            log("%d/%d" % (it, generator.batch_num()))
+    return total / max(frames, 1)
+
+
+def save_state(model, optimizer, epoch_no, lr, foldername, random_state=None, tag=None):
+    """The reference's checkpoint dictionary (common/logging.py:83-115): evaluate() and --resume read it back."""
+    import torch
+    module = model.module if hasattr(model, "module") else model
+    params = {"optimizer": optimizer.state_dict(), "epoch": epoch_no, "lr": lr, "model_pos": module.state_dict()}
+    if random_state is not None:
+        params["random_state"] = random_state
+    fname = f"{foldername}/{tag or f'epoch_{epoch_no}'}.bin"
+    torch.save(params, fname)
+    return fname

@@ -115,8 +115,7 @@ class MixSTE2(nn.Module):
             raise _lib.PafuseError("MixSTE2 runs on the HIP device only (no CPU fallback)")
         if self.is_train:
             return self._forward_train(x_2d, x_3d, t)
-        B, P, F, J, _ = x_3d.shape
-        assert (F, J) == (self.num_frame, self.num_joints) and x_2d.shape == (B, F, J, 2) and t.shape == (B,)
+        B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()
         x_3d = x_3d.contiguous().float()
         t = t.contiguous().long()
@@ -128,6 +127,20 @@ class MixSTE2(nn.Module):
         _lib.check(lib.pafuse_mixste2_forward(C.byref(w), x_2d.data_ptr(), x_3d.data_ptr(), t.data_ptr(), B, P,
                                               out.data_ptr(), ws.data_ptr(), nbytes, stream))
         return out
+
+    def _check_inputs(self, x_2d, x_3d, t, ndim):
+        """The kernels index by (B, P, F, J): refuse anything else on the host instead of faulting on the device."""
+        if x_3d.dim() != ndim or x_3d.shape[-1] != 3:
+            raise ValueError(f"x_3d must be [B,{'P,' if ndim == 5 else ''}F,J,3], got {tuple(x_3d.shape)}")
+        B, P = x_3d.shape[0], (x_3d.shape[1] if ndim == 5 else 1)
+        F, J = x_3d.shape[-3], x_3d.shape[-2]
+        if (F, J) != (self.num_frame, self.num_joints):
+            raise ValueError(f"this MixSTE2 was built for {self.num_frame} frames x {self.num_joints} joints, got {F} x {J}")
+        if tuple(x_2d.shape) != (B, F, J, 2) or tuple(t.shape) != (B,):
+            raise ValueError(f"x_2d must be [{B},{F},{J},2] and t [{B}], got {tuple(x_2d.shape)} and {tuple(t.shape)}")
+        if x_2d.device != x_3d.device or t.device != x_3d.device:
+            raise ValueError("x_2d, x_3d and t must live on the same device")
+        return B, P, F, J
 
     # ------------------------------------------------------------------------------------------------ training
     def side_stream(self, device):
@@ -164,8 +177,7 @@ class MixSTE2(nn.Module):
         return out
 
     def _forward_train(self, x_2d, x_3d, t):
-        B, F, J, _ = x_3d.shape
-        assert (F, J) == (self.num_frame, self.num_joints) and x_2d.shape == (B, F, J, 2) and t.shape == (B,)
+        B, _, F, J = self._check_inputs(x_2d, x_3d, t, 4)
         drop = self.drop_path_factors(B, x_3d.device)
         params = [attrgetter(n)(self) for n in self._param_names]
         return _TrainFunction.apply(self, x_2d.contiguous().float(), x_3d.contiguous().float(), t.contiguous().long(),

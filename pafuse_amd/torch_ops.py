@@ -31,6 +31,12 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _need(cond, msg):
+    """host-side operand check: a kernel launched on mismatched shapes faults on the device"""
+    if not cond:
+        raise ValueError(msg)
+
+
 @lru_cache(maxsize=None)
 def mixste_param_names(frames, joints, channels, depth, heads):
     """named_parameters() order of a MixSTE2 of these dimensions (built on the meta device: no storage)."""
@@ -38,6 +44,14 @@ def mixste_param_names(frames, joints, channels, depth, heads):
         m = MixSTE2(num_frame=frames, num_joints=joints, in_chans=5, embed_dim_ratio=channels, depth=depth,
                     num_heads=heads, is_train=False)
     return tuple(n for n, _ in m.named_parameters())
+
+
+@lru_cache(maxsize=None)
+def mixste_param_shapes(frames, joints, channels, depth, heads):
+    with torch.device("meta"):
+        m = MixSTE2(num_frame=frames, num_joints=joints, in_chans=5, embed_dim_ratio=channels, depth=depth,
+                    num_heads=heads, is_train=False)
+    return tuple(tuple(p.shape) for _, p in m.named_parameters())
 
 
 _freq_cache = {}
@@ -57,7 +71,8 @@ def mixste_struct(weights, frames, joints, depth, heads):
     if len(weights) != len(names):
         raise _lib.PafuseError(f"expected {len(names)} weight tensors (named_parameters() order), got {len(weights)}")
     table = dict(zip(names, weights))
-    for n, t in table.items():
+    for (n, t), shape in zip(table.items(), mixste_param_shapes(frames, joints, channels, depth, heads)):
+        _need(tuple(t.shape) == shape, f"{n} must be {shape}, got {tuple(t.shape)}")
         _ptr(t, n)
     fr = _freqs(channels, weights[0].device)
     w = _lib.MixSTE2Weights()
@@ -70,6 +85,7 @@ def mixste_struct(weights, frames, joints, depth, heads):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, gelu: bool = False) -> torch.Tensor:
     lib = _lib.load()
     K, N = x.shape[-1], weight.shape[0]
+    _need(tuple(weight.shape) == (N, K) and bias.numel() == N, f"linear: x [..,{K}] needs weight [N,{K}] and bias [N]")
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
     _lib.check(lib.pafuse_linear(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
@@ -86,6 +102,7 @@ def _(x, weight, bias, gelu=False):
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
     lib = _lib.load()
     Cc = x.shape[-1]
+    _need(weight.numel() == Cc and bias.numel() == Cc, f"layer_norm: weight and bias must have {Cc} elements")
     x2 = x.contiguous().view(-1, Cc)
     out = torch.empty_like(x2)
     _lib.check(lib.pafuse_layernorm(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
@@ -105,6 +122,8 @@ def attention(qkv: torch.Tensor, heads: int, seq_len: int, joints: int = 0) -> t
     lib = _lib.load()
     M, C3 = qkv.shape
     Cc = C3 // 3
+    _need(C3 % 3 == 0 and heads > 0 and Cc % heads == 0 and seq_len > 0 and joints >= 0,
+          "attention: qkv must be [M, 3*heads*d]")
     if M % seq_len or (joints and M % (seq_len * joints)):
         raise _lib.PafuseError(f"attention: {M} rows do not split into sequences of {seq_len}")
     o = torch.empty(M, Cc, device=qkv.device, dtype=torch.float32)
@@ -128,6 +147,10 @@ def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int) -> torch.Ten
     if len(weights) != len(BLOCK_KEYS):
         raise _lib.PafuseError(f"block: expected {len(BLOCK_KEYS)} tensors in order {BLOCK_KEYS}")
     S, L, Cc = x.shape
+    shapes = ((Cc,), (Cc,), (3 * Cc, Cc), (3 * Cc,), (Cc, Cc), (Cc,), (Cc,), (Cc,), (2 * Cc, Cc), (2 * Cc,), (Cc, 2 * Cc), (Cc,))
+    for t, shape, name in zip(weights, shapes, BLOCK_KEYS):
+        _need(tuple(t.shape) == shape, f"block: {name} must be {shape}, got {tuple(t.shape)}")
+    _need(heads > 0 and Cc % heads == 0, "block: heads must divide the width")
     y = x.contiguous().clone()
     w = _lib.BlockWeights()
     for field, t, name in zip(_lib.BLOCK_FIELDS, weights, BLOCK_KEYS):
@@ -148,7 +171,9 @@ def _(x, weights, heads):
 def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: List[torch.Tensor], depth: int,
                 heads: int) -> torch.Tensor:
     lib = _lib.load()
+    _need(x3d.dim() == 5 and x3d.shape[-1] == 3, "mixste_eval: x3d must be [B,P,F,J,3]")
     B, P, F, J, _ = x3d.shape
+    _need(tuple(x2d.shape) == (B, F, J, 2) and tuple(t.shape) == (B,), "mixste_eval: x2d must be [B,F,J,2], t [B]")
     w, keep = mixste_struct(weights, F, J, depth, heads)
     x2d, x3d, t = x2d.contiguous().float(), x3d.contiguous().float(), t.contiguous().long()
     out = torch.empty(B, P, F, J, 3, device=x3d.device, dtype=torch.float32)
@@ -173,7 +198,12 @@ def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, we
     times[k] the k-th timestep (the last one is the step whose time_next < 0); sched 5 doubles per step:
     sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t], sqrt(alpha_next), c, sigma.  -> [B,T,P,F,J,3]"""
     lib = _lib.load()
+    _need(noise.dim() == 6 and noise.shape[-1] == 3, "ddim_loop: noise must be [n_draws,B,P,F,J,3]")
     n_draws, B, P, F, J, _ = noise.shape
+    _need(tuple(x2d.shape) == (B, F, J, 2) and (not flip or tuple(x2d_flip.shape) == (B, F, J, 2)),
+          "ddim_loop: x2d / x2d_flip must be [B,F,J,2]")
+    _need(flip_perm.numel() == J and int(flip_perm.min()) >= 0 and int(flip_perm.max()) < J, "ddim_loop: flip_perm")
+    _need(all(int(i.min()) >= 0 and int(i.max()) < J for i in part_joints), "ddim_loop: joint index out of range")
     T = len(times)
     if len(sched) != 5 * T or len(part_joints) > _lib.MAX_PARTS:
         raise _lib.PafuseError("ddim_loop: sched needs 5 values per step; at most %d parts" % _lib.MAX_PARTS)

@@ -537,6 +537,29 @@ def g15_camera_to_world():
     save("g15_camera_to_world.npz", X=X, rot=rot, out=camera_to_world(X, R=rot, t=0))
 
 
+# ------------------------------------------------------------------------------------------------- G16
+def g16_chunked_generator():
+    """ChunkedGenerator_Seq (common/generators.py:5-172) on the synthetic H3WB training subjects: shuffled,
+    flip-augmented 27-frame clips, batch size 3 - the first two batches of the first two epochs."""
+    from common.generators import ChunkedGenerator_Seq
+    from pafuse_amd import h3wb                                  # the loader is pinned by G14
+    ds = h3wb.Human3WBDataset(os.path.join(HERE, "h3wb_synth", "train_h3wb.npz"))
+    keypoints = h3wb.prepare_keypoints(ds)
+    kl, kr = ds.keypoints_metadata["keypoints_symmetry"]
+    cams, p3, p2 = h3wb.fetch(["S1", "S5"], keypoints, ds)
+    gen = ChunkedGenerator_Seq(3, cams, p3, p2, 27, pad=13, causal_shift=0, shuffle=True, augment=True,
+                               kps_left=kl, kps_right=kr, joints_left=list(ds.skeleton().joints_left()),
+                               joints_right=list(ds.skeleton().joints_right()))
+    arrays = {"num_batches": torch.tensor(gen.batch_num()), "num_pairs": torch.tensor(len(gen.pairs))}
+    for epoch in range(2):
+        for b, (cam, b3, b2) in enumerate(gen.next_epoch()):
+            if b < 2:
+                arrays[f"e{epoch}.b{b}.cam"] = torch.from_numpy(cam.copy())
+                arrays[f"e{epoch}.b{b}.p3"] = torch.from_numpy(b3.copy())
+                arrays[f"e{epoch}.b{b}.p2"] = torch.from_numpy(b2.copy())
+    save("g16_chunked_generator.npz", **arrays)
+
+
 # -------------------------------------------------------------------------------------------------- G8
 def g8_default_init():
     """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
@@ -550,10 +573,11 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
                  g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train,
-                 g14=g14_h3wb_loader, g15=g15_camera_to_world)
+                 g14=g14_h3wb_loader, g15=g15_camera_to_world,
+                 g16=g16_chunked_generator)
     for w in which:
         table[w]()

@@ -204,3 +204,35 @@ def test_training_errors_are_loud():
                                           z["t"].to(DEV).data_ptr(), 4, None, out.data_ptr(), short.data_ptr(),
                                           need // 2, torch.cuda.current_stream().cuda_stream)
     assert rc == -3 and b"too small" in lib.pafuse_last_error()
+
+
+def test_train_epoch_on_synthetic_h3wb_files_and_checkpoint_round_trip(tmp_path):
+    """files -> ChunkedClips -> train_epoch (HIP forward/backward, AdamW) -> reference-format checkpoint -> an eval-mode
+    D3DP loads it (same 636 keys) and samples."""
+    import os
+    import pafuse_amd
+    from pafuse_amd import config, h3wb, harness
+    from tests.conftest import ROOT
+    ds = h3wb.Human3WBDataset(os.path.join(ROOT, "tests", "golden", "h3wb_synth", "train_h3wb.npz"))
+    keypoints = h3wb.prepare_keypoints(ds)
+    kl, kr = (list(x) for x in ds.keypoints_metadata["keypoints_symmetry"])
+    jl, jr = list(ds.skeleton().joints_left()), list(ds.skeleton().joints_right())
+    cams, p3, p2 = h3wb.fetch(["S1", "S5"], keypoints, ds)
+    gen = h3wb.ChunkedClips(4, cams, p3, p2, 27, augment=True, kps_left=kl, kps_right=kr, joints_left=jl, joints_right=jr)
+    args = config.load(overrides=["model.dep=1"])
+    torch.manual_seed(0)
+    model = pafuse_amd.D3DP(args, jl, jr, dataset=ds, is_train=True).to(DEV).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=6e-4, weight_decay=0.1)
+    losses = [h3wb.train_epoch(model, opt, gen, ds, torch.device(DEV)) for _ in range(3)]
+    assert all(l == l and l > 0 for l in losses) and losses[-1] < losses[0], losses
+    fname = h3wb.save_state(model, opt, 3, 6e-4, str(tmp_path), random_state=gen.random_state())
+    ckpt = torch.load(fname, map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"optimizer", "epoch", "lr", "model_pos", "random_state"} and len(ckpt["model_pos"]) == 12 + 3 * 40
+    ev = pafuse_amd.D3DP(args, jl, jr, dataset=ds, is_train=False, num_proposals=2, sampling_timesteps=1)
+    harness.load_checkpoint(ev, ckpt)
+    ev = ev.to(DEV).eval()
+    x2d = harness.cut_clips(torch.as_tensor(p2[0], dtype=torch.float32)).to(DEV)      # 8 frames -> one padded clip
+    with pytest.raises(ValueError):                                                    # wrong frame count: refused
+        ev(x2d[:, :8], None, input_2d_flip=x2d[:, :8])
+    out = ev(x2d, None, input_2d_flip=harness.flip_2d(x2d, kl, kr))
+    assert out.shape == (1, 1, 2, 27, 134, 3) and bool(torch.isfinite(out).all())

@@ -206,3 +206,24 @@ def test_in_the_wild_host_helpers(tmp_path):
     z = load_golden("g15_camera_to_world.npz")
     out = harness.camera_to_world(z["X"], z["rot"])
     assert torch.allclose(out, z["out"], rtol=0, atol=1e-6)
+
+
+def test_training_clip_generator_matches_reference():
+    """pafuse_amd.h3wb.ChunkedClips against the reference's ChunkedGenerator_Seq (golden G16): item count, the
+    RandomState(1234) shuffles of two consecutive epochs, edge padding, flip augmentation of 2-D, 3-D and camera."""
+    import numpy as np
+    from pafuse_amd import h3wb
+    z = load_golden("g16_chunked_generator.npz")
+    ds = h3wb.Human3WBDataset(os.path.join(ROOT, "tests", "golden", "h3wb_synth", "train_h3wb.npz"))
+    keypoints = h3wb.prepare_keypoints(ds)
+    kl, kr = ds.keypoints_metadata["keypoints_symmetry"]
+    cams, p3, p2 = h3wb.fetch(["S1", "S5"], keypoints, ds)
+    gen = h3wb.ChunkedClips(3, cams, p3, p2, 27, shuffle=True, augment=True, kps_left=kl, kps_right=kr,
+                            joints_left=list(ds.skeleton().joints_left()), joints_right=list(ds.skeleton().joints_right()))
+    assert gen.batch_num() == int(z["num_batches"]) and len(gen.pairs) == int(z["num_pairs"])
+    for epoch in range(2):
+        for b, (cam, b3, b2) in enumerate(gen.next_epoch()):
+            if b < 2:
+                assert np.array_equal(cam, z[f"e{epoch}.b{b}.cam"].numpy())
+                assert np.array_equal(b3, z[f"e{epoch}.b{b}.p3"].numpy())
+                assert np.array_equal(b2, z[f"e{epoch}.b{b}.p2"].numpy())
