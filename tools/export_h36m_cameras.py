@@ -6,7 +6,6 @@ reference; the values are written with repr() precision so float32 conversion re
 import json
 import os
 import sys
-import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("PAFUSE_REFERENCE", "/root/reference")
@@ -14,8 +13,6 @@ REF = os.environ.get("PAFUSE_REFERENCE", "/root/reference")
 
 def main():
     sys.path.insert(0, REF)
-    for name in ("common.quaternion",):          # nothing to stub: the module only needs numpy/torch
-        pass
     from common import h36m_dataset as h
     intr = [{k: v for k, v in cam.items() if k != "azimuth"} for cam in h.h36m_cameras_intrinsic_params]
     extr = {s: cams for s, cams in h.h36m_cameras_extrinsic_params.items()}
