@@ -1,8 +1,9 @@
-"""D3DP - drop-in for the reference diffusion wrapper (common/diffusionpose.py:54-388), eval path on HIP.
+"""D3DP - drop-in for the reference diffusion wrapper (common/diffusionpose.py:54-388) on the HIP library.
 
 Same constructor, ``forward(input_2d, input_3d, input_2d_flip=None)`` and state-dict layout (12 fp64 schedule
-buffers + ``pose_estimator.{body,face,hands}.*``).  The whole DDIM loop - flip-TTA, per-part denoisers,
-fp64 epsilon, stochastic update - is one call into ``pafuse_d3dp_sample`` (include/pafuse_hip.h).
+buffers + ``pose_estimator.{body,face,hands}.*``).  Eval: the whole DDIM loop - flip-TTA, per-part denoisers,
+fp64 epsilon, stochastic update - is one call into ``pafuse_d3dp_sample`` (include/pafuse_hip.h).  Train: per-sample
+(t, noise) draws, ``pafuse_d3dp_qsample`` and the three train-mode denoisers (differentiable, HIP forward and backward).
 """
 import ctypes as C
 import math

@@ -3,7 +3,8 @@
 The module owns exactly the reference's parameters (same names, shapes, creation order and default init, so
 ``torch.manual_seed(s); MixSTE2(...)`` yields the reference's weights and ``load_state_dict`` accepts its
 checkpoints), but has no per-layer Python forward: ``forward`` hands raw device pointers to
-``pafuse_mixste2_forward`` (include/pafuse_hip.h), which runs the fused gfx950 kernels.
+``pafuse_mixste2_forward`` (include/pafuse_hip.h), which runs the fused gfx950 kernels; in train mode it is one
+autograd node over ``pafuse_mixste2_train_forward`` / ``_backward`` (DropPath factors drawn here, as timm draws them).
 """
 import ctypes as C
 import math
