@@ -484,3 +484,45 @@ def test_c_abi_from_plain_c():
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 mismatches" in out.stdout
+
+
+def test_unit_ops_on_a_seeded_sweep_of_shapes():
+    """40 seeded random shapes inside the documented limits (M tails, every N % 32 class, K up to 1152; sequence
+    lengths 1..80, head dims 4..48, contiguous and strided sequences; LayerNorm widths up to 768): each against an
+    fp64 evaluation of the same op."""
+    import random
+    from pafuse_amd import ops
+    rng = random.Random(20240607)
+    for case in range(16):
+        M, N, K = rng.randint(1, 700), 32 * rng.randint(1, 40), 32 * rng.randint(1, 36)
+        act = rng.choice([None, "gelu"])
+        x, w, b = _seeded((M, K), 100 + case), _seeded((N, K), 200 + case, K ** -0.5), _seeded((N,), 300 + case, 0.1)
+        ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+        ref = torch.nn.functional.gelu(ref) if act else ref
+        out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act).cpu().double()
+        assert torch.allclose(out, ref, rtol=0, atol=2.5e-7 * K ** 0.5 + 1e-6), ("linear", M, N, K, act)
+    for case in range(16):
+        heads = rng.choice([1, 2, 4, 8])
+        d = 4 * rng.randint(1, 12)
+        L, S = rng.randint(1, 80), rng.randint(1, 9)
+        C = heads * d
+        temporal = rng.random() < 0.5
+        if temporal:                                   # S groups of J interleaved sequences, tokens J rows apart
+            J = rng.randint(1, 7)
+            qkv = _seeded((S * L * J, 3 * C), 400 + case)
+            out = ops.attention(qkv.to(DEV), heads, S * J, L, group=J, group_stride=L * J, seq_stride=1, tok_stride=J).cpu()
+            q = qkv.view(S, L, J, 3, heads, d).permute(3, 0, 2, 4, 1, 5).double()          # 3, S, J, h, L, d
+            o = torch.softmax(q[0] @ q[1].transpose(-1, -2) * d ** -0.5, -1) @ q[2]         # S, J, h, L, d
+            ref = o.permute(0, 3, 1, 2, 4).reshape(S * L * J, C)
+        else:
+            qkv = _seeded((S * L, 3 * C), 400 + case)
+            out = ops.attention(qkv.to(DEV), heads, S, L).cpu()
+            ref = _attn_ref(qkv.double(), S, L, heads)
+        assert torch.allclose(out.double(), ref, rtol=0, atol=3e-6), ("attention", heads, d, L, S, temporal)
+    for case in range(8):
+        M, C = rng.randint(1, 300), rng.randint(1, 768)
+        x, g, b = _seeded((M, C), 500 + case), _seeded((C,), 600 + case), _seeded((C,), 700 + case)
+        eps = rng.choice([1e-5, 1e-6])
+        ref = torch.nn.functional.layer_norm(x.double(), (C,), g.double(), b.double(), eps)
+        out = ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), eps).cpu().double()
+        assert torch.allclose(out, ref, rtol=0, atol=5e-6), ("layer_norm", M, C)

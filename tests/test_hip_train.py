@@ -236,3 +236,27 @@ def test_train_epoch_on_synthetic_h3wb_files_and_checkpoint_round_trip(tmp_path)
         ev(x2d[:, :8], None, input_2d_flip=x2d[:, :8])
     out = ev(x2d, None, input_2d_flip=harness.flip_2d(x2d, kl, kr))
     assert out.shape == (1, 1, 2, 27, 134, 3) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.parametrize("F,J,C,depth,B", [(2, 1, 64, 1, 1), (5, 7, 128, 1, 2), (9, 17, 64, 2, 3), (27, 80, 64, 1, 1)])
+def test_train_gradients_vs_oracle_odd_shapes(F, J, C, depth, B):
+    """edge geometries (one joint, sequences of 80, widths 64/128, several batch sizes) against the oracle's autograd"""
+    import pafuse_amd
+    m = pafuse_amd.MixSTE2(num_frame=F, num_joints=J, in_chans=5, embed_dim_ratio=C, depth=depth, num_heads=8,
+                           drop_path_rate=0.0, is_train=True)
+    sd = {k: gu.seeded_tensor(k, v.shape, 91) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(92)
+    x2d = torch.rand(B, F, J, 2, generator=g) * 2 - 1
+    x3d = torch.randn(B, F, J, 3, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    dout = torch.randn(B, F, J, 3, generator=g)
+    out = m(x2d.to(DEV), x3d.to(DEV), t.to(DEV))
+    out.backward(dout.to(DEV))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = orc.mixste2_train(leaves, "", x2d, x3d, t, depth=depth, heads=8)
+    assert torch.allclose(out.detach().cpu(), ref.detach(), rtol=0, atol=1e-5), (out.cpu() - ref).abs().max()
+    ref.backward(dout)
+    for n, p in m.named_parameters():
+        _close(p.grad, leaves[n].grad, n)
