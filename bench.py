@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md section 3 (one denoiser pass)
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 matrix peak (opt-in --dtype bf16 runs are priced against this)
 
 
 def main():
@@ -44,6 +45,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
     ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="bf16: opt-in reduced-precision mode (bf16 matrix operands, fp32 accumulate); the contract's "
+                         "line is the f32 default")
     ap.add_argument("--train", action="store_true",
                     help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
                          "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
@@ -77,6 +81,7 @@ def main():
     model, sd = ge.make_model(P_total, T, seed=51, device=dev)
     model.n_aux_streams = args.streams
     model.use_graph = args.graph
+    model.precision = args.dtype
     sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)
     x2d, x2f = x2d.to(dev), x2f.to(dev)
@@ -107,19 +112,22 @@ def main():
     sec_per_step = elapsed / args.steps
     value = B * P_total / sec_per_step
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
+    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
 
     line = {
         "metric": "hypotheses/sec through DDIM loop (H3WB 133-kp, P=20, T=10)",
         "value": round(value, 3), "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "f32" else "bf16 operands, f32 accumulate (opt-in, not the parity path)",
+        "data": "synthetic",
         "config": {"workload": f"D3DP.forward flip-TTA DDIM loop, H3WB 27x134 clips, B={B}, P={P_local}/GPU "
                                f"(P={P_total} total), T={T}, part-based MixSTE2 body/face/hands 384/224/256 ch, depth 8",
                    "B": B, "P_per_gpu": P_local, "P_total": P_total, "T": T, "flip_tta": True,
                    "parallelism": f"hypothesis-sharded x{world} + 1 all-gather" if world > 1 else "single GPU",
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
-        "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                          "unit": "TFLOP/s", "frac": round(loop_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+        "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
+                          "unit": "TFLOP/s", "frac": round(loop_tflops / peak, 4),
                           "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"},
     }
 
@@ -153,9 +161,10 @@ def main():
             # gfx950 correction + WRITE_SIZE); rocprof cannot run inside the benchmark, so the committed summary is read.
             tj = json.load(open(tpath))
             traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
-        line["roofline"] = {"bound": "mfma", "kernel": "pafuse::gemm_kernel (v_mfma_f32_32x32x2_f32)",
-                            "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        mfma = "v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
+        line["roofline"] = {"bound": "mfma", "kernel": f"pafuse::gemm_kernel ({mfma})",
+                            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                            "frac": round(achieved / peak, 4), "traffic": traffic if args.dtype == "f32" else None,
                             "traffic_unit": "HBM bytes per launch (algorithmic: 203.5e6)", "traffic_source": traffic_src,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                             "flops_per_launch": round(flops.value / n / 1e9, 3),

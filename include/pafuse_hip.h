@@ -56,6 +56,9 @@ typedef struct pafuse_block_weights {
  * `depth` temporal blocks, `heads` heads (C % heads == 0), mlp hidden = 2C. */
 typedef struct pafuse_mixste2_weights {
     int32_t frames, joints, channels, depth, heads, in_chans; /* in_chans must be 5 (2-D + 3-D) */
+    int32_t operand_bf16; /* 0: fp32 matrix products (the parity path). 1: opt-in reduced precision - the linear layers'
+                             operands are rounded to bf16 in registers (RNE), products accumulate in fp32; activations,
+                             LayerNorm, softmax, attention and everything in memory stay fp32 (inference only) */
     const float *patch_w, *patch_b;                           /* Spatial_patch_to_embedding [C,5], [C] */
     const float *pos_spatial;                                 /* Spatial_pos_embed [J,C] */
     const float *pos_temporal;                                /* Temporal_pos_embed [F,C] */
@@ -95,7 +98,8 @@ typedef struct pafuse_ddim_step {
 const char *pafuse_version(void);
 const char *pafuse_last_error(void);
 
-/* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU.  K,N multiples of 32. */
+/* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU; +2: bf16 operands (see operand_bf16).
+ * K,N multiples of 32. */
 int pafuse_linear(const float *A, const float *W, const float *bias, float *out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void *stream);
 

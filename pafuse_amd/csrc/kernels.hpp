@@ -19,6 +19,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;   // K-chunk of the linear-layer kernels
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B stride makes the ds_read_b128 fragment reads conflict-free
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 lo, const f32x4 hi) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (__bf16)lo[i], v[4 + i] = (__bf16)hi[i];
+    return v;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // nn.GELU() default (approximate='none'): x * 0.5 * (1 + erf(x / sqrt(2)))   (common/mixste.py:25,32)
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -50,7 +58,8 @@ struct GemmParams {
     float* out;         // EPI_BIAS: [M,N]
     int64_t M;
     int N, K;
-    int act;  // EPI_BIAS: 0 none, 1 GELU
+    int bf16;  // host-side only: pick the BF16 instantiation (bf16 operands, fp32 accumulate)
+    int act;   // EPI_BIAS: 0 none, 1 GELU
     // EPI_ROWLN (the workgroup owns whole rows, N == BN; row-per-lane form only):  y = A W^T + bias + resid
     //   z  = post_w ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;  out_x = z
     //   n  = next_w ? LN(z; next) : -  ;  out_n = n   |  out_head = n @ head_w^T + head_b
@@ -106,7 +115,11 @@ struct GemmTile {
 // lane (r, h) holds output ROW r of the strip and, per 32-column block, the 16 columns {8q+4h .. 8q+4h+3}: four
 // consecutive columns per register quad = one dwordx4, a whole row's statistics = in-lane adds + one
 // xor-32 shuffle.  Epilogues then need no LDS transposition.
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
+// BF16 = 1 (opt-in reduced precision, BASELINE configs[1]): the same tiles, staging and epilogues, but the fp32
+// fragments are rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE) and multiplied by v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation: per 16-wide K step lane (r, h) contributes k = {16s + 4h + 0..3} u {16s + 8 + 4h + 0..3} - the two
+// fragments it already holds - for A and W alike, so no data moves differently; only the products are bf16 x bf16.
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
@@ -194,18 +207,33 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
         const float* Ac = As + cur * BM * LDK + a_frag;
         const float* Wc = Ws + cur * BN * LDK + w_frag;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (BF16 != 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(Ac + 8 * g);
-            f32x4 wf[NT];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 a8 = to_bf16x8(*reinterpret_cast<const f32x4*>(Ac + 16 * s2),
+                                            *reinterpret_cast<const f32x4*>(Ac + 16 * s2 + 8));
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 8 * g);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 w8 = to_bf16x8(*reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 16 * s2),
+                                                *reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 16 * s2 + 8));
+                    acc[nt] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w8, a8, acc[nt], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, w8, acc[nt], 0, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(Ac + 8 * g);
+                f32x4 wf[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][j], af[j], acc[nt], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt][j], af[j], acc[nt], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         if (NSTAGE == 1) __syncthreads();  // everyone done reading before the single buffer is refilled

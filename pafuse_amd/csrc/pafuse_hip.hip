@@ -36,14 +36,14 @@ int check_launch(const char* what) {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------ GEMM dispatch
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
     constexpr size_t stage_bytes = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
     static_assert(EPI == EPI_BIAS || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
     constexpr size_t lds = stage_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR>;
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, BF16>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -63,6 +63,11 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
+    if (p.bf16) {  // opt-in bf16-operand mode: same tiles, bf16 MFMA
+        if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 5, 0, 1>(p, s);
+        if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 1>(p, s);
+        return launch_gemm<4, 1, 1, EPI_BIAS, 1, 1, 0, 1>(p, s);
+    }
     if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 5>(p, s);   // pin 5 waves/SIMD (98 registers)
     if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>(p, s);  // row-per-lane epilogue wins at NT=3
     return launch_gemm<4, 1, 1, EPI_BIAS, 1>(p, s);
@@ -72,6 +77,18 @@ template <int EPI>
 int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
+    if constexpr (EPI == EPI_ROWLN) {
+        if (p.bf16) {
+            switch (p.N) {
+                case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1, 1>(p, s);
+                case 256: return launch_gemm<2, 2, 4, EPI, 1, 3, 1, 1>(p, s);
+                case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1, 1>(p, s);
+                case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 1>(p, s);
+                case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 1>(p, s);
+                default: break;
+            }
+        }
+    }
     switch (p.N) {
         // row-per-lane accumulators (TR): LayerNorm statistics are in-lane sums + one shuffle + a tiny cross-wave
         // exchange, all global traffic is dwordx4, no LDS transposition (picked with tools/gemm_bench.hip)
@@ -183,11 +200,12 @@ struct BlockTail {
 
 int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
               int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
-              hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
+              hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr, int bf16 = 0) {
     int rc;
     GemmParams g{};
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
+    g.bf16 = bf16;
     if ((rc = gemm_bias(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     if (!gemms_only) {
@@ -202,11 +220,13 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
     g.A = pb.o, g.W = bw.proj_w, g.bias = bw.proj_b, g.M = M, g.N = C, g.K = C;
     g.resid = pb.x, g.out_x = pb.x, g.out_n = pb.xn;
     g.next_w = bw.norm2_w, g.next_b = bw.norm2_b, g.next_eps = 1e-6f;
+    g.bf16 = bf16;
     if ((rc = gemm_rowln(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
     g = GemmParams{};
     g.A = pb.xn, g.W = bw.fc1_w, g.bias = bw.fc1_b, g.out = pb.wide, g.M = M, g.N = 2 * C, g.K = C, g.act = 1;
+    g.bf16 = bf16;
     if ((rc = gemm_bias(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
@@ -218,6 +238,7 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
     g.next_w = tail.next_w, g.next_b = tail.next_b, g.next_eps = tail.next_eps;
     g.head_w = tail.head_w, g.head_b = tail.head_b, g.out_head = tail.out_head;
     if (!tail.next_w) g.out_n = nullptr;
+    g.bf16 = bf16;
     if ((rc = gemm_rowln(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     return PAFUSE_OK;
@@ -236,7 +257,8 @@ int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, in
         t.post_w = w->snorm_w, t.post_b = w->snorm_b, t.post_eps = 1e-6f;
         if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
         t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
-        if ((rc = run_block(w->ste[i], pb, M, C, w->heads, R * F, J, 1, J, 0, 1, t, s, gemms_only, flops, launches)))
+        if ((rc = run_block(w->ste[i], pb, M, C, w->heads, R * F, J, 1, J, 0, 1, t, s, gemms_only, flops, launches,
+                            w->operand_bf16)))
             return rc;
         // temporal block i: sequences = the F frames of one (r, j); then Temporal_norm; next is norm1 of spatial
         // block i+1, or the head (LayerNorm eps 1e-5 + Linear(C,3)) after the last block.
@@ -249,7 +271,7 @@ int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, in
             t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pb.pred;
         }
         if ((rc = run_block(w->tte[i], pb, M, C, w->heads, R * J, F, J, (int64_t)F * J, 1, J, t, s, gemms_only, flops,
-                            launches)))
+                            launches, w->operand_bf16)))
             return rc;
     }
     return PAFUSE_OK;
@@ -285,7 +307,7 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
                   int32_t act, void* stream) {
     if (!A || !W || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear: null pointer or negative M");
     GemmParams g{};
-    g.A = A, g.W = W, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act;
+    g.A = A, g.W = W, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = (act >> 1) & 1;
     return gemm_bias(g, (hipStream_t)stream);
 }
 

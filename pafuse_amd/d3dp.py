@@ -112,6 +112,20 @@ class D3DP(nn.Module):
         #                                 workspace (0.9 GB per 40 rows) and keeps activations cache-resident
         self._graphs = {}
 
+    @property
+    def precision(self):
+        """'f32' (default, the parity path) or 'bf16': the denoisers' linear layers multiply bf16-rounded operands with
+        fp32 accumulation (BASELINE configs[1]); everything else, and every tensor in memory, stays fp32."""
+        return "bf16" if all(m.operand_bf16 for m in self.pose_estimator.values()) else "f32"
+
+    @precision.setter
+    def precision(self, value):
+        if value not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        for m in self.pose_estimator.values():
+            m.operand_bf16 = value == "bf16"
+        self._graphs.clear()
+
     # ------------------------------------------------------------------------------------------ schedule
     def time_pairs(self):
         """common/diffusionpose.py:279-281"""

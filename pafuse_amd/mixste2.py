@@ -89,6 +89,7 @@ class MixSTE2(nn.Module):
         self._wcache = None
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
+        self.operand_bf16 = False      # opt-in reduced precision for inference: bf16 matrix operands, fp32 accumulate
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -98,12 +99,12 @@ class MixSTE2(nn.Module):
         """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes)."""
         # attribute access, not named_parameters(): nn.DataParallel replicas keep their copies as plain attributes
         get = lambda name: attrgetter(name)(self)
-        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(),)
+        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), bool(self.operand_bf16))
         if self._wcache is not None and self._wcache[0] == key:
             return self._wcache[1]
         w = _lib.MixSTE2Weights()
         fill_weights_struct(w, get, self._freqs, self.num_frame, self.num_joints, self.embed_dim,
-                            self.block_depth, self.num_heads, self.in_chans)
+                            self.block_depth, self.num_heads, self.in_chans, self.operand_bf16)
         self._wcache = (key, w)
         return w
 
@@ -115,6 +116,8 @@ class MixSTE2(nn.Module):
         if not x_3d.is_cuda:
             raise _lib.PafuseError("MixSTE2 runs on the HIP device only (no CPU fallback)")
         if self.is_train:
+            if self.operand_bf16:
+                raise NotImplementedError("bf16 operands are an inference option; training runs in fp32")
             return self._forward_train(x_2d, x_3d, t)
         B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()
@@ -248,11 +251,12 @@ MODEL_PARAMS = (("patch_w", "Spatial_patch_to_embedding.weight"), ("patch_b", "S
                 ("hnorm_b", "head.0.bias"), ("head_w", "head.1.weight"), ("head_b", "head.1.bias"))
 
 
-def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, in_chans):
+def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, in_chans, operand_bf16=0):
     """Fill a pafuse_mixste2_weights from ``get(state-dict key) -> tensor`` (keys as in common/mixste.py)."""
     if depth > _lib.MAX_DEPTH:
         raise _lib.PafuseError(f"depth {depth} > {_lib.MAX_DEPTH}")
     w.frames, w.joints, w.channels, w.depth, w.heads, w.in_chans = frames, joints, channels, depth, heads, in_chans
+    w.operand_bf16 = int(operand_bf16)
     for field, key in MODEL_PARAMS:
         setattr(w, field, _ptr(get(key), key))
     w.freqs = _ptr(freqs, "freqs")

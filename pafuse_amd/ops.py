@@ -17,8 +17,9 @@ def _need(cond, msg):
         raise ValueError(msg)
 
 
-def linear(x, weight, bias, act=None):
-    """nn.Linear (+ exact GELU when act == 'gelu') on the last dim of a contiguous fp32 tensor."""
+def linear(x, weight, bias, act=None, bf16=False):
+    """nn.Linear (+ exact GELU when act == 'gelu') on the last dim of a contiguous fp32 tensor; bf16=True rounds both
+    operands to bf16 in registers (fp32 accumulate)."""
     lib = _lib.load()
     K = x.shape[-1]
     N = weight.shape[0]
@@ -26,7 +27,7 @@ def linear(x, weight, bias, act=None):
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
     _lib.check(lib.pafuse_linear(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
-                                 x2.shape[0], N, K, 1 if act == "gelu" else 0, _stream(x)))
+                                 x2.shape[0], N, K, (1 if act == "gelu" else 0) | (2 if bf16 else 0), _stream(x)))
     return out.view(*x.shape[:-1], N)
 
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Print how far the HIP path is from the CPU oracle on seeded inputs (pointwise and MPJPE, fp64 metric math).
 
-Run on the GPU box:  python tests/reports/parity_report.py [P T [B]]  ->  one JSON line.
+Run on the GPU box:  python tests/reports/parity_report.py [P T [B [f32|bf16]]]  ->  one JSON line
+(bf16 = the opt-in bf16-operand mode: how far it is from the fp32 oracle).
 """
 import json
 import os
@@ -20,6 +21,7 @@ from tests.test_hip_parity import _mpjpe_report  # noqa: E402
 P, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (5, 5)
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 model, sd = make_model(P, T, seed=77)
+model.precision = sys.argv[4] if len(sys.argv) > 4 else "f32"
 x2d, x2f = gu.synthetic_inputs_2d(B=B)
 noises = gu.synthetic_noises(B=B, P=P, n=T, seed=3)
 model.noise_fn = lambda k, shape, device: noises[k]
@@ -31,7 +33,7 @@ target = orc.center_pose_parts(gu.synthetic_target_3d(B))
 got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
 d = (out - ref).abs()
 print(json.dumps({
-    "B": B, "P": P, "T": T, "oracle_cpu_s": round(cpu_s, 2),
+    "B": B, "P": P, "T": T, "precision": model.precision, "oracle_cpu_s": round(cpu_s, 2),
     "pointwise_max_abs": d.max().item(), "pointwise_mean_abs": d.mean().item(),
     "per_step_max_abs": [d[:, k].max().item() for k in range(T)],
     "clamped_frac": (ref.abs() >= 1.1).float().mean().item(),

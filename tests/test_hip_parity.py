@@ -526,3 +526,37 @@ def test_unit_ops_on_a_seeded_sweep_of_shapes():
         ref = torch.nn.functional.layer_norm(x.double(), (C,), g.double(), b.double(), eps)
         out = ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), eps).cpu().double()
         assert torch.allclose(out, ref, rtol=0, atol=5e-6), ("layer_norm", M, C)
+
+
+# ------------------------------------------------------------------------------------------ bf16-operand mode
+@pytest.mark.parametrize("M,N,K", [(200, 1152, 384), (129, 448, 224), (77, 672, 224), (50, 96, 64), (33, 32, 32)])
+def test_linear_bf16_operands(M, N, K):
+    """opt-in mode: both operands rounded to bf16 (RNE), exact products, fp32 accumulation - checked against that
+    arithmetic carried out in fp64 on bf16-rounded inputs."""
+    from pafuse_amd import ops
+    x, w, b = _seeded((M, K), 1), _seeded((N, K), 2, K ** -0.5), _seeded((N,), 3, 0.1)
+    ref = torch.nn.functional.linear(x.bfloat16().double(), w.bfloat16().double(), b.double())
+    out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), bf16=True).cpu()
+    assert torch.allclose(out.double(), ref, rtol=0, atol=2.5e-7 * K ** 0.5 + 1e-6), (out - ref).abs().max()
+    plain = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+    assert not torch.equal(plain, out)                                   # it really is the other arithmetic
+
+
+def test_bf16_precision_mode_end_to_end():
+    """model.precision = 'bf16' (BASELINE configs[1]: P=5, T=5): finite, close to the fp32 result at bf16 accuracy,
+    and switching back restores the fp32 path bit for bit.  Reported, not a parity claim (tests/reports/parity_report.py
+    ... bf16 prints the distances): only gross failure is caught here."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(5, 5, seed=61)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=5, n=5, seed=21)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    f32 = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    model.precision = "bf16"
+    assert model.precision == "bf16"
+    low = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    model.precision = "f32"
+    again = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    assert torch.equal(f32, again)
+    err = (low - f32).abs()
+    assert bool(torch.isfinite(low).all()) and 0 < float(err.max()) < 0.5 and float(err.mean()) < 2e-2, (err.max(), err.mean())
