@@ -3,6 +3,8 @@
 // by piece on LDS-resident data (no global traffic), 5 workgroups of 4 waves per CU like production:
 //   V0 MFMAs on register operands      V1 + fragment reads from LDS      V2 + the two barriers per chunk
 //   V3 + the LDS refill writes         V4 = V1 with the accumulators in AGPRs (inline asm)
+//   V5 + the 6 global_load_dwordx4 of the register-staged refill (V6 half of them, V8 no s_setprio, V12 prefetch
+//   distance 2)   V7/V9/V10/V11 the refill as LDS-DMA (scratch target / after the cluster / double-buffered / 16-wide)
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_lds.hip -o build/mfma_lds ; gpurun -- ./build/mfma_lds
 #include <hip/hip_runtime.h>
 
@@ -240,6 +242,67 @@ __global__ void __launch_bounds__(256, 6) dma16_kernel(float* out, int chunks, c
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// V12: register-staged refill with a prefetch distance of TWO chunks (two staging register sets, ping-pong), so a
+// load has two MFMA clusters of its own workgroup (plus everybody else's) to land.  4 workgroups per CU.
+__global__ void __launch_bounds__(256, 4) pre2_kernel(float* out, int chunks, const float* big, int rows, int K) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Ws = smem + BM * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    for (int i = tid; i < (BM + BN) * LDK; i += 256) smem[i] = big[(i * 7 + blockIdx.x) & 65535];
+    __syncthreads();
+    f32x16 acc[2];
+    for (int n = 0; n < 2; ++n)
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+    const float* Ac = As + (wave * 32 + r) * LDK + 4 * h;
+    const float* Wc = Ws + r * LDK + 4 * h;
+    const int tile_row0 = (blockIdx.x * 192) % (rows - 192);
+    const float* gbase = big + (size_t)(tile_row0 + (tid >> 3)) * K + (tid & 7) * 4;
+    const int nkc = K / 32;
+    f32x4 sa[6], sb[6];
+    auto load = [&](f32x4* st, int kc) {
+        const float* gp = gbase + (kc % nkc) * 32;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st[i] = *reinterpret_cast<const f32x4*>(gp + (size_t)32 * i * K);
+    };
+    auto store = [&](const f32x4* st) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(smem + ((tid >> 3) + 32 * i) * LDK + (tid & 7) * 4) = st[i];
+    };
+    auto cluster = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(Ac + 8 * g);
+            f32x4 wf[2];
+            wf[0] = *reinterpret_cast<const f32x4*>(Wc + 8 * g);
+            wf[1] = *reinterpret_cast<const f32x4*>(Wc + 32 * LDK + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], wf[nt][j], acc[nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    load(sa, 1);
+    for (int kc = 0; kc < chunks; kc += 2) {
+        load(sb, kc + 2);   // two ahead
+        cluster();          // chunk kc (in LDS)
+        __syncthreads();
+        store(sa);          // chunk kc+1
+        __syncthreads();
+        load(sa, kc + 3);
+        cluster();          // chunk kc+1
+        __syncthreads();
+        store(sb);          // chunk kc+2
+        __syncthreads();
+    }
+    float s = 0;
+    for (int n = 0; n < 2; ++n)
+        for (int i = 0; i < 16; ++i) s += acc[n][i];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int MINW>
 void run_dma(const char* what, float* out, const float* big, int rows, int wgs_per_cu) {
     const int blocks = 256 * wgs_per_cu, chunks = 3000;
@@ -321,6 +384,23 @@ int main() {
         }
         const double flops = (double)blocks * 4 * chunks * 32 * 4096.0;
         printf("%-46s %.2f ms  %.1f TFLOP/s (%.0f %% of 157.3)\n", "V10 double-buffered DMA, swizzled, 3 WG/CU", ms,
+               flops / ms / 1e9, flops / ms / 1e9 / 1.573);
+    }
+    for (int wpc : {3, 4}) {
+        const int blocks = 256 * wpc, chunks = 3000;
+        const size_t lds = (size_t)(BM + BN) * LDK * 4;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0), hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(pre2_kernel, dim3(blocks), dim3(256), lds, 0, out, chunks, big, 26112, 384);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        const double flops = (double)blocks * 4 * chunks * 32 * 4096.0;
+        printf("V12 register staging, prefetch distance 2, %d WG/CU  %.2f ms  %.1f TFLOP/s (%.0f %% of 157.3)\n", wpc, ms,
                flops / ms / 1e9, flops / ms / 1e9 / 1.573);
     }
     for (int wpc : {4, 6}) {
