@@ -48,6 +48,11 @@ def main():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="bf16: opt-in reduced-precision mode (bf16 matrix operands, fp32 accumulate); the contract's "
                          "line is the f32 default")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend for N > 1: nccl (= RCCL over xGMI, the contract's line); gloo only for "
+                         "rehearsing the N > 1 code path on a box with fewer GPUs than ranks (with --single-device)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (never a performance number; needs --backend gloo)")
     ap.add_argument("--train", action="store_true",
                     help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
                          "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
@@ -56,24 +61,32 @@ def main():
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
-    from tests.golden import golden_util as gu
+    from pafuse_amd import synthetic as gu
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if args.single_device:
+        if args.backend != "gloo":
+            raise SystemExit("--single-device shares one GPU between the ranks: RCCL cannot, use --backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where the small collective operands live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     ge.build()
     if args.train:
         return train_bench(args, rank, local_rank, world, dev)
     from pafuse_amd import _lib
-    from pafuse_amd.parallel import ShardedSampler
+    from pafuse_amd.parallel import ShardedSampler, gather_hypotheses, rank_census, shard_range
     import ctypes as C
 
     B, T, P_local = args.batch, args.timesteps, args.proposals
@@ -106,10 +119,27 @@ def main():
     elapsed = time.perf_counter() - t0
     assert out.shape == (B, T, P_total, 27, 134, 3) and bool(torch.isfinite(out).all())
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     sec_per_step = elapsed / args.steps
+    # what the collective layer saw (one all-gather of (rank, local hypothesis count)) and the all-gather's own cost
+    lo, hi = shard_range(P_total, rank, world)
+    census = rank_census(hi - lo)
+    if census["ranks_seen"] != world or sum(census["P_local"]) != P_total:
+        raise SystemExit(f"rank census {census} does not match --gpus {world} x {P_local} hypotheses")
+    gather_ms = None
+    if world > 1:
+        local = out[:, :, lo:hi].contiguous()
+        gather_hypotheses(local, P_total)                      # warm-up
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gather_hypotheses(local, P_total)
+        fence()
+        gt = torch.tensor([(time.perf_counter() - t0) / 5], dtype=torch.float64, device=cdev)
+        dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+        gather_ms = round(float(gt.item()) * 1e3, 3)
     value = B * P_total / sec_per_step
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
@@ -125,7 +155,12 @@ def main():
                                f"(P={P_total} total), T={T}, part-based MixSTE2 body/face/hands 384/224/256 ch, depth 8",
                    "B": B, "P_per_gpu": P_local, "P_total": P_total, "T": T, "flip_tta": True,
                    "parallelism": f"hypothesis-sharded x{world} + 1 all-gather" if world > 1 else "single GPU",
+                   "collective_backend": (("nccl (RCCL)" if args.backend == "nccl" else "gloo (REHEARSAL, not a "
+                                           "performance number)") if world > 1 else None),
+                   "single_device_rehearsal": bool(args.single_device),
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
+        "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
+        "allgather_ms": gather_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
                           "unit": "TFLOP/s", "frac": round(loop_tflops / peak, 4),
                           "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"},
@@ -154,18 +189,41 @@ def main():
         ms = e0.elapsed_time(e1)
         n = launches * reps
         achieved = flops.value / (ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10):
-            # HBM bytes per gemm_kernel launch from rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the
-            # gfx950 correction + WRITE_SIZE); rocprof cannot run inside the benchmark, so the committed summary is read.
+        # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
+        # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
+        traffic, traffic_info = None, {"traffic_source": None}
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10) and args.dtype == "f32":
             tj = json.load(open(tpath))
-            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), "profiles/r01_pmc_traffic.json"
+            if tj.get("kernel_source_sha256") == _lib.kernel_source_digest():
+                traffic = round(tj["traffic_bytes_per_launch"])
+                traffic_info = {"traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                  "FETCH doubled per the gfx950 correction)",
+                                "hbm_GBps_dominant_kernel": round(traffic / (ms * 1e-3 / n) / 1e9, 1),
+                                "hbm_GBps_by_kernel_family": tj.get("hbm_GBps_by_kernel_family")}
+            else:
+                traffic_info = {"traffic_source": "profiles/r02_pmc_traffic.json is from other kernel sources "
+                                                  "(kernel_source_sha256 differs): not quoted"}
+        # algorithmic bytes per launch, two ways: (i) this design's launch boundaries (every GEMM reads A and W and
+        # writes its outputs; whole-row kernels also read the residual and write x and xn); (ii) SURVEY 8(d)'s fused
+        # figure - weights once per pass + one read and one write of the residual stream per block:
+        # 140 MB + 2*16*sum(M*C)*4 B per flip-TTA pass, over the pass' GEMM launches
+        rows = 2 * B * P_local * 27
+        mc = rows * (24 * 384 + 68 * 224 + 42 * 256)
+        # (i) per token and block: qkv reads C writes 3C; proj reads o, x writes x, xn; fc1 reads C writes 2C; fc2 reads
+        #     2C, x writes x, xn = 16 C floats; 16 blocks per pass; + the 139.8 MB of weights once
+        alg_unfused = (mc * 4 * 16 * 16 + 139.8e6) / launches
+        alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
         mfma = "v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse::gemm_kernel ({mfma})",
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                            "frac": round(achieved / peak, 4), "traffic": traffic if args.dtype == "f32" else None,
-                            "traffic_unit": "HBM bytes per launch (algorithmic: 203.5e6)", "traffic_source": traffic_src,
+                            "frac": round(achieved / peak, 4), "traffic": traffic,
+                            "traffic_unit": "HBM bytes per launch",
+                            "algorithmic_bytes_per_launch": {"this_design_unfused_between_gemms": round(alg_unfused),
+                                                             "survey_8d_fused_blocks": round(alg_fused)},
+                            "traffic_over_algorithmic": None if traffic is None else {
+                                "vs_unfused": round(traffic / alg_unfused, 2), "vs_survey_8d": round(traffic / alg_fused, 2)},
+                            **traffic_info,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                             "flops_per_launch": round(flops.value / n / 1e9, 3),
                             "flops_unit": "GFLOP (algorithmic 2*M*N*K)"}
@@ -218,7 +276,7 @@ def train_bench(args, rank, local_rank, world, dev):
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
-    from tests.golden import golden_util as gu
+    from pafuse_amd import synthetic as gu
 
     B = args.batch if args.batch > 1 else 37
     model, _ = ge.make_model(1, 1, seed=51, device=dev, is_train=True)

@@ -50,7 +50,7 @@ def main():
                             num_proposals=args.ft2d.num_proposals, sampling_timesteps=args.ft2d.sampling_timesteps)
     print("INFO: Trainable parameter count:", sum(p.numel() for p in model.parameters()) / 1e6, "Million")
     if a.checkpoint:
-        ckpt = torch.load(a.checkpoint, map_location="cpu")
+        ckpt = harness.read_checkpoint(a.checkpoint)    # holds a pickled numpy RandomState: weights_only=False
         print("This model was trained for {} epochs".format(ckpt.get("epoch", "?")))
         harness.load_checkpoint(model, ckpt)
     model = model.to(f"cuda:{local}").eval()

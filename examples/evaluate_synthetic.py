@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
 from pafuse_amd import harness  # noqa: E402
-from tests.golden import golden_util as gu  # noqa: E402
+from pafuse_amd import synthetic as gu  # noqa: E402
 
 
 def main():
@@ -39,7 +39,7 @@ def main():
     ge.build()
     model, _ = ge.make_model(a.proposals, a.timesteps, device=f"cuda:{local}")
     if a.checkpoint:
-        harness.load_checkpoint(model, torch.load(a.checkpoint, map_location="cpu"))
+        harness.load_checkpoint(model, harness.read_checkpoint(a.checkpoint))
         model = model.to(f"cuda:{local}").eval()
     ds = SimpleNamespace(parts_joint_indices=gu.DATASET_PART_JOINTS, root_indices=gu.ROOT_INDICES,
                          parts_connection_indices=dict(gu.CONNECTION_INDICES))

@@ -56,7 +56,7 @@ def main():
     model = pafuse_amd.D3DP(args, kps_left, kps_right, dataset=dataset, is_train=False,
                             num_proposals=args.ft2d.num_proposals, sampling_timesteps=args.ft2d.sampling_timesteps)
     if a.checkpoint:
-        harness.load_checkpoint(model, torch.load(a.checkpoint, map_location="cpu"))
+        harness.load_checkpoint(model, harness.read_checkpoint(a.checkpoint))
     model = model.cuda().eval()
 
     pixels = harness.load_pifpaf_keypoints(a.keypoints, args.data.num_kps)

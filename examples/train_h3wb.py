@@ -53,9 +53,10 @@ def main():
     cams, poses_3d, poses_2d = h3wb.fetch(args.data.subjects_train.split(","), keypoints, dataset,
                                           stride=args.experiment.downsample, action_filter=action_filter)
     generator = h3wb.ChunkedClips(args.model.batch_size // args.model.number_of_frames, cams, poses_3d, poses_2d,
-                                  args.model.number_of_frames, shuffle=True, random_seed=1234 + rank,
+                                  args.model.number_of_frames, shuffle=True, random_seed=1234,
                                   augment=args.model.data_augmentation, kps_left=kps_left, kps_right=kps_right,
-                                  joints_left=joints_left, joints_right=joints_right)
+                                  joints_left=joints_left, joints_right=joints_right,
+                                  shard=(rank, world) if world > 1 else None)   # rank's slice of the global batch
     log("INFO: Training on {} frames".format(sum(p.shape[0] for p in poses_2d)))
 
     model = pafuse_amd.D3DP(args, joints_left, joints_right, dataset=dataset, is_train=True).to(dev).train()
@@ -65,7 +66,8 @@ def main():
     optimizer = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=0.1)
     for epoch in range(args.model.epochs):
         t0 = time.time()
-        loss = h3wb.train_epoch(net, optimizer, generator, dataset, dev, wb_loss=args.model.wb_loss, log=log)
+        loss = h3wb.train_epoch(net, optimizer, generator, dataset, dev, wb_loss=args.model.wb_loss, log=log,
+                                mse_loss=args.model.mse_loss, weighted_loss=args.model.weighted_loss)
         log("[%d] time %.2f lr %f 3d_train %f" % (epoch + 1, (time.time() - t0) / 60, lr, loss * 1000))
         lr *= args.model.lr_decay
         for group in optimizer.param_groups:

@@ -17,6 +17,10 @@
  *   pafuse_mixste2_forward   MixSTE2.forward (is_train=False), common/mixste.py:278-298
  *   pafuse_d3dp_sample       D3DP.ddim_sample_flip / ddim_sample, common/diffusionpose.py:227-316
  *                            (with model_predictions[_fliping] :174-225, pred_parts/split_data :163-172,328-335)
+ *   pafuse_embed             the input stage of model_predictions_fliping + split_data + the first lines of
+ *                            MixSTE2.STE_forward: common/diffusionpose.py:193-198,328-335, common/mixste.py:227-235
+ *   pafuse_ddim_finalize     the output stage of a DDIM step: part concat + un-flip + TTA mean + clamp
+ *                            (common/diffusionpose.py:165-171,211-218), epsilon in fp64 (:157-161,222-223), update (:302-312)
  *   pafuse_hypothesis_errors the per-joint part of evaluate()'s aggregation, main_h3wb.py:327-362
  *   pafuse_mixste2_train_*   MixSTE2.forward (is_train=True) + autograd backward, common/mixste.py:215-225,260-298
  *   pafuse_d3dp_qsample      D3DP.prepare_diffusion_concat / q_sample, common/diffusionpose.py:319-326,358-374
@@ -77,7 +81,9 @@ typedef struct pafuse_d3dp_config {
     int32_t num_kps;                   /* 134 */
     int32_t frames;                    /* 27 */
     int32_t flip;                      /* 1: ddim_sample_flip, 0: ddim_sample */
-    float scale;                       /* args.ft2d.scale */
+    double scale;                      /* args.ft2d.scale (a Python float in the reference: the clamp bound is
+                                          (float)(1.1 * scale) formed in fp64, multiplier / divisor are (float)scale,
+                                          exactly as torch demotes Python scalars against fp32 tensors) */
     pafuse_mixste2_weights part[PAFUSE_MAX_PARTS];
     const int32_t *part_joints[PAFUSE_MAX_PARTS]; /* device: joint indices of each part (split_data) */
     const int32_t *joint_part;         /* device [num_kps]: part id of every joint */
@@ -143,6 +149,43 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *st
                        const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,
                        int32_t P, float *out, void *workspace, size_t workspace_bytes, void *stream,
                        void *const *aux_streams, int32_t n_aux);
+
+/* Number of distinct HIP streams pafuse_d3dp_sample will launch on when handed `n_aux` aux streams (the caller's
+ * stream + the first (result - 1) aux streams).  A caller that forks its aux streams into a stream capture must fork
+ * exactly those: the library joins the streams it used, an extra forked stream would leave the capture unjoined. */
+int pafuse_d3dp_lanes(const pafuse_d3dp_config *cfg, int32_t B, int32_t P, int32_t n_aux);
+
+/* ---- the two index-carrying stages of a DDIM step as unit entry points (SURVEY.md 8b "finer ops") ---------------
+ * pafuse_embed: input stage of one body part.  For every row (fl, b, p, f, j) of the part's token matrix
+ * (fl < nflip; row = (((fl*B + b)*P + p)*F + f)*J + j):
+ *   jj = joints ? joints[j] : j                      split_data's gather            diffusionpose.py:328-335
+ *   v3 = x3d[b, p, f, fl ? perm[jj] : jj, :]         L/R swap of the flipped copy   diffusionpose.py:197-198
+ *   if do_clamp: v3 = clamp(v3, +-1.1*scale) / scale                                diffusionpose.py:193-194
+ *   if fl: v3.x = -v3.x                                                             diffusionpose.py:196
+ *   v2 = (fl ? x2d_flip : x2d)[b, f, jj, :]          2-D input broadcast over P     mixste.py:228-229
+ *   x[row]  = patch_w [v2, v3] + patch_b + pos_spatial[j] + temb[b]                 mixste.py:230-235
+ *   xn[row] = LayerNorm(x[row]; norm_w, norm_b, norm_eps)                           (norm1 of the first block)
+ * x3d [B,P,F,J3,3], x2d/x2d_flip [B,F,J3,2], joints int32 [J] (values < J3; NULL = identity, needs J3 == J),
+ * perm int32 [J3] (needed when nflip == 2), patch_w [C,5], patch_b [C], pos_spatial [J,C], temb [B,C],
+ * x / xn [nflip*B*P*F*J, C].  C % 4 == 0, C <= 384.  The index tables live on the device and are trusted. */
+int pafuse_embed(const float *x3d, const float *x2d, const float *x2d_flip, const int32_t *joints, const int32_t *perm,
+                 const float *patch_w, const float *patch_b, const float *pos_spatial, const float *temb,
+                 const float *norm_w, const float *norm_b, float norm_eps, int32_t B, int32_t P, int32_t F, int32_t J,
+                 int32_t J3, int32_t C, int32_t nflip, int32_t do_clamp, double scale, float *x, float *xn, void *stream);
+
+/* pafuse_ddim_finalize: output stage of DDIM step `step` of T.  pred[i] = part i's denoiser output
+ * [nflip*B*P*F*part_joints[i], 3] (host array of `num_parts` device pointers; flipped half second).  Per (b,p,f,j):
+ *   x0 = pred[joint_part[j]][.., joint_local[j], :]                       torch.cat(dim=-2)   diffusionpose.py:171
+ *   if flip: u = flipped prediction of joint flip_perm[j], u.x = -u.x ; x0 = (x0 + u) / 2     :211-215
+ *   x0 = clamp(x0 * scale, +-1.1*scale) -> out[b, step, p, f, j, :]                            :216-218, :298
+ *   last step: img = x0.  Otherwise eps = (sqrt_recip_acp*img - x0) / sqrt_recipm1_acp in fp64 (:157-161) and
+ *   img = x0*sqrt_alpha_next + c*eps + sigma*noise (:308-312; scalar demotion as torch does it per sampler).
+ * img [B,P,F,J,3] in/out, noise [B,P,F,J,3] (may be NULL on the last step), out [B,T,P,F,J,3];
+ * joint_part / joint_local / flip_perm int32 [J] on the device (trusted). */
+int pafuse_ddim_finalize(const float *const *pred, const int32_t *part_joints, int32_t num_parts,
+                         const int32_t *joint_part, const int32_t *joint_local, const int32_t *flip_perm, float *img,
+                         const float *noise, float *out, int32_t B, int32_t P, int32_t F, int32_t J, int32_t T,
+                         int32_t step, int32_t flip, double scale, const pafuse_ddim_step *st, void *stream);
 
 /* Hypothesis aggregation on the gathered predictions - the caller-side step of main_h3wb.py:327-362
  * (wb_pose_from_parts common/utils.py:113-126, project_to_2d common/camera.py:30-60, the per-joint parts of

@@ -37,7 +37,7 @@ class MixSTE2Weights(C.Structure):
 
 class D3DPConfig(C.Structure):
     _fields_ = [("num_parts", C.c_int32), ("num_kps", C.c_int32), ("frames", C.c_int32), ("flip", C.c_int32),
-                ("scale", C.c_float),
+                ("scale", C.c_double),
                 ("part", MixSTE2Weights * MAX_PARTS),
                 ("part_joints", C.c_void_p * MAX_PARTS),
                 ("joint_part", C.c_void_p), ("joint_local", C.c_void_p), ("flip_perm", C.c_void_p)]
@@ -71,6 +71,11 @@ SIGNATURES = {
     "pafuse_d3dp_sample": (C.c_int, [C.POINTER(D3DPConfig), C.POINTER(DDIMStep), C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
+    "pafuse_d3dp_lanes": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_int32]),
+    "pafuse_embed": (C.c_int, [C.c_void_p] * 11 + [C.c_float] + [C.c_int32] * 8 + [C.c_double, C.c_void_p, C.c_void_p,
+                                                                                    C.c_void_p]),
+    "pafuse_ddim_finalize": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32] + [C.c_void_p] * 6 +
+                             [C.c_int32] * 7 + [C.c_double, C.POINTER(DDIMStep), C.c_void_p]),
     "pafuse_hypothesis_errors": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 7),
     "pafuse_d3dp_replay_gemms": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.POINTER(C.c_double)]),
@@ -85,6 +90,22 @@ SIGNATURES = {
 }
 
 _lib = None
+
+KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
+                  "pafuse_amd/csrc/train_host.inc", "include/pafuse_hip.h")
+
+
+def kernel_source_digest():
+    """SHA-256 over the native sources the library is built from.  Measurements kept under profiles/ carry it, and
+    bench.py only quotes a committed counter profile whose digest equals the running tree's (the GPU box has no .git)."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(rel.encode())
+        with open(os.path.join(root, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 class PafuseError(RuntimeError):

@@ -17,7 +17,7 @@ DEFAULTS = {
     "model": {"diff_model": "MixSTE2", "number_of_frames": 27, "stride": 27, "batch_size": 1024,
               "test_time_augmentation": True, "input_size": 5, "dep": 8, "cs": 288, "epochs": 400,
               "data_augmentation": True, "learning_rate": 0.00006, "lr_decay": 0.993, "wb_loss": False,
-              "mse_loss": False},
+              "mse_loss": False, "weighted_loss": False},
     "ft2d": {"scale": 1.0, "timestep": 1000, "sampling_timesteps": 5, "num_proposals": 10, "debug": False, "p2": False},
 }
 

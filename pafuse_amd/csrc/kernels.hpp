@@ -713,7 +713,8 @@ struct EmbedParams {
     float *x, *xn;  // [M,C]
     int B, P, F, J, J3, C, nflip;
     int do_clamp;
-    float scale;
+    float scale;  // (float)args.ft2d.scale: the divisor, as torch demotes the Python scalar
+    float lim;    // (float)(1.1 * scale) formed in fp64 on the host, as torch.clamp demotes its Python-float bound
     int64_t row0, nrows;  // this launch embeds rows [row0, row0 + nrows) of the part's token matrix
 };
 
@@ -738,7 +739,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
     const float* s3 = p.x3d + ((((int64_t)b * p.P + pp) * p.F + f) * p.J3 + j3) * 3;
     float in[5] = {s2[0], s2[1], s3[0], s3[1], s3[2]};
     if (p.do_clamp) {
-        const float lim = 1.1f * p.scale;
+        const float lim = p.lim;
 #pragma unroll
         for (int i = 2; i < 5; ++i) in[i] = fminf(fmaxf(in[i], -lim), lim) / p.scale;
     }
@@ -816,7 +817,7 @@ struct FinalizeParams {
     const float* noise;  // [B,P,F,J,3] or null when last
     float* out;          // [B,T,P,F,J,3]
     int B, P, F, J, T, step, flip, last;
-    float scale;
+    float scale, lim;  // (float)scale and (float)(1.1 * scale) (fp64 product), see EmbedParams
     double sr, srm1, c;
     float an_f, c_f, sigma_f;
 };
@@ -841,7 +842,7 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
         x0[1] = __fdiv_rn(__fadd_rn(x0[1], u[1]), 2.0f);
         x0[2] = __fdiv_rn(__fadd_rn(x0[2], u[2]), 2.0f);
     }
-    const float lim = 1.1f * p.scale;
+    const float lim = p.lim;
     float* o = p.out + ((((int64_t)b * p.T + p.step) * p.P + pp) * p.F + f) * p.J * 3 + j * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -35,6 +35,40 @@ int check_launch(const char* what) {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// "first call on the current device" latch for per-device function attributes (benign race: the guarded call is
+// idempotent).  A failing hipGetDevice reports "first" every time, which is merely slower.
+struct DeviceOnce {
+    static constexpr int MAX_DEV = 64;
+    bool done[MAX_DEV] = {};
+    bool first() {
+        int d = -1;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) return true;
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
+
+// Makes the device of the caller's stream current for the duration of an entry point (kernel launches, events and
+// function attributes go to the CURRENT device): a caller whose tensors live on cuda:1 while cuda:0 is current
+// would otherwise record events on the wrong device.  The legacy null stream belongs to the current device.
+struct StreamDevice {
+    int prev = -1;
+    bool switched = false;
+    explicit StreamDevice(void* stream) {
+        hipDevice_t d = -1;
+        if (stream && hipStreamGetDevice((hipStream_t)stream, &d) == hipSuccess && hipGetDevice(&prev) == hipSuccess &&
+            d >= 0 && d != prev)
+            switched = hipSetDevice(d) == hipSuccess;
+        (void)hipGetLastError();  // a failed query must not surface as the next launch's error
+    }
+    ~StreamDevice() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    StreamDevice(const StreamDevice&) = delete;
+    StreamDevice& operator=(const StreamDevice&) = delete;
+};
+
 // ------------------------------------------------------------------------------------------------ GEMM dispatch
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
@@ -44,10 +78,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds = stage_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, BF16>;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    if (lds > 64 * 1024) {
+        static DeviceOnce once;  // the attribute is per device (one-process multi-device callers: nn.DataParallel)
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
     const int64_t tiles_m = (p.M + T::BM - 1) / T::BM;
     const int64_t tiles = tiles_m * (p.N / T::BN);
@@ -305,6 +338,7 @@ const char* pafuse_last_error(void) { return g_err; }
 
 int pafuse_linear(const float* A, const float* W, const float* bias, float* out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!A || !W || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear: null pointer or negative M");
     GemmParams g{};
     g.A = A, g.W = W, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = (act >> 1) & 1;
@@ -313,6 +347,7 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
 
 int pafuse_layernorm(const float* x, const float* w, const float* b, float* out, int64_t M, int32_t C, float eps,
                      void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!x || !w || !b || !out || M < 0) return fail(PAFUSE_E_ARG, "layernorm: null pointer or negative M");
     if (C <= 0 || C > 64 * LN_MAX_PER_LANE) return fail(PAFUSE_E_SHAPE, "layernorm: C=%d out of range", C);
     if (M == 0) return PAFUSE_OK;
@@ -323,6 +358,7 @@ int pafuse_layernorm(const float* x, const float* w, const float* b, float* out,
 
 int pafuse_attention(const float* qkv, float* o, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group,
                      int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!qkv || !o || nseq < 0 || heads <= 0 || C % heads || group <= 0)
         return fail(PAFUSE_E_ARG, "attention: bad argument");
     AttnParams a{};
@@ -336,8 +372,11 @@ size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C) { return part_buffe
 
 int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int32_t L, int32_t C, int32_t heads,
                          void* workspace, size_t workspace_bytes, void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!w || !x || !workspace || S < 0) return fail(PAFUSE_E_ARG, "block_forward: bad argument");
     if (!width_supported(C)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", C);
+    if (heads <= 0 || C % heads) return fail(PAFUSE_E_SHAPE, "block_forward: heads %d must divide C %d", heads, C);
+    if (L <= 0) return fail(PAFUSE_E_SHAPE, "block_forward: sequence length %d", L);
     const int64_t M = S * L;
     if (workspace_bytes < pafuse_block_workspace_bytes(M, C)) return fail(PAFUSE_E_WORKSPACE, "workspace too small");
     if (M == 0) return PAFUSE_OK;
@@ -353,6 +392,7 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
 
 int pafuse_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int32_t B, float* temb, float* hid_scratch,
                       void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!w || !t || !temb || B <= 0) return fail(PAFUSE_E_ARG, "time_embed: bad argument");
     if (w->channels % 2 || w->channels > 1024) return fail(PAFUSE_E_SHAPE, "time_embed: C=%d", w->channels);
     if (!hid_scratch) return fail(PAFUSE_E_ARG, "time_embed: null scratch");
@@ -366,6 +406,7 @@ size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights* w, int32_t B
 
 int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, const float* x3d, const int64_t* t,
                            int32_t B, int32_t P, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    StreamDevice on_stream_device(stream);
     int rc = check_weights(w);
     if (rc) return rc;
     if (!x2d || !x3d || !t || !out || !workspace || B <= 0 || P <= 0)
@@ -382,7 +423,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
     e.x = pb.x, e.xn = pb.xn;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
-    e.do_clamp = 0, e.scale = 1.f, e.row0 = 0, e.nrows = M;
+    e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
     if ((rc = check_launch("embed_kernel"))) return rc;
     if ((rc = run_mixste_layers(w, pb, R, s))) return rc;
@@ -421,6 +462,7 @@ static int d3dp_check(const pafuse_d3dp_config* cfg, int B, int P) {
 int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* steps, int32_t nsteps, const float* x2d,
                        const float* x2d_flip, const float* noise, int32_t n_draws, int32_t B, int32_t P, float* out,
                        void* workspace, size_t workspace_bytes, void* stream, void* const* aux_streams, int32_t n_aux) {
+    StreamDevice on_stream_device(stream);
     int rc = d3dp_check(cfg, B, P);
     if (rc) return rc;
     if (!steps || nsteps <= 0 || !x2d || !noise || !out || !workspace || (cfg->flip && !x2d_flip) || n_draws < 1)
@@ -470,10 +512,14 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
         }
     }
     bool forked = false;  // lanes hold work the main stream has not waited for yet
+    hipError_t sync_err = hipSuccess;  // first failing event call: a missed fork/join would be a silent race
+    auto note = [&](hipError_t e) {
+        if (e != hipSuccess && sync_err == hipSuccess) sync_err = e;
+    };
     auto join = [&]() {
         for (int i = 1; i < lanes; ++i) {
-            hipEventRecord(ev_join[i], lane_stream(i));
-            hipStreamWaitEvent(s0, ev_join[i], 0);
+            note(hipEventRecord(ev_join[i], lane_stream(i)));
+            note(hipStreamWaitEvent(s0, ev_join[i], 0));
         }
         forked = false;
     };
@@ -485,9 +531,13 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             rc = launch_time_embed(&cfg->part[i], nullptr, st.time, B, pb[i].temb, pb[i].wide, s0);
         if (rc) break;
         if (multi) {
-            hipEventRecord(ev_fork, s0);
-            for (int i = 1; i < lanes; ++i) hipStreamWaitEvent(lane_stream(i), ev_fork, 0);
+            note(hipEventRecord(ev_fork, s0));
+            for (int i = 1; i < lanes; ++i) note(hipStreamWaitEvent(lane_stream(i), ev_fork, 0));
             forked = true;
+            if (sync_err != hipSuccess) {
+                rc = fail(PAFUSE_E_HIP, "d3dp_sample: stream fork failed: %s", hipGetErrorString(sync_err));
+                break;
+            }
         }
         for (int lane = 0; lane < lanes && rc == PAFUSE_OK; ++lane) {
             const int i = lane % NP, gi = lane / NP;
@@ -501,20 +551,26 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
             e.x = pb[i].x, e.xn = pb[i].xn;
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
-            e.do_clamp = 1, e.scale = cfg->scale, e.row0 = row0, e.nrows = nrows;
+            e.do_clamp = 1, e.scale = (float)cfg->scale, e.lim = (float)(1.1 * cfg->scale), e.row0 = row0, e.nrows = nrows;
             hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)),
                                dim3(256), 0, ls, e);
             if ((rc = check_launch("embed_kernel"))) break;
             rc = run_mixste_layers(w, offset_rows(pb[i], row0, w->channels), r1 - r0, ls);
         }
         if (rc) break;
-        if (multi) join();
+        if (multi) {
+            join();
+            if (sync_err != hipSuccess) {
+                rc = fail(PAFUSE_E_HIP, "d3dp_sample: stream join failed: %s", hipGetErrorString(sync_err));
+                break;
+            }
+        }
         FinalizeParams f{};
         for (int i = 0; i < NP; ++i) f.pred[i] = pb[i].pred, f.Jp[i] = cfg->part[i].joints;
         f.joint_part = cfg->joint_part, f.joint_local = cfg->joint_local, f.perm = cfg->flip_perm;
         f.img = img, f.noise = st.last ? nullptr : noise + (int64_t)draw * img_elems, f.out = out;
         f.B = B, f.P = P, f.F = F, f.J = J, f.T = nsteps, f.step = k, f.flip = cfg->flip, f.last = st.last;
-        f.scale = cfg->scale, f.sr = st.sqrt_recip_acp, f.srm1 = st.sqrt_recipm1_acp, f.c = st.c;
+        f.scale = (float)cfg->scale, f.lim = (float)(1.1 * cfg->scale), f.sr = st.sqrt_recip_acp, f.srm1 = st.sqrt_recipm1_acp, f.c = st.c;
         f.an_f = (float)st.sqrt_alpha_next, f.c_f = (float)st.c, f.sigma_f = (float)st.sigma;
         const int64_t n = (int64_t)B * P * F * J;
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s0, f);
@@ -523,16 +579,87 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     }
     if (multi) {
         if (forked) join();  // error exit mid-step: the caller's stream still orders after everything launched
+        // aux streams beyond the lanes in use did no work: nothing to join (callers that capture the call into a graph
+        // must fork only the first pafuse_d3dp_lanes(...) - 1 aux streams, see include/pafuse_hip.h)
         hipEventDestroy(ev_fork);
         for (int i = 1; i < lanes; ++i) hipEventDestroy(ev_join[i]);
+        if (rc == PAFUSE_OK && sync_err != hipSuccess)
+            rc = fail(PAFUSE_E_HIP, "d3dp_sample: stream join failed: %s", hipGetErrorString(sync_err));
     }
     return rc;
+}
+
+int pafuse_d3dp_lanes(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, int32_t n_aux) {
+    if (!cfg || B <= 0 || P <= 0 || cfg->num_parts < 1) return fail(PAFUSE_E_ARG, "d3dp_lanes: bad argument");
+    const int64_t R = (int64_t)(cfg->flip ? 2 : 1) * B * P;
+    int groups = (1 + (n_aux > 0 ? n_aux : 0)) / cfg->num_parts;
+    if (groups < 1) groups = 1;
+    if (groups > R) groups = (int)R;
+    const int lanes = cfg->num_parts * groups;
+    if (n_aux <= 0) return 1;
+    return lanes < 1 + n_aux ? lanes : 1 + n_aux;  // distinct streams in use (lane 0 = the caller's stream)
+}
+
+int pafuse_embed(const float* x3d, const float* x2d, const float* x2d_flip, const int32_t* joints, const int32_t* perm,
+                 const float* patch_w, const float* patch_b, const float* pos_spatial, const float* temb,
+                 const float* norm_w, const float* norm_b, float norm_eps, int32_t B, int32_t P, int32_t F, int32_t J,
+                 int32_t J3, int32_t C, int32_t nflip, int32_t do_clamp, double scale, float* x, float* xn, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!x3d || !x2d || !patch_w || !patch_b || !pos_spatial || !temb || !norm_w || !norm_b || !x || !xn)
+        return fail(PAFUSE_E_ARG, "embed: null pointer");
+    if (B <= 0 || P <= 0 || F <= 0 || J <= 0 || J3 < J || (nflip != 1 && nflip != 2))
+        return fail(PAFUSE_E_ARG, "embed: bad size (B=%d P=%d F=%d J=%d J3=%d nflip=%d)", B, P, F, J, J3, nflip);
+    if (nflip == 2 && (!x2d_flip || !perm)) return fail(PAFUSE_E_ARG, "embed: the flipped half needs x2d_flip and perm");
+    if (J3 != J && !joints) return fail(PAFUSE_E_ARG, "embed: a part of %d joints out of %d needs its joint list", J, J3);
+    if (C % 4 || C <= 0 || C > EMBED_NV * 128) return fail(PAFUSE_E_SHAPE, "embed: C=%d (need %%4, <= %d)", C, EMBED_NV * 128);
+    if (do_clamp && !(scale > 0.0)) return fail(PAFUSE_E_ARG, "embed: scale must be positive");
+    EmbedParams e{};
+    e.x3d = x3d, e.x2d = x2d, e.x2d_flip = x2d_flip, e.joints = joints, e.perm = perm;
+    e.pw = patch_w, e.pb = patch_b, e.pos = pos_spatial, e.temb = temb;
+    e.n_w = norm_w, e.n_b = norm_b, e.n_eps = norm_eps, e.x = x, e.xn = xn;
+    e.B = B, e.P = P, e.F = F, e.J = J, e.J3 = J3, e.C = C, e.nflip = nflip, e.do_clamp = do_clamp;
+    e.scale = (float)scale, e.lim = (float)(1.1 * scale);
+    e.row0 = 0, e.nrows = (int64_t)nflip * B * P * F * J;
+    const int64_t blocks = (e.nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK;
+    if (blocks > 0x7fffffff) return fail(PAFUSE_E_ARG, "embed: grid out of range");
+    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, e);
+    return check_launch("embed_kernel");
+}
+
+int pafuse_ddim_finalize(const float* const* pred, const int32_t* part_joints, int32_t num_parts, const int32_t* joint_part,
+                         const int32_t* joint_local, const int32_t* flip_perm, float* img, const float* noise, float* out,
+                         int32_t B, int32_t P, int32_t F, int32_t J, int32_t T, int32_t step, int32_t flip, double scale,
+                         const pafuse_ddim_step* st, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!pred || !part_joints || !joint_part || !joint_local || !img || !out || !st)
+        return fail(PAFUSE_E_ARG, "ddim_finalize: null pointer");
+    if (num_parts < 1 || num_parts > PAFUSE_MAX_PARTS) return fail(PAFUSE_E_SHAPE, "ddim_finalize: num_parts %d", num_parts);
+    if (B <= 0 || P <= 0 || F <= 0 || J <= 0 || T <= 0 || step < 0 || step >= T)
+        return fail(PAFUSE_E_ARG, "ddim_finalize: bad size");
+    if (flip && !flip_perm) return fail(PAFUSE_E_ARG, "ddim_finalize: flip needs the permutation");
+    if (!st->last && !noise) return fail(PAFUSE_E_ARG, "ddim_finalize: an update step needs its noise draw");
+    FinalizeParams f{};
+    int total = 0;
+    for (int i = 0; i < num_parts; ++i) {
+        if (!pred[i] || part_joints[i] <= 0) return fail(PAFUSE_E_ARG, "ddim_finalize: part %d", i);
+        f.pred[i] = pred[i], f.Jp[i] = part_joints[i], total += part_joints[i];
+    }
+    if (total != J) return fail(PAFUSE_E_SHAPE, "ddim_finalize: parts cover %d joints, expected %d", total, J);
+    f.joint_part = joint_part, f.joint_local = joint_local, f.perm = flip_perm;
+    f.img = img, f.noise = st->last ? nullptr : noise, f.out = out;
+    f.B = B, f.P = P, f.F = F, f.J = J, f.T = T, f.step = step, f.flip = flip ? 1 : 0, f.last = st->last;
+    f.scale = (float)scale, f.lim = (float)(1.1 * scale), f.sr = st->sqrt_recip_acp, f.srm1 = st->sqrt_recipm1_acp, f.c = st->c;
+    f.an_f = (float)st->sqrt_alpha_next, f.c_f = (float)st->c, f.sigma_f = (float)st->sigma;
+    const int64_t n = (int64_t)B * P * F * J;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f);
+    return check_launch("finalize_kernel");
 }
 
 int pafuse_hypothesis_errors(const float* pred, const float* gt, const float* x2d, const float* traj, const float* cam,
                              const int32_t* conn, const int32_t* pbroot, int32_t B, int32_t T, int32_t P, int32_t F,
                              int32_t J, float* e3, float* epb, float* jbest, float* pagg, float* jagg, float* paggpb,
                              void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!pred || !gt || !x2d || !traj || !cam || !conn || !pbroot || !e3 || !epb || !jbest || !pagg || !jagg || !paggpb)
         return fail(PAFUSE_E_ARG, "hypothesis_errors: null pointer");
     if (B <= 0 || T <= 0 || P <= 0 || F <= 0 || J <= 0) return fail(PAFUSE_E_ARG, "hypothesis_errors: bad size");
@@ -547,6 +674,7 @@ int pafuse_hypothesis_errors(const float* pred, const float* gt, const float* x2
 
 int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, void* workspace,
                              size_t workspace_bytes, void* stream, double* flops) {
+    StreamDevice on_stream_device(stream);
     int rc = d3dp_check(cfg, B, P);
     if (rc) return rc;
     if (!workspace || workspace_bytes < pafuse_d3dp_workspace_bytes(cfg, B, P))
@@ -574,6 +702,7 @@ size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights* w, int32_t B) {
 int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x2d, const float* x3d, const int64_t* t,
                                  int32_t B, const float* drop_path, float* out, void* saved, size_t saved_bytes,
                                  void* stream) {
+    StreamDevice on_stream_device(stream);
     int rc = check_weights(w);
     if (rc) return rc;
     if (!x2d || !x3d || !t || !out || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_forward: bad argument");
@@ -586,6 +715,7 @@ int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x
 int pafuse_mixste2_train_backward(const pafuse_mixste2_weights* w, const pafuse_mixste2_weights* grads, const float* dout,
                                   int32_t B, const float* drop_path, void* saved, size_t saved_bytes, void* stream,
                                   void* side_stream) {
+    StreamDevice on_stream_device(stream);
     int rc = check_weights(w);
     if (rc) return rc;
     if (!grads || !dout || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_backward: bad argument");
@@ -598,6 +728,7 @@ int pafuse_mixste2_train_backward(const pafuse_mixste2_weights* w, const pafuse_
 int pafuse_d3dp_qsample(const float* x0, const float* noise, const int64_t* t, const double* sqrt_alphas_cumprod,
                         const double* sqrt_one_minus_alphas_cumprod, double scale, float* out, int32_t B,
                         int64_t per_sample, void* stream) {
+    StreamDevice on_stream_device(stream);
     if (!x0 || !noise || !t || !sqrt_alphas_cumprod || !sqrt_one_minus_alphas_cumprod || !out || B <= 0 || per_sample <= 0)
         return fail(PAFUSE_E_ARG, "d3dp_qsample: bad argument");
     const int64_t n = (int64_t)B * per_sample;

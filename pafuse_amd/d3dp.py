@@ -227,14 +227,18 @@ class D3DP(nn.Module):
         nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P)
         stream = torch.cuda.current_stream(dev)
         aux = self._aux_for(dev)
+        # hand the library exactly the side streams it will spread the (part, hypothesis-group) lanes over: a stream
+        # forked into a capture but never used (and so never joined) would end the capture with "unjoined work"
+        aux = aux[:max(0, _lib.check(lib.pafuse_d3dp_lanes(C.byref(cfg), B, P, len(aux))) - 1)]
 
         def launch(x2d_, x2f_, noise_, out_, ws_, stream_):
             for s in aux:
                 s.wait_stream(stream_)
             aux_arr = (C.c_void_p * max(1, len(aux)))(*[s.cuda_stream for s in aux])
-            _lib.check(lib.pafuse_d3dp_sample(C.byref(cfg), steps, len(steps), x2d_.data_ptr(), x2f_.data_ptr(),
-                                              noise_.data_ptr(), n_draws, B, P, out_.data_ptr(), ws_.data_ptr(), nbytes,
-                                              stream_.cuda_stream, aux_arr, len(aux)))
+            with torch.cuda.device(dev):
+                _lib.check(lib.pafuse_d3dp_sample(C.byref(cfg), steps, len(steps), x2d_.data_ptr(), x2f_.data_ptr(),
+                                                  noise_.data_ptr(), n_draws, B, P, out_.data_ptr(), ws_.data_ptr(),
+                                                  nbytes, stream_.cuda_stream, aux_arr, len(aux)))
 
         if self.use_graph:
             # the C ABI neither allocates nor synchronises, so the whole T-step loop (~2 500 launches, fork/join

@@ -242,7 +242,7 @@ class ChunkedClips:
     same buffers' dtype (float64) as the reference's ChunkedGenerator_Seq."""
 
     def __init__(self, batch_size, cameras, poses_3d, poses_2d, chunk_length, shuffle=True, random_seed=1234,
-                 augment=False, kps_left=None, kps_right=None, joints_left=None, joints_right=None):
+                 augment=False, kps_left=None, kps_right=None, joints_left=None, joints_right=None, shard=None):
         assert poses_3d is None or len(poses_3d) == len(poses_2d)
         assert cameras is None or len(cameras) == len(poses_2d)
         items = []
@@ -264,6 +264,11 @@ class ChunkedClips:
         self.cameras, self.poses_3d, self.poses_2d = cameras, poses_3d, poses_2d
         self.kps_left, self.kps_right = kps_left, kps_right
         self.joints_left, self.joints_right = joints_left, joints_right
+        # shard = (rank, world): one process per GPU.  Every rank keeps the reference's item list, seed and GLOBAL
+        # batches (so an epoch is one pass and model.batch_size is the global batch, as with the reference's
+        # nn.DataParallel, main_h3wb.py:699-705) and serves clips rank, rank + world, ... of each batch.
+        self.shard = shard
+        self.last_share = None
 
     def batch_num(self):
         return self.num_batches
@@ -288,6 +293,12 @@ class ChunkedClips:
         pairs = self.random.permutation(self.pairs) if self.shuffle else self.pairs
         for b in range(self.num_batches):
             chunk = pairs[b * self.batch_size:(b + 1) * self.batch_size]
+            if self.shard is not None:
+                rank, world = self.shard
+                n_global, chunk = len(chunk), chunk[rank::world]
+                self.last_share = (len(chunk), n_global, world)
+                if len(chunk) == 0:            # fewer clips than ranks: keep the collective's call count, weight 0
+                    chunk = pairs[b * self.batch_size:b * self.batch_size + 1]
             n = len(chunk)
             b2 = np.empty((n, self.chunk_length) + self.poses_2d[0].shape[-2:])
             b3 = None if self.poses_3d is None else np.empty((n, self.chunk_length) + self.poses_3d[0].shape[-2:])
@@ -311,12 +322,37 @@ class ChunkedClips:
             yield bc, b3, b2
 
 
-def train_epoch(model, optimizer, generator, dataset, device, wb_loss=False, log=None):
-    """One epoch of main_h3wb.py:820-870: part-centred targets, train-mode D3DP forward (HIP), mpjpe loss, backward
-    (HIP), optimizer step.  `model` may be wrapped in DistributedDataParallel.  Returns the frame-weighted mean loss (m)."""
+# per-joint loss weights of model.weighted_loss (main_h3wb.py:724-727: 18 body weights "from MixSTE", 1.0 for the rest)
+WEIGHTED_LOSS_HEAD = (1, 1, 1, 1, 1, 1, 1.5, 1.5, 4, 4, 4, 4, 1, 1, 2.5, 2.5, 2.5, 2.5)
+
+
+def mpjpe_loss(predicted, target, weights=None, mse_loss=False):
+    """The training loss, common/loss.py:9-27 (`mpjpe` without return_joints_err): mean joint distance, optionally
+    per-joint weighted and/or squared.  Plain torch on the caller's side of the boundary, as in the reference."""
+    import torch
+    assert predicted.shape == target.shape
+    err = torch.norm(predicted - target, dim=len(target.shape) - 1)
+    if weights is not None:
+        assert weights.shape[0] == target.shape[-2]
+        err = weights[None, None, :].to(predicted.device) * err
+    return torch.mean(torch.square(err)) if mse_loss else torch.mean(err)
+
+
+def train_epoch(model, optimizer, generator, dataset, device, wb_loss=False, log=None, mse_loss=False,
+                weighted_loss=False):
+    """One epoch of main_h3wb.py:820-870: part-centred targets, train-mode D3DP forward (HIP), mpjpe loss
+    (`model.mse_loss` / `model.weighted_loss` variants included, :724-727,:859), backward (HIP), optimizer step.
+    `model` may be wrapped in DistributedDataParallel: with a rank-sharded generator (``ChunkedClips(..., shard=(rank,
+    world))``) every rank holds its slice of the reference's global batch and the local loss is weighted by
+    n_local * world / n_global, so the all-reduced (averaged) gradient is the gradient of the global-batch mean - what
+    the reference's DataParallel computes on the gathered batch.  Returns the clip-weighted mean loss (m)."""
     import torch
     from . import harness
     total, frames = 0.0, 0
+    weights = None
+    if weighted_loss:
+        J = dataset.skeleton().num_joints() if hasattr(dataset, "skeleton") else 134
+        weights = torch.tensor(list(WEIGHTED_LOSS_HEAD) + [1.0] * (J - len(WEIGHTED_LOSS_HEAD)), device=device)
     for it, (_, batch_3d, batch_2d) in enumerate(generator.next_epoch()):
         inputs_3d = torch.from_numpy(batch_3d.astype("float32")).to(device)
         inputs_2d = torch.from_numpy(batch_2d.astype("float32")).to(device)
@@ -326,21 +362,36 @@ def train_epoch(model, optimizer, generator, dataset, device, wb_loss=False, log
         target = inputs_3d
         if wb_loss:
             pred, target = harness.wb_pose_from_parts(pred, dataset), harness.wb_pose_from_parts(inputs_3d, dataset)
-        loss = torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))         # common/loss.py:27-34
-        loss.backward()
+        loss = mpjpe_loss(pred, target, weights, mse_loss)                              # common/loss.py:9-27
+        share = getattr(generator, "last_share", None)        # (clips that count here, clips of the global batch, world)
+        n_local = inputs_3d.shape[0]
+        scale = 1.0
+        if share is not None:
+            n_local, n_global, world = share
+            scale = n_local * world / n_global
+        (loss * scale if scale != 1.0 else loss).backward()
         optimizer.step()
-        n = inputs_3d.shape[0] * inputs_3d.shape[1]
+        n = n_local * inputs_3d.shape[1]
         total, frames = total + n * float(loss.detach()), frames + n
         if log is not None and it % 10 == 0:
             log("%d/%d" % (it, generator.batch_num()))
     return total / max(frames, 1)
 
 
-def save_state(model, optimizer, epoch_no, lr, foldername, random_state=None, tag=None):
-    """The reference's checkpoint dictionary (common/logging.py:83-115): evaluate() and --resume read it back."""
+def save_state(model, optimizer, epoch_no, lr, foldername, random_state=None, tag=None, reference_layout=True):
+    """The reference's checkpoint dictionary (common/logging.py:83-115): evaluate() and --resume read it back.
+
+    The reference always saves the state dict of an ``nn.DataParallel`` wrapper (main_h3wb.py:699-705,1029), so its
+    'model_pos' keys carry a ``module.`` prefix and its loaders expect one (:252 strict, :713-714).  With
+    ``reference_layout`` (default) the file written here has exactly those keys whether or not `model` is wrapped
+    (DataParallel / DistributedDataParallel), so checkpoints are interchangeable with the reference in both directions
+    (``harness.load_checkpoint`` strips the prefix); ``reference_layout=False`` writes bare keys."""
     import torch
     module = model.module if hasattr(model, "module") else model
-    params = {"optimizer": optimizer.state_dict(), "epoch": epoch_no, "lr": lr, "model_pos": module.state_dict()}
+    sd = module.state_dict()
+    if reference_layout:
+        sd = type(sd)(("module." + k, v) for k, v in sd.items())
+    params = {"optimizer": optimizer.state_dict(), "epoch": epoch_no, "lr": lr, "model_pos": sd}
     if random_state is not None:
         params["random_state"] = random_state
     fname = f"{foldername}/{tag or f'epoch_{epoch_no}'}.bin"

@@ -122,9 +122,20 @@ def camera_to_world(X, R, t=0.0):
     return X + 2 * (R[0] * uv + uuv) + t
 
 
+def read_checkpoint(path):
+    """``torch.load`` for the reference's checkpoint files (``best_epoch.bin`` / ``pafuse_model.bin``, written by
+    common/logging.py:83-115) and for the ones :func:`pafuse_amd.h3wb.save_state` writes.  Besides tensors they hold
+    ``random_state``, a pickled ``numpy.random.RandomState`` (main_h3wb.py:1047), which the ``weights_only=True``
+    default of torch >= 2.6 refuses - so the file is loaded with ``weights_only=False`` (only open files you trust,
+    as with the reference)."""
+    return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_checkpoint(model, checkpoint):
     """Accept what the reference saves (common/logging.py:83-115): a dict with 'model_pos', DataParallel
-    ``module.``-prefixed keys, or a bare state dict."""
+    ``module.``-prefixed keys, or a bare state dict - or the path of such a file (:func:`read_checkpoint`)."""
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = read_checkpoint(checkpoint)
     sd = checkpoint.get("model_pos", checkpoint) if isinstance(checkpoint, dict) else checkpoint
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
     return model.load_state_dict(sd)

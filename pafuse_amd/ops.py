@@ -1,4 +1,6 @@
-"""Thin tensor-level wrappers over the unit entry points of the C ABI (used by the parity tests)."""
+"""Thin tensor-level wrappers over the unit entry points of the C ABI (used by the parity tests).
+
+Every wrapper checks operand shapes on the host and launches with the operands' device current."""
 import ctypes as C
 
 import torch
@@ -26,8 +28,9 @@ def linear(x, weight, bias, act=None, bf16=False):
     _need(tuple(weight.shape) == (N, K) and bias.numel() == N, f"linear: x [..,{K}] needs weight [N,{K}] and bias [N]")
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
-    _lib.check(lib.pafuse_linear(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
-                                 x2.shape[0], N, K, (1 if act == "gelu" else 0) | (2 if bf16 else 0), _stream(x)))
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_linear(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
+                                     x2.shape[0], N, K, (1 if act == "gelu" else 0) | (2 if bf16 else 0), _stream(x)))
     return out.view(*x.shape[:-1], N)
 
 
@@ -37,8 +40,9 @@ def layer_norm(x, weight, bias, eps):
     _need(weight.numel() == Cc and bias.numel() == Cc, f"layer_norm: weight and bias must have {Cc} elements")
     x2 = x.contiguous().view(-1, Cc)
     out = torch.empty_like(x2)
-    _lib.check(lib.pafuse_layernorm(_ptr(x2, "x"), _ptr(weight, "w"), _ptr(bias, "b"), out.data_ptr(), x2.shape[0],
-                                    Cc, eps, _stream(x)))
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_layernorm(_ptr(x2, "x"), _ptr(weight, "w"), _ptr(bias, "b"), out.data_ptr(), x2.shape[0],
+                                        Cc, eps, _stream(x)))
     return out.view_as(x)
 
 
@@ -53,9 +57,10 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
         last = ((nseq - 1) // group) * gs + ((nseq - 1) % group) * seq_stride + (L - 1) * tok_stride
         _need(0 <= last < M and min(gs, seq_stride, tok_stride) >= 0, f"attention: sequences reach row {last} of {M}")
     o = torch.zeros(M, Cc, device=qkv.device, dtype=torch.float32)
-    _lib.check(lib.pafuse_attention(_ptr(qkv, "qkv"), o.data_ptr(), nseq, L, Cc, heads, group,
-                                    L if group_stride is None else group_stride, seq_stride, tok_stride,
-                                    _stream(qkv)))
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.pafuse_attention(_ptr(qkv, "qkv"), o.data_ptr(), nseq, L, Cc, heads, group,
+                                        L if group_stride is None else group_stride, seq_stride, tok_stride,
+                                        _stream(qkv)))
     return o
 
 
@@ -69,7 +74,8 @@ def block_forward(block_params, x, heads=8):
     fill_block_struct(w, block_params)
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    _lib.check(lib.pafuse_block_forward(C.byref(w), y.data_ptr(), S, L, Cc, heads, ws.data_ptr(), nbytes, _stream(x)))
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_block_forward(C.byref(w), y.data_ptr(), S, L, Cc, heads, ws.data_ptr(), nbytes, _stream(x)))
     return y
 
 
@@ -81,5 +87,82 @@ def time_embed(model, t):
     t = t.contiguous().long()
     out = torch.empty(t.shape[0], model.embed_dim, device=t.device, dtype=torch.float32)
     hid = torch.empty(t.shape[0], 2 * model.embed_dim, device=t.device, dtype=torch.float32)
-    _lib.check(lib.pafuse_time_embed(C.byref(w), t.data_ptr(), t.shape[0], out.data_ptr(), hid.data_ptr(), _stream(t)))
+    with torch.cuda.device(t.device):
+        _lib.check(lib.pafuse_time_embed(C.byref(w), t.data_ptr(), t.shape[0], out.data_ptr(), hid.data_ptr(), _stream(t)))
     return out
+
+
+def embed(x3d, x2d, patch_w, patch_b, pos_spatial, temb, norm_w, norm_b, norm_eps=1e-6, joints=None, perm=None,
+          x2d_flip=None, do_clamp=False, scale=1.0):
+    """Input stage of one body part (pafuse_embed, include/pafuse_hip.h): clamp / scale / flip / part gather of the
+    noised 3-D pose, 2-D broadcast over P, Linear(5->C) + pos-embed + time-embed -> x, and LayerNorm(x) -> xn.
+
+    x3d [B,P,F,J3,3], x2d [B,F,J3,2]; ``joints`` = this part's indices into the J3 axis (None: all joints);
+    ``x2d_flip`` + ``perm`` switch on the flipped half (rows of the second half).  Returns (x, xn) as
+    [nflip, B, P, F, J, C]."""
+    lib = _lib.load()
+    B, P, F, J3, _ = x3d.shape
+    Cc = patch_w.shape[0]
+    nflip = 2 if x2d_flip is not None else 1
+    J = J3 if joints is None else int(joints.numel())
+    _need(tuple(x3d.shape) == (B, P, F, J3, 3) and tuple(x2d.shape) == (B, F, J3, 2), "embed: x3d [B,P,F,J3,3], x2d [B,F,J3,2]")
+    _need(tuple(patch_w.shape) == (Cc, 5) and patch_b.numel() == Cc and tuple(pos_spatial.shape[-2:]) == (J, Cc) and
+          tuple(temb.shape) == (B, Cc) and norm_w.numel() == Cc and norm_b.numel() == Cc, "embed: parameter shapes")
+    idx = {}
+    for name, t, n in (("joints", joints, J), ("perm", perm, J3)):
+        if t is not None:
+            _need(t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() == n, f"embed: {name} int32 [{n}]")
+            _need(int(t.min()) >= 0 and int(t.max()) < J3, f"embed: {name} values must index the {J3} joints")
+            idx[name] = t.data_ptr()
+    if nflip == 2:
+        _need(perm is not None and tuple(x2d_flip.shape) == (B, F, J3, 2), "embed: the flipped half needs perm and x2d_flip")
+    x = torch.empty(nflip, B, P, F, J, Cc, device=x3d.device, dtype=torch.float32)
+    xn = torch.empty_like(x)
+    with torch.cuda.device(x3d.device):
+        _lib.check(lib.pafuse_embed(_ptr(x3d, "x3d"), _ptr(x2d, "x2d"), _ptr(x2d_flip, "x2d_flip") if nflip == 2 else None,
+                                    idx.get("joints"), idx.get("perm"), _ptr(patch_w, "patch_w"), _ptr(patch_b, "patch_b"),
+                                    _ptr(pos_spatial, "pos"), _ptr(temb, "temb"), _ptr(norm_w, "norm_w"),
+                                    _ptr(norm_b, "norm_b"), float(norm_eps), B, P, F, J, J3, Cc, nflip, int(do_clamp),
+                                    float(scale), x.data_ptr(), xn.data_ptr(), _stream(x3d)))
+    return x, xn
+
+
+def ddim_finalize(preds, joint_part, joint_local, img, step_scalars, noise=None, flip_perm=None, scale=1.0, T=1, step=0,
+                  out=None):
+    """Output stage of one DDIM step (pafuse_ddim_finalize): concat of the parts' predictions, un-flip + TTA mean,
+    scale + clamp -> x_start (written to out[:, step]); epsilon in fp64; img update in place.
+
+    preds: list of per-part tensors [nflip,B,P,F,Jp,3]; img [B,P,F,J,3] (updated in place); step_scalars: a
+    ``_lib.DDIMStep``.  Returns (out [B,T,P,F,J,3], img)."""
+    lib = _lib.load()
+    B, P, F, J, _ = img.shape
+    flip = flip_perm is not None
+    nflip = 2 if flip else 1
+    for p in preds:
+        _need(tuple(p.shape[:4]) == (nflip, B, P, F) and p.shape[-1] == 3, f"ddim_finalize: prediction {tuple(p.shape)}")
+    _need(sum(p.shape[4] for p in preds) == J, "ddim_finalize: the parts must cover every joint")
+    for name, t in (("joint_part", joint_part), ("joint_local", joint_local), ("flip_perm", flip_perm)):
+        if t is not None:
+            _need(t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() == J, f"ddim_finalize: {name}")
+    _need(int(joint_part.min()) >= 0 and int(joint_part.max()) < len(preds), "ddim_finalize: joint_part range")
+    for i, p in enumerate(preds):
+        sel = joint_local[joint_part == i]
+        _need(sel.numel() == p.shape[4] and int(sel.max()) < p.shape[4] and int(sel.min()) >= 0,
+              f"ddim_finalize: joint_local of part {i}")
+    if flip:
+        _need(int(flip_perm.min()) >= 0 and int(flip_perm.max()) < J, "ddim_finalize: flip_perm range")
+    if not step_scalars.last:
+        _need(noise is not None and tuple(noise.shape) == tuple(img.shape), "ddim_finalize: an update step needs noise")
+    if out is None:
+        out = torch.zeros(B, T, P, F, J, 3, device=img.device, dtype=torch.float32)
+    _need(tuple(out.shape) == (B, T, P, F, J, 3) and 0 <= step < T, "ddim_finalize: out [B,T,P,F,J,3]")
+    n = len(preds)
+    ptrs = (C.c_void_p * n)(*[_ptr(p, "pred") for p in preds])
+    counts = (C.c_int32 * n)(*[p.shape[4] for p in preds])
+    with torch.cuda.device(img.device):
+        _lib.check(lib.pafuse_ddim_finalize(ptrs, counts, n, joint_part.data_ptr(), joint_local.data_ptr(),
+                                            flip_perm.data_ptr() if flip else None, _ptr(img, "img"),
+                                            _ptr(noise, "noise") if noise is not None else None, _ptr(out, "out"),
+                                            B, P, F, J, T, step, int(flip), float(scale), C.byref(step_scalars),
+                                            _stream(img)))
+    return out, img

@@ -19,6 +19,9 @@ from tests.golden import golden_util as gu
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
+# |MPJPE_hip - MPJPE_oracle| bounds in mm, per protocol (PROVISIONAL until profiles/r02_parity_report.json is in)
+MPJPE_TOL_MM = {"J-Best": 1e-4, "P-Best": 1e-4, "P-Agg": 1e-4, "J-Agg": 1e-3}
+
 
 def _seeded(shape, seed, scale=1.0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
@@ -189,7 +192,7 @@ def test_loop_vs_oracle_mpjpe(B, P, T):
     target = orc.center_pose_parts(gu.synthetic_target_3d(B))
     got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
     for k in want:
-        assert (got[k] - want[k]).abs().max() <= 1e-3, (k, got[k], want[k])       # mm
+        assert (got[k] - want[k]).abs().max() <= MPJPE_TOL_MM[k], (k, got[k], want[k])       # mm
 
 
 def test_accuracy_equivalent_to_reference_fp32():

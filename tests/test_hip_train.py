@@ -226,7 +226,8 @@ def test_train_epoch_on_synthetic_h3wb_files_and_checkpoint_round_trip(tmp_path)
     losses = [h3wb.train_epoch(model, opt, gen, ds, torch.device(DEV)) for _ in range(3)]
     assert all(l == l and l > 0 for l in losses) and losses[-1] < losses[0], losses
     fname = h3wb.save_state(model, opt, 3, 6e-4, str(tmp_path), random_state=gen.random_state())
-    ckpt = torch.load(fname, map_location="cpu", weights_only=False)
+    ckpt = harness.read_checkpoint(fname)
+    assert all(k.startswith("module.") for k in ckpt["model_pos"])                     # the reference's layout
     assert set(ckpt) == {"optimizer", "epoch", "lr", "model_pos", "random_state"} and len(ckpt["model_pos"]) == 12 + 3 * 40
     ev = pafuse_amd.D3DP(args, jl, jr, dataset=ds, is_train=False, num_proposals=2, sampling_timesteps=1)
     harness.load_checkpoint(ev, ckpt)

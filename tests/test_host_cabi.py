@@ -56,6 +56,33 @@ def test_state_dict_layout_matches_reference():
     model.load_state_dict({k[7:]: v for k, v in {"module." + k: v for k, v in sd.items()}.items()})
 
 
+def test_checkpoints_are_interchangeable_with_the_reference(tmp_path):
+    """save_state writes the reference's file: 'model_pos' keys = the 636 template keys with DataParallel's
+    ``module.`` prefix (main_h3wb.py:699-705,1029 save the wrapper; :252 loads into a wrapper, strictly), next to a
+    pickled numpy RandomState; read_checkpoint reads it back under torch >= 2.6 and load_checkpoint accepts the path,
+    the dict, and un-prefixed dicts alike."""
+    import numpy as np
+    from __graft_entry__ import make_model
+    from pafuse_amd import h3wb, harness
+    from tests.golden.state_template import d3dp_template
+    model, sd = make_model(2, 2, device="cpu")
+    opt = torch.optim.AdamW(model.parameters(), lr=6e-5)
+    for wrapped in (False, True):
+        m = torch.nn.DataParallel(model) if wrapped else model
+        fname = h3wb.save_state(m, opt, 7, 6e-5, str(tmp_path), random_state=np.random.RandomState(3), tag=f"w{wrapped}")
+        with pytest.raises(Exception):                      # the RandomState pickle: refused by the safe loader
+            torch.load(fname, map_location="cpu", weights_only=True)
+        ckpt = harness.read_checkpoint(fname)
+        assert set(ckpt) == {"optimizer", "epoch", "lr", "model_pos", "random_state"} and ckpt["epoch"] == 7
+        assert set(ckpt["model_pos"]) == {"module." + k for k in d3dp_template()}
+        for src in (fname, ckpt, ckpt["model_pos"], {k[7:]: v for k, v in ckpt["model_pos"].items()}):
+            fresh, _ = make_model(2, 2, seed=99, device="cpu")
+            harness.load_checkpoint(fresh, src)
+            assert gu.sha256_of(fresh.state_dict()) == gu.sha256_of(sd)
+    bare = harness.read_checkpoint(h3wb.save_state(model, opt, 1, 6e-5, str(tmp_path), reference_layout=False))
+    assert set(bare["model_pos"]) == set(d3dp_template())
+
+
 def test_schedule_buffers_and_step_scalars_match_golden():
     from __graft_entry__ import make_model
     z = load_golden("g2_schedule.npz")
@@ -227,3 +254,46 @@ def test_training_clip_generator_matches_reference():
                 assert np.array_equal(cam, z[f"e{epoch}.b{b}.cam"].numpy())
                 assert np.array_equal(b3, z[f"e{epoch}.b{b}.p3"].numpy())
                 assert np.array_equal(b2, z[f"e{epoch}.b{b}.p2"].numpy())
+
+
+def test_rank_sharded_clip_generator_covers_the_reference_batches():
+    """one process per GPU: every rank serves its slice of the reference's GLOBAL batches (same seed, same shuffle), so
+    an epoch stays one pass over the data and the ranks' clips together are exactly the unsharded batch (golden G16
+    pins that one to the reference).  World size 5 > the 3-clip batch also exercises the empty-share case."""
+    import numpy as np
+    from pafuse_amd import h3wb
+    ds = h3wb.Human3WBDataset(os.path.join(ROOT, "tests", "golden", "h3wb_synth", "train_h3wb.npz"))
+    keypoints = h3wb.prepare_keypoints(ds)
+    kl, kr = ds.keypoints_metadata["keypoints_symmetry"]
+    cams, p3, p2 = h3wb.fetch(["S1", "S5"], keypoints, ds)
+    kw = dict(shuffle=True, augment=True, kps_left=kl, kps_right=kr, joints_left=list(ds.skeleton().joints_left()),
+              joints_right=list(ds.skeleton().joints_right()))
+    for world in (2, 5):
+        whole = h3wb.ChunkedClips(3, cams, p3, p2, 27, **kw)
+        ranks = [h3wb.ChunkedClips(3, cams, p3, p2, 27, shard=(r, world), **kw) for r in range(world)]
+        assert all(g.batch_num() == whole.batch_num() for g in ranks)
+        its = [g.next_epoch() for g in ranks]
+        for cam, b3, b2 in whole.next_epoch():
+            parts = [next(it) for it in its]
+            shares = [g.last_share for g in ranks]
+            assert all(s[1] == len(b2) and s[2] == world for s in shares) and sum(s[0] for s in shares) == len(b2)
+            for r, ((c_r, b3_r, b2_r), (n_r, _, _)) in enumerate(zip(parts, shares)):
+                want = slice(r, None, world)
+                if n_r == 0:                    # padded with the batch's first clip, weight 0 in train_epoch
+                    assert len(b2_r) == 1 and np.array_equal(b2_r[0], b2[0])
+                else:
+                    assert np.array_equal(b2_r, b2[want]) and np.array_equal(b3_r, b3[want]) and np.array_equal(c_r, cam[want])
+
+
+def test_training_loss_variants_match_the_reference_formulas():
+    """model.mse_loss / model.weighted_loss (common/loss.py:9-27, main_h3wb.py:724-727)."""
+    from pafuse_amd import h3wb
+    g = torch.Generator().manual_seed(0)
+    p, t = torch.randn(2, 27, 134, 3, generator=g), torch.randn(2, 27, 134, 3, generator=g)
+    w = torch.tensor(list(h3wb.WEIGHTED_LOSS_HEAD) + [1.0] * 116)
+    d = (p - t).pow(2).sum(-1).sqrt()
+    assert w.shape == (134,) and float(w.sum()) == 116 + 6 + 3 + 16 + 2 + 10
+    assert torch.allclose(h3wb.mpjpe_loss(p, t), d.mean())
+    assert torch.allclose(h3wb.mpjpe_loss(p, t, mse_loss=True), d.pow(2).mean())
+    assert torch.allclose(h3wb.mpjpe_loss(p, t, w), (w * d).mean())
+    assert torch.allclose(h3wb.mpjpe_loss(p, t, w, True), (w * d).pow(2).mean())

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pafuse_amd.parallel import gather_hypotheses, shard_range
+from pafuse_amd.parallel import gather_hypotheses, rank_census, shard_range
 
 
 def test_shard_ranges_cover_axis():
@@ -35,6 +35,9 @@ def _worker(rank, world, port, P, q):
         q.put((rank, bool(torch.equal(got, full)), tuple(got.shape)))
         got2 = gather_hypotheses(full[:, :, lo:hi].contiguous())          # sizes discovered by a tiny all-gather
         q.put((rank, bool(torch.equal(got2, full)), tuple(got2.shape)))
+        census = rank_census(hi - lo)
+        want = {"ranks_seen": world, "P_local": [shard_range(P, r, world)[1] - shard_range(P, r, world)[0] for r in range(world)]}
+        q.put((rank, census == want, tuple(got.shape)))
     finally:
         dist.destroy_process_group()
 
@@ -46,7 +49,7 @@ def test_all_gather_world2(P):
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, P, q)) for r in range(2)]
     [p.start() for p in procs]
-    res = [q.get(timeout=120) for _ in range(4)]
+    res = [q.get(timeout=120) for _ in range(6)]
     [p.join(timeout=60) for p in procs]
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (2, 3, P, 4, 5, 3) for _, _, shape in res)
