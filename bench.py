@@ -28,9 +28,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DEFAULT_DTYPE = "f32"
 GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md section 3 (one denoiser pass)
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 matrix peak (opt-in --dtype bf16 runs are priced against this)
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # bf16x3: six bf16 MFMA products per fp32-equivalent product = 416.7
 
 
 def main():
@@ -45,9 +47,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
     ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="bf16: opt-in reduced-precision mode (bf16 matrix operands, fp32 accumulate); the contract's "
-                         "line is the f32 default")
+    ap.add_argument("--dtype", choices=("f32", "bf16x3", "bf16"), default=DEFAULT_DTYPE,
+                    help="matrix-product mode of the linear layers: f32 = fp32-input matrix cores; bf16x3 = split "
+                         "precision (fp32 operands as three bf16 slices, six bf16 MFMA products, fp32 accumulate: "
+                         "fp32-equivalent results, same parity bounds); bf16 = opt-in reduced precision (operands "
+                         "rounded to one bf16) - never the contract's line")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the contract's line); gloo only for "
                          "rehearsing the N > 1 code path on a box with fewer GPUs than ranks (with --single-device)")
@@ -142,14 +146,18 @@ def main():
         gather_ms = round(float(gt.item()) * 1e3, 3)
     value = B * P_total / sec_per_step
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
-    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
+    dtype_label = {"f32": "f32",
+                   "bf16x3": "bf16x3 (fp32 operands split into three bf16 slices, six bf16 MFMA products per fp32-"
+                             "equivalent product, fp32 accumulate; activations and everything in memory fp32)",
+                   "bf16": "bf16 operands, f32 accumulate (opt-in, not the parity path)"}[args.dtype]
 
     line = {
         "metric": "hypotheses/sec through DDIM loop (H3WB 133-kp, P=20, T=10)",
         "value": round(value, 3), "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.dtype == "f32" else "bf16 operands, f32 accumulate (opt-in, not the parity path)",
+        "dtype": dtype_label,
         "data": "synthetic",
         "config": {"workload": f"D3DP.forward flip-TTA DDIM loop, H3WB 27x134 clips, B={B}, P={P_local}/GPU "
                                f"(P={P_total} total), T={T}, part-based MixSTE2 body/face/hands 384/224/256 ch, depth 8",
@@ -163,6 +171,7 @@ def main():
         "allgather_ms": gather_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
                           "unit": "TFLOP/s", "frac": round(loop_tflops / peak, 4),
+                          "frac_of_f32_peak": round(loop_tflops / PEAK_F32_MFMA_TFLOPS, 4),
                           "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"},
     }
 
@@ -215,9 +224,14 @@ def main():
         alg_unfused = (mc * 4 * 16 * 16 + 139.8e6) / launches
         alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
         mfma = "v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
+        peak_note = {"f32": "dense f32-input matrix peak",
+                     "bf16x3": "dense bf16 matrix peak 2500 / 6 products; the same FLOPs against the f32-input matrix "
+                               f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
+                     "bf16": "dense bf16 matrix peak"}[args.dtype]
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse::gemm_kernel ({mfma})",
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                            "frac": round(achieved / peak, 4), "traffic": traffic,
+                            "frac": round(achieved / peak, 4), "peak_note": peak_note,
+                            "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                             "traffic_unit": "HBM bytes per launch",
                             "algorithmic_bytes_per_launch": {"this_design_unfused_between_gemms": round(alg_unfused),
                                                              "survey_8d_fused_blocks": round(alg_fused)},

@@ -54,15 +54,25 @@ typedef struct pafuse_block_weights {
     const float *norm2_w, *norm2_b; /* [C] */
     const float *fc1_w, *fc1_b;     /* [2C,C], [2C] */
     const float *fc2_w, *fc2_b;     /* [C,2C], [C] */
+    /* split-precision mode only (pafuse_mixste2_weights.operand_bf16 == 2): the pre-split images of the four linear
+     * weights, made by pafuse_split_weights from the fp32 tensors above (a cache - remake after a weight changes);
+     * NULL otherwise */
+    const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
 } pafuse_block_weights;
 
 /* One MixSTE2 (common/mixste.py:141-210): F frames, J joints of this part, C channels, `depth` spatial +
  * `depth` temporal blocks, `heads` heads (C % heads == 0), mlp hidden = 2C. */
 typedef struct pafuse_mixste2_weights {
     int32_t frames, joints, channels, depth, heads, in_chans; /* in_chans must be 5 (2-D + 3-D) */
-    int32_t operand_bf16; /* 0: fp32 matrix products (the parity path). 1: opt-in reduced precision - the linear layers'
-                             operands are rounded to bf16 in registers (RNE), products accumulate in fp32; activations,
-                             LayerNorm, softmax, attention and everything in memory stay fp32 (inference only) */
+    int32_t operand_bf16; /* matrix-product mode of the linear layers (activations, LayerNorm, softmax, attention and
+                             everything in memory are fp32 in every mode):
+                             0: fp32-input matrix cores (v_mfma_f32_32x32x2_f32): a k-ordered fp32 FMA chain.
+                             2: split precision "bf16x3" (inference): every fp32 operand is the exact sum of three
+                                bf16 slices, products keep the six terms above 2^-24 relative on the bf16 matrix cores
+                                with fp32 accumulation - fp32-equivalent results (closer to exact arithmetic than the
+                                FMA chain) at 2.7x the matrix rate; needs the *_ws weight images.
+                             1: opt-in reduced precision - operands rounded to ONE bf16 (RNE), fp32 accumulate
+                                (BASELINE configs[1]; inference only) */
     const float *patch_w, *patch_b;                           /* Spatial_patch_to_embedding [C,5], [C] */
     const float *pos_spatial;                                 /* Spatial_pos_embed [J,C] */
     const float *pos_temporal;                                /* Temporal_pos_embed [F,C] */
@@ -108,6 +118,15 @@ const char *pafuse_last_error(void);
  * K,N multiples of 32. */
 int pafuse_linear(const float *A, const float *W, const float *bias, float *out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void *stream);
+
+/* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K bytes
+ * ([K/32][N][192 B]: per row and 32-wide K chunk, 4 sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels' LDS
+ * image).  pafuse_linear_split is pafuse_linear on such an image (act: 0 none, 1 GELU): the unit entry of the
+ * split-precision products, which replace the same nn.Linear call sites (common/mixste.py:38-42,65,80). */
+size_t pafuse_split_weights_bytes(int64_t N, int64_t K);
+int pafuse_split_weights(const float *W, int32_t N, int32_t K, void *out, void *stream);
+int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, float *out, int64_t M, int32_t N,
+                        int32_t K, int32_t act, void *stream);
 
 /* out[M,C] = LayerNorm(x[M,C]) * w + b  (biased variance, eps inside the sqrt). */
 int pafuse_layernorm(const float *x, const float *w, const float *b, float *out, int64_t M, int32_t C, float eps,

@@ -21,7 +21,8 @@ BLOCK_FIELDS = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
 
 class BlockWeights(C.Structure):
     _names = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-              "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+              "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+              "qkv_ws", "proj_ws", "fc1_ws", "fc2_ws")
     _fields_ = [(n, C.c_void_p) for n in _names]
 
 
@@ -55,6 +56,10 @@ SIGNATURES = {
     "pafuse_last_error": (C.c_char_p, []),
     "pafuse_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
+    "pafuse_split_weights_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "pafuse_split_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pafuse_linear_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_void_p]),
     "pafuse_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "pafuse_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

@@ -27,6 +27,52 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 lo, const f32x4 hi) {
     return v;
 }
 
+// ---- split precision ("bf16x3"): an fp32 value as the sum of three bf16 numbers, x = s0 + s1 + s2 (exact up to
+// 2^-24 |x|: each slice takes the next 8 significand bits of what is left, round-to-nearest).  A product of two split
+// operands keeps the six terms of order <= 2^-16 (s0*t0; s0*t1, s1*t0; s1*t1, s0*t2, s2*t0) on the bf16 matrix cores
+// with fp32 accumulation: 6 v_mfma_f32_32x32x16_bf16 (192 cycles per 16-deep step) replace 8 v_mfma_f32_32x32x2_f32
+// (512 cycles); the dropped terms are below 2^-24 |x t|, i.e. below the rounding of a single fp32 product.
+struct bf16x8x3 {
+    bf16x8 s0, s1, s2;
+};
+__device__ __forceinline__ bf16x8x3 split3(const f32x4 lo, const f32x4 hi) {
+    bf16x8x3 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = i < 4 ? lo[i] : hi[i - 4];
+        const __bf16 b0 = (__bf16)x;
+        const float r1 = x - (float)b0;  // exact
+        const __bf16 b1 = (__bf16)r1;
+        const float r2 = r1 - (float)b1;  // exact
+        o.s0[i] = b0, o.s1[i] = b1, o.s2[i] = (__bf16)r2;
+    }
+    return o;
+}
+
+// Pre-split weight image W' of a [N,K] fp32 matrix (K % 32 == 0): [K/32 chunks][N rows][192 bytes].  A row of a chunk
+// holds four sub-blocks (s2, h) of 8 consecutive k (k = 32*chunk + 16*s2 + 8*h + 0..7 - exactly what MFMA lane half h
+// feeds to 16-deep step s2) x three slices, 16 bytes each: sub-block sb = 2*s2 + h sits at position
+// (sb + (n >> 2)) & 3 of the row (a rotation that makes the ds_read_b128 fragment reads of 16 consecutive rows hit 16
+// different bank quads with unpadded 192-byte rows), its slices at +0, +16, +32.  The image is read as it lies: a
+// tile's chunk is one contiguous run of BN * 192 bytes in HBM and in LDS.
+constexpr int WSPLIT_ROW_BYTES = 192;
+__host__ __device__ inline size_t wsplit_bytes(int64_t N, int64_t K) { return (size_t)N * (size_t)K * 6; }
+__device__ __forceinline__ int wsplit_sub_offset(int n, int sb) { return ((sb + (n >> 2)) & 3) * 48; }
+
+__global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint8_t* out, int N, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one (n, group of 8 k) per thread
+    const int groups = K / 8;
+    if (idx >= (int64_t)N * groups) return;
+    const int n = (int)(idx / groups), g8 = (int)(idx % groups);
+    const int chunk = g8 >> 2, sb = g8 & 3;
+    const float* src = W + (int64_t)n * K + g8 * 8;
+    const bf16x8x3 s = split3(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    uint8_t* dst = out + ((int64_t)chunk * N + n) * WSPLIT_ROW_BYTES + wsplit_sub_offset(n, sb);
+    *reinterpret_cast<bf16x8*>(dst) = s.s0;
+    *reinterpret_cast<bf16x8*>(dst + 16) = s.s1;
+    *reinterpret_cast<bf16x8*>(dst + 32) = s.s2;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // nn.GELU() default (approximate='none'): x * 0.5 * (1 + erf(x / sqrt(2)))   (common/mixste.py:25,32)
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
@@ -58,7 +104,8 @@ struct GemmParams {
     float* out;         // EPI_BIAS: [M,N]
     int64_t M;
     int N, K;
-    int bf16;  // host-side only: pick the BF16 instantiation (bf16 operands, fp32 accumulate)
+    int bf16;  // host-side only: matrix-product mode - 0 fp32 MFMA, 1 bf16-rounded operands, 2 split bf16x3 (needs Wsplit)
+    const uint8_t* Wsplit;  // mode 2: the pre-split image of W (split_weights_kernel), wsplit_bytes(N, K) bytes
     int act;   // EPI_BIAS: 0 none, 1 GELU
     // EPI_ROWLN (the workgroup owns whole rows, N == BN; row-per-lane form only):  y = A W^T + bias + resid
     //   z  = post_w ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;  out_x = z
@@ -105,6 +152,8 @@ struct GemmTile {
     static constexpr int BM = WM * 32;
     static constexpr int BN = WN * NT * 32;
     static constexpr int STAGE_FLOATS = (BM + BN) * LDK;
+    static constexpr int W_ROW_SPLIT = WSPLIT_ROW_BYTES / 4;                 // floats per W' row of a chunk
+    static constexpr int STAGE_FLOATS_SPLIT = BM * LDK + BN * W_ROW_SPLIT;  // mode 2: A fp32 padded + W' image
 };
 
 // Workgroup = WM x WN waves, each wave a 32 x (32*NT) strip of the BM x BN tile, K streamed in 32-wide chunks:
@@ -119,11 +168,17 @@ struct GemmTile {
 // fragments are rounded to bf16 in registers (v_cvt_pk_bf16_f32, RNE) and multiplied by v_mfma_f32_32x32x16_bf16 with
 // fp32 accumulation: per 16-wide K step lane (r, h) contributes k = {16s + 4h + 0..3} u {16s + 8 + 4h + 0..3} - the two
 // fragments it already holds - for A and W alike, so no data moves differently; only the products are bf16 x bf16.
+// BF16 = 2 (split precision, "bf16x3"): fp32-equivalent products on the bf16 matrix cores.  A stays fp32 in memory and
+// in LDS and is split into three bf16 slices in registers when a fragment is read (each wave owns its rows, so every A
+// element is split once per workgroup); W comes pre-split (p.Wsplit, the W' image above) and is staged as it lies.  Per
+// 16-deep step lane (r, h) multiplies k = 16*s2 + 8*h + 0..7 - six MFMAs per (A, W) fragment pair.
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
     constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;  // float4 per thread per chunk
+    constexpr bool SPLIT = BF16 == 2;
+    constexpr int W_ROW = SPLIT ? T::W_ROW_SPLIT : LDK;  // floats per W row of a stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Ws = smem + NSTAGE * BM * LDK;
@@ -170,22 +225,41 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
         row = row < BM ? row : BM - 1;
         return row * LDK + tc4 * 4;
     };
-    static_assert((BN * 8) % NTHR == 0, "W staging must divide evenly");
+    static_assert(SPLIT || (BN * 8) % NTHR == 0, "W staging must divide evenly");
     const int w_off = w_row0 * K + tc4 * 4;
-    f32x4 a_reg[A_LD], w_reg[W_LD];
+    // split mode: the tile's chunk of the W' image is BN * 192 contiguous bytes, copied as it lies (16-byte pieces)
+    constexpr int WS_PIECES = BN * (WSPLIT_ROW_BYTES / 16), WS_LD = (WS_PIECES + NTHR - 1) / NTHR;
+    const uint8_t* Wsbase = SPLIT ? p.Wsplit + (int64_t)n0 * WSPLIT_ROW_BYTES + tid * 16 : nullptr;
+    const int64_t ws_chunk = (int64_t)p.N * WSPLIT_ROW_BYTES;  // bytes per K chunk of the image
+    f32x4 a_reg[A_LD], w_reg[SPLIT ? WS_LD : W_LD];
     auto load_chunk = [&](int kc) {
         const float* Ak = Abase + kc * BK;
-        const float* Wk = Wbase + kc * BK;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(Ak + a_off[i]);
+        if constexpr (SPLIT) {
+            const uint8_t* Wk = Wsbase + kc * ws_chunk;
 #pragma unroll
-        for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)i * RSTEP * K + w_off);
+            for (int i = 0; i < WS_LD; ++i)
+                if ((i + 1) * NTHR <= WS_PIECES || tid + i * NTHR < WS_PIECES)
+                    w_reg[i] = *reinterpret_cast<const f32x4*>(Wk + i * NTHR * 16);
+        } else {
+            const float* Wk = Wbase + kc * BK;
+#pragma unroll
+            for (int i = 0; i < W_LD; ++i) w_reg[i] = *reinterpret_cast<const f32x4*>(Wk + (int64_t)i * RSTEP * K + w_off);
+        }
     };
     auto store_chunk = [&](float* Ad, float* Wd) {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(Ad + a_dst(i)) = a_reg[i];
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Wd + w_dst0 + i * RSTEP * LDK) = w_reg[i];
+            for (int i = 0; i < WS_LD; ++i)
+                if ((i + 1) * NTHR <= WS_PIECES || tid + i * NTHR < WS_PIECES)
+                    *reinterpret_cast<f32x4*>(Wd + (tid + i * NTHR) * 4) = w_reg[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < W_LD; ++i) *reinterpret_cast<f32x4*>(Wd + w_dst0 + i * RSTEP * LDK) = w_reg[i];
+        }
     };
     load_chunk(0);
     store_chunk(As, Ws);
@@ -197,17 +271,48 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
-    const int a_frag = (wm * 32 + r) * LDK + 4 * h;
-    const int w_frag = (wn * NT * 32 + r) * LDK + 4 * h;
+    const int a_frag = (wm * 32 + r) * LDK + (SPLIT ? 8 : 4) * h;
+    const int w_frag = (wn * NT * 32 + r) * W_ROW + (SPLIT ? 0 : 4 * h);
+    // split mode: float offset of this lane's sub-block (s2, h) inside a W' row (rotation by row, see split_weights_kernel)
+    const int ws_sub[2] = {wsplit_sub_offset(r, h) / 4, wsplit_sub_offset(r, 2 + h) / 4};
     const int nk = K / BK;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = (NSTAGE == 2) ? (kc & 1) : 0;
         const bool more = kc + 1 < nk;
         if (more) load_chunk(kc + 1);
         const float* Ac = As + cur * BM * LDK + a_frag;
-        const float* Wc = Ws + cur * BN * LDK + w_frag;
+        const float* Wc = Ws + cur * BN * W_ROW + w_frag;
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (BF16 != 0) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8x3 a = split3(*reinterpret_cast<const f32x4*>(Ac + 16 * s2),
+                                          *reinterpret_cast<const f32x4*>(Ac + 16 * s2 + 4));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float* wp = Wc + nt * 32 * W_ROW + ws_sub[s2];
+                    const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                    const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 4);
+                    const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 8);
+                    // small terms first, the leading product last
+                    if constexpr (TR) {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s2, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a.s0, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s1, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s1, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s0, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s0, acc[nt], 0, 0, 0);
+                    } else {
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s2, w0, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s0, w2, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s1, w1, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s1, w0, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s0, w1, acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s0, w0, acc[nt], 0, 0, 0);
+                    }
+                }
+            }
+        } else if constexpr (BF16 != 0) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 a8 = to_bf16x8(*reinterpret_cast<const f32x4*>(Ac + 16 * s2),
@@ -239,7 +344,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
         if (NSTAGE == 1) __syncthreads();  // everyone done reading before the single buffer is refilled
         if (more) {
             const int nxt = (NSTAGE == 2) ? (cur ^ 1) : 0;
-            store_chunk(As + nxt * BM * LDK, Ws + nxt * BN * LDK);
+            store_chunk(As + nxt * BM * LDK, Ws + nxt * BN * W_ROW);
         }
         __syncthreads();
     }

@@ -73,7 +73,8 @@ struct StreamDevice {
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
-    constexpr size_t stage_bytes = (size_t)NSTAGE * T::STAGE_FLOATS * sizeof(float);
+    constexpr size_t stage_bytes = (size_t)NSTAGE * (BF16 == 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * sizeof(float);
+    if (BF16 == 2 && !p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     static_assert(EPI == EPI_BIAS || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
     constexpr size_t lds = stage_bytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -96,6 +97,11 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
+    if (p.bf16 == 2) {  // split precision (bf16x3): fp32-equivalent products on the bf16 matrix cores
+        if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>(p, s);
+        if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>(p, s);
+        return launch_gemm<4, 1, 1, EPI_BIAS, 1, 1, 0, 2>(p, s);
+    }
     if (p.bf16) {  // opt-in bf16-operand mode: same tiles, bf16 MFMA
         if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 5, 0, 1>(p, s);
         if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 1>(p, s);
@@ -111,7 +117,16 @@ int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
     if constexpr (EPI == EPI_ROWLN) {
-        if (p.bf16) {
+        if (p.bf16 == 2) {
+            switch (p.N) {
+                case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1, 2>(p, s);
+                case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1, 2>(p, s);
+                case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1, 2>(p, s);
+                case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 2>(p, s);
+                case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 2>(p, s);
+                default: break;
+            }
+        } else if (p.bf16) {
             switch (p.N) {
                 case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1, 1>(p, s);
                 case 256: return launch_gemm<2, 2, 4, EPI, 1, 3, 1, 1>(p, s);
@@ -216,6 +231,13 @@ int check_weights(const pafuse_mixste2_weights* w) {
     if (d % 4 || d > 48) return fail(PAFUSE_E_SHAPE, "head dim %d unsupported", d);
     if (w->joints < 1 || w->joints > 80 || w->frames < 1 || w->frames > 80)
         return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..80", w->joints, w->frames);
+    if (w->operand_bf16 < 0 || w->operand_bf16 > 2) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
+    if (w->operand_bf16 == 2)
+        for (int i = 0; i < w->depth; ++i)
+            for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]})
+                if (!b->qkv_ws || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)
+                    return fail(PAFUSE_E_ARG, "split-precision mode needs the pre-split image of every linear weight "
+                                              "(pafuse_split_weights)");
     return PAFUSE_OK;
 }
 
@@ -238,7 +260,7 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
     GemmParams g{};
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
-    g.bf16 = bf16;
+    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws;
     if ((rc = gemm_bias(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     if (!gemms_only) {
@@ -253,13 +275,13 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
     g.A = pb.o, g.W = bw.proj_w, g.bias = bw.proj_b, g.M = M, g.N = C, g.K = C;
     g.resid = pb.x, g.out_x = pb.x, g.out_n = pb.xn;
     g.next_w = bw.norm2_w, g.next_b = bw.norm2_b, g.next_eps = 1e-6f;
-    g.bf16 = bf16;
+    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.proj_ws;
     if ((rc = gemm_rowln(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
     g = GemmParams{};
     g.A = pb.xn, g.W = bw.fc1_w, g.bias = bw.fc1_b, g.out = pb.wide, g.M = M, g.N = 2 * C, g.K = C, g.act = 1;
-    g.bf16 = bf16;
+    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.fc1_ws;
     if ((rc = gemm_bias(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
@@ -271,7 +293,7 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
     g.next_w = tail.next_w, g.next_b = tail.next_b, g.next_eps = tail.next_eps;
     g.head_w = tail.head_w, g.head_b = tail.head_b, g.out_head = tail.out_head;
     if (!tail.next_w) g.out_n = nullptr;
-    g.bf16 = bf16;
+    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.fc2_ws;
     if ((rc = gemm_rowln(g, s))) return rc;
     if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     return PAFUSE_OK;
@@ -333,7 +355,7 @@ __global__ void copy_kernel(const float* src, float* dst, int64_t n) {
 // ================================================================================================== C ABI
 extern "C" {
 
-const char* pafuse_version(void) { return "pafuse_hip 0.1 (gfx950, f32 MFMA)"; }
+const char* pafuse_version(void) { return "pafuse_hip 0.2 (gfx950, f32 MFMA + split-bf16x3 MFMA)"; }
 const char* pafuse_last_error(void) { return g_err; }
 
 int pafuse_linear(const float* A, const float* W, const float* bias, float* out, int64_t M, int32_t N, int32_t K,
@@ -342,6 +364,28 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
     if (!A || !W || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear: null pointer or negative M");
     GemmParams g{};
     g.A = A, g.W = W, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = (act >> 1) & 1;
+    return gemm_bias(g, (hipStream_t)stream);
+}
+
+size_t pafuse_split_weights_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
+
+int pafuse_split_weights(const float* W, int32_t N, int32_t K, void* out, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!W || !out) return fail(PAFUSE_E_ARG, "split_weights: null pointer");
+    if (N <= 0 || K <= 0 || K % BK) return fail(PAFUSE_E_SHAPE, "split_weights: N=%d, K=%d (K must be a positive multiple of 32)", N, K);
+    const int64_t n = (int64_t)N * (K / 8);
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
+                       (uint8_t*)out, N, K);
+    return check_launch("split_weights_kernel");
+}
+
+int pafuse_linear_split(const float* A, const void* Wsplit, const float* bias, float* out, int64_t M, int32_t N, int32_t K,
+                        int32_t act, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!A || !Wsplit || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear_split: null pointer or negative M");
+    GemmParams g{};
+    g.A = A, g.Wsplit = (const uint8_t*)Wsplit, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1;
+    g.bf16 = 2;
     return gemm_bias(g, (hipStream_t)stream);
 }
 

@@ -112,18 +112,28 @@ class D3DP(nn.Module):
         #                                 workspace (0.9 GB per 40 rows) and keeps activations cache-resident
         self._graphs = {}
 
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+
     @property
     def precision(self):
-        """'f32' (default, the parity path) or 'bf16': the denoisers' linear layers multiply bf16-rounded operands with
-        fp32 accumulation (BASELINE configs[1]); everything else, and every tensor in memory, stays fp32."""
-        return "bf16" if all(m.operand_bf16 for m in self.pose_estimator.values()) else "f32"
+        """Matrix-product mode of the denoisers' linear layers (everything else, and every tensor in memory, is fp32):
+        'f32'    fp32-input matrix cores, a k-ordered fp32 FMA chain per output;
+        'bf16x3' split precision (inference): fp32 operands as three bf16 slices, six bf16 MFMA products, fp32
+                 accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h);
+        'bf16'   opt-in reduced precision: operands rounded to one bf16 (BASELINE configs[1])."""
+        modes = {int(m.operand_bf16) for m in self.pose_estimator.values()}
+        if len(modes) != 1:
+            return "mixed"
+        return {v: k for k, v in self.PRECISIONS.items()}[modes.pop()]
 
     @precision.setter
     def precision(self, value):
-        if value not in ("f32", "bf16"):
-            raise ValueError("precision must be 'f32' or 'bf16'")
+        if value not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        if self.is_train and value != "f32":
+            raise ValueError("training runs the fp32 matrix cores: precision must stay 'f32'")
         for m in self.pose_estimator.values():
-            m.operand_bf16 = value == "bf16"
+            m.operand_bf16 = self.PRECISIONS[value]
         self._graphs.clear()
 
     # ------------------------------------------------------------------------------------------ schedule
@@ -243,7 +253,8 @@ class D3DP(nn.Module):
         if self.use_graph:
             # the C ABI neither allocates nor synchronises, so the whole T-step loop (~2 500 launches, fork/join
             # events included) is captured once per (shape, weights) and replayed on static buffers
-            key = (B, P, len(steps), bool(flip), dev, tuple(cfg.part[i].patch_w for i in range(cfg.num_parts)))
+            key = (B, P, len(steps), bool(flip), dev, tuple(cfg.part[i].patch_w for i in range(cfg.num_parts)),
+                   tuple((cfg.part[i].operand_bf16, cfg.part[i].ste[0].qkv_ws) for i in range(cfg.num_parts)))
             g = self._graphs.get(key)
             if g is None:
                 st = {"x2d": x2d.clone(), "x2f": x2f.clone(), "noise": noise.clone(),

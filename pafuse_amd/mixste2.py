@@ -89,7 +89,9 @@ class MixSTE2(nn.Module):
         self._wcache = None
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
-        self.operand_bf16 = False      # opt-in reduced precision for inference: bf16 matrix operands, fp32 accumulate
+        self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA,
+        #                                2 split precision "bf16x3" (fp32-equivalent, inference), 1 opt-in bf16 operands
+        self._split_cache = None       # (key, {weight name: uint8 image}) of the pre-split weights for mode 2
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -99,14 +101,36 @@ class MixSTE2(nn.Module):
         """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes)."""
         # attribute access, not named_parameters(): nn.DataParallel replicas keep their copies as plain attributes
         get = lambda name: attrgetter(name)(self)
-        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), bool(self.operand_bf16))
+        mode = int(self.operand_bf16)
+        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode)
+        if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
+            key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
         if self._wcache is not None and self._wcache[0] == key:
             return self._wcache[1]
         w = _lib.MixSTE2Weights()
         fill_weights_struct(w, get, self._freqs, self.num_frame, self.num_joints, self.embed_dim,
-                            self.block_depth, self.num_heads, self.in_chans, self.operand_bf16)
+                            self.block_depth, self.num_heads, self.in_chans, mode,
+                            self._split_images(get) if mode == 2 else None)
         self._wcache = (key, w)
         return w
+
+    def _split_images(self, get):
+        """Pre-split (bf16x3) images of every linear weight, made on the device by pafuse_split_weights: one uint8
+        tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct)."""
+        lib = _lib.load()
+        images = {}
+        for name in self._param_names:
+            if not name.endswith(SPLIT_SUFFIXES):
+                continue
+            wt = get(name)
+            N, K = wt.shape
+            img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=wt.device)
+            with torch.cuda.device(wt.device):
+                _lib.check(lib.pafuse_split_weights(_ptr(wt.detach(), name), N, K, img.data_ptr(),
+                                                    torch.cuda.current_stream(wt.device).cuda_stream))
+            images[name] = img
+        self._split_cache = images          # keeps the storage alive as long as the struct that points into it
+        return images
 
     # ---------------------------------------------------------------------------------------------- forward
     def forward(self, x_2d, x_3d, t):
@@ -117,7 +141,8 @@ class MixSTE2(nn.Module):
             raise _lib.PafuseError("MixSTE2 runs on the HIP device only (no CPU fallback)")
         if self.is_train:
             if self.operand_bf16:
-                raise NotImplementedError("bf16 operands are an inference option; training runs in fp32")
+                raise NotImplementedError("bf16 / split-precision products are inference options; training runs the "
+                                          "fp32 matrix cores (set precision = 'f32')")
             return self._forward_train(x_2d, x_3d, t)
         B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()
@@ -239,6 +264,9 @@ class _TrainFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads[n] for n in module._param_names)
 
 
+SPLIT_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+BLOCK_SPLIT = (("qkv_ws", "attn.qkv.weight"), ("proj_ws", "attn.proj.weight"), ("fc1_ws", "mlp.fc1.weight"),
+               ("fc2_ws", "mlp.fc2.weight"))
 BLOCK_PARAMS = (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
                 ("qkv_b", "attn.qkv.bias"), ("proj_w", "attn.proj.weight"), ("proj_b", "attn.proj.bias"),
                 ("norm2_w", "norm2.weight"), ("norm2_b", "norm2.bias"), ("fc1_w", "mlp.fc1.weight"),
@@ -251,8 +279,9 @@ MODEL_PARAMS = (("patch_w", "Spatial_patch_to_embedding.weight"), ("patch_b", "S
                 ("hnorm_b", "head.0.bias"), ("head_w", "head.1.weight"), ("head_b", "head.1.bias"))
 
 
-def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, in_chans, operand_bf16=0):
-    """Fill a pafuse_mixste2_weights from ``get(state-dict key) -> tensor`` (keys as in common/mixste.py)."""
+def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, in_chans, operand_bf16=0, split=None):
+    """Fill a pafuse_mixste2_weights from ``get(state-dict key) -> tensor`` (keys as in common/mixste.py); ``split``
+    maps the names of the linear weights to their pre-split images (mode 2 only)."""
     if depth > _lib.MAX_DEPTH:
         raise _lib.PafuseError(f"depth {depth} > {_lib.MAX_DEPTH}")
     w.frames, w.joints, w.channels, w.depth, w.heads, w.in_chans = frames, joints, channels, depth, heads, in_chans
@@ -264,6 +293,8 @@ def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, i
         for i in range(depth):
             for field, key in BLOCK_PARAMS:
                 setattr(dst[i], field, _ptr(get(f"{prefix}.{i}.{key}"), f"{prefix}.{i}.{key}"))
+            for field, key in BLOCK_SPLIT:
+                setattr(dst[i], field, split[f"{prefix}.{i}.{key}"].data_ptr() if split is not None else None)
 
 
 def fill_block_struct(dst, blk):

@@ -166,3 +166,31 @@ def ddim_finalize(preds, joint_part, joint_local, img, step_scalars, noise=None,
                                             B, P, F, J, T, step, int(flip), float(scale), C.byref(step_scalars),
                                             _stream(img)))
     return out, img
+
+
+def split_weights(weight):
+    """Pre-split (bf16x3) image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights)."""
+    lib = _lib.load()
+    _need(weight.dim() == 2 and weight.shape[1] % 32 == 0, "split_weights: weight must be [N, K] with K % 32 == 0")
+    N, K = weight.shape
+    img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, img.data_ptr(), _stream(weight)))
+    return img
+
+
+def linear_split(x, weight, bias, act=None, image=None):
+    """nn.Linear (+ exact GELU) with split-precision (bf16x3) products: fp32 operands as three bf16 slices each, six
+    bf16 MFMA products per pair, fp32 accumulation.  ``image`` = split_weights(weight) to reuse a cached image."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    N = weight.shape[0]
+    _need(tuple(weight.shape) == (N, K) and bias.numel() == N, f"linear: x [..,{K}] needs weight [N,{K}] and bias [N]")
+    img = split_weights(weight) if image is None else image
+    _need(img.numel() == lib.pafuse_split_weights_bytes(N, K), "linear_split: image size does not match the weight")
+    x2 = x.contiguous().view(-1, K)
+    out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_linear_split(_ptr(x2, "x"), img.data_ptr(), _ptr(bias, "bias"), out.data_ptr(),
+                                           x2.shape[0], N, K, 1 if act == "gelu" else 0, _stream(x)))
+    return out.view(*x.shape[:-1], N)

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import make_model  # noqa: E402
 from oracle import d3dp_oracle as orc  # noqa: E402
 from pafuse_amd import synthetic as gu  # noqa: E402
-from tests.test_hip_parity import _mpjpe_report  # noqa: E402
+from tests.test_hip_parity import _j_agg_compare, _mpjpe_report  # noqa: E402
 
 
 def run_case(P, T, B=1, precision="f32"):
@@ -38,6 +38,7 @@ def run_case(P, T, B=1, precision="f32"):
     target = orc.center_pose_parts(gu.synthetic_target_3d(B))
     got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
     d = (out - ref).abs()
+    jagg_same, jagg_flip_frac, jagg_flip_margin = _j_agg_compare(out, ref, target, x2d)
     # J-Agg picks, per (frame, joint), the hypothesis with the smallest 2-D reprojection error: count the joints whose
     # pick differs between the two runs (a near-tie decided the other way swaps in another hypothesis' 3-D error)
     return {
@@ -48,6 +49,8 @@ def run_case(P, T, B=1, precision="f32"):
         "mpjpe_mm_abs_diff_per_step": {k: [abs(v) for v in (got[k] - want[k]).tolist()] for k in want},
         "mpjpe_mm_abs_diff_max": {k: (got[k] - want[k]).abs().max().item() for k in want},
         "mpjpe_mm_oracle_per_step": {k: want[k].tolist() for k in want},
+        "j_agg_same_picks_mm_abs_diff_max": jagg_same, "j_agg_fraction_of_joints_with_different_pick": jagg_flip_frac,
+        "j_agg_largest_2d_margin_m_among_different_picks": jagg_flip_margin,
         "north_star_1e-4mm_met": {k: bool((got[k] - want[k]).abs().max().item() <= 1e-4) for k in want},
     }
 

