@@ -98,6 +98,9 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
     if (p.bf16 == 2) {  // split precision (bf16x3): fp32-equivalent products on the bf16 matrix cores
+        // measured per shape with tools/gemm_bench.hip (profiles/r02_gemm_bench_split_v1.log): 128x128 tiles at two
+        // workgroups per CU where N allows (159 TFLOP/s at the body qkv shape), 128x64 at four otherwise (148)
+        if (p.N % 128 == 0 && p.M >= 4096) return launch_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>(p, s);
         if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>(p, s);
         if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>(p, s);
         return launch_gemm<4, 1, 1, EPI_BIAS, 1, 1, 0, 2>(p, s);
@@ -119,9 +122,11 @@ int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
     if constexpr (EPI == EPI_ROWLN) {
         if (p.bf16 == 2) {
             switch (p.N) {
-                case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1, 2>(p, s);
+                // taller whole-row tiles than the fp32 path: with the MFMA time cut to 3/8 the operand stream (72 KB of
+                // W' per 32-deep chunk at C = 384) is what counts, and 128 rows per workgroup read it 4x less often
+                case 384: return p.M >= 4096 ? launch_gemm<4, 4, 3, EPI, 1, 1, 1, 2>(p, s) : launch_gemm<1, 4, 3, EPI, 1, 1, 1, 2>(p, s);
                 case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1, 2>(p, s);
-                case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1, 2>(p, s);
+                case 224: return p.M >= 4096 ? launch_gemm<2, 1, 7, EPI, 1, 1, 1, 2>(p, s) : launch_gemm<1, 7, 1, EPI, 1, 1, 1, 2>(p, s);
                 case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 2>(p, s);
                 case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 2>(p, s);
                 default: break;
@@ -129,7 +134,7 @@ int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
         } else if (p.bf16) {
             switch (p.N) {
                 case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1, 1>(p, s);
-                case 256: return launch_gemm<2, 2, 4, EPI, 1, 3, 1, 1>(p, s);
+                case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1, 1>(p, s);
                 case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1, 1>(p, s);
                 case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 1>(p, s);
                 case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 1>(p, s);
@@ -141,7 +146,7 @@ int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
         // row-per-lane accumulators (TR): LayerNorm statistics are in-lane sums + one shuffle + a tiny cross-wave
         // exchange, all global traffic is dwordx4, no LDS transposition (picked with tools/gemm_bench.hip)
         case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1>(p, s);
-        case 256: return launch_gemm<2, 2, 4, EPI, 1, 3, 1>(p, s);
+        case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1>(p, s);  // (MINW 3 capped it at 168 VGPRs: 6 spilled, -2 %)
         case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1>(p, s);
         case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1>(p, s);
         case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1>(p, s);
