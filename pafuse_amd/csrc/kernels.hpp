@@ -156,6 +156,168 @@ struct GemmTile {
     static constexpr int STAGE_FLOATS_SPLIT = BM * LDK + BN * W_ROW_SPLIT;  // mode 2: A fp32 padded + W' image
 };
 
+// ----------------------------------------------------------------------------------------------------------------
+// Epilogues on row-per-lane accumulators (shared by gemm_kernel<.., TR = 1> and gemm_dma_kernel): lane (r, h) of wave
+// (wm, wn) owns output row m0 + 32*wm + r; acc[nt][4q..4q+3] are columns n0 + 32*(wn*NT + nt) + 8q + 4h + {0,1,2,3}.
+// EPI_BIAS: out = act(acc + bias).  EPI_ROWLN / _TRAIN: the whole-row residual + LayerNorm chain of GemmParams; `smem` is
+// scratch for the cross-wave row sums (WN > 1; the caller guarantees every wave is done with its staging contents).
+// ----------------------------------------------------------------------------------------------------------------
+template <int WN, int NT, int BM, int EPI>
+__device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0,
+                                                      const int wm, const int wn, const int r, const int h, float* smem) {
+    // lane (r, h) owns row m = m0 + 32*wm + r; acc[nt][4q..4q+3] are columns 32*(wn*NT+nt) + 8q + 4h + {0,1,2,3}
+    const int64_t m = m0 + wm * 32 + r;
+    const bool live = m < p.M;
+    const int64_t mo = (live ? m : p.M - 1) * p.N;
+    const int nb = n0 + wn * NT * 32 + 4 * h;  // + 32*nt + 8*q
+    if constexpr (EPI == EPI_BIAS) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 32 * nt + 8 * q;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[nt][4 * q + e] + b4[e];
+                    if (p.act) v[e] = gelu_erf(v[e]);
+                }
+                if (live) *reinterpret_cast<f32x4*>(p.out + mo + n) = v;
+            }
+        PAFUSE_STAMP(2);
+        return;
+    } else {
+        float* red = smem;  // [slot][BM][WN] cross-wave partial sums (staging LDS is dead after the last barrier)
+        const float invC = 1.0f / (float)p.N;
+        auto row_total = [&](float s, int slot) {
+            s += __shfl_xor(s, 32);
+            if (WN > 1) {
+                float* rs = red + slot * BM * WN + (wm * 32 + r) * WN;
+                if (h == 0) rs[wn] = s;
+                __syncthreads();
+                s = rs[0];
+#pragma unroll
+                for (int w = 1; w < WN; ++w) s += rs[w];
+            }
+            return s;
+        };
+        auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot) {
+            float s = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += acc[nt][i];
+            const float mean = row_total(s, slot) * invC;
+            float qv = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float d = acc[nt][i] - mean;
+                    qv += d * d;
+                }
+            const float rstd = 1.0f / sqrtf(row_total(qv, slot + 1) * invC + eps);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb + 32 * nt + 8 * q;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + n);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
+                }
+        };
+        float rs = 1.0f;
+        if constexpr (EPI == EPI_ROWLN_TRAIN) {
+            if (p.rowscale) {
+                const int64_t mm = live ? m : p.M - 1;
+                rs = p.rowscale[p.rs_temporal ? (mm / p.rs_FJ) * p.rs_J + mm % p.rs_J : mm / p.rs_J];
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = nb + 32 * nt + 8 * q;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.resid + mo + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (EPI == EPI_ROWLN_TRAIN)
+                        acc[nt][4 * q + e] = r4[e] + rs * (acc[nt][4 * q + e] + b4[e]);
+                    else
+                        acc[nt][4 * q + e] = (acc[nt][4 * q + e] + b4[e]) + r4[e];
+                }
+                if constexpr (EPI == EPI_ROWLN_TRAIN) {
+                    if (p.out_pre && live) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                        *reinterpret_cast<f32x4*>(p.out_pre + mo + n) = v;
+                    }
+                }
+            }
+        if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
+        if (p.pos) {  // only the first spatial block of a pass
+            const int f = (int)(((live ? m : p.M - 1) / p.posJ) % p.posF);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * p.N + nb + 32 * nt + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] += pe[e];
+                }
+        }
+        if (p.out_x && live) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                    *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
+                }
+        }
+        if (p.next_w) {
+            layer_norm(p.next_w, p.next_b, p.next_eps, 2);
+            if (p.out_n && live) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                        *reinterpret_cast<f32x4*>(p.out_n + mo + nb + 32 * nt + 8 * q) = v;
+                    }
+            }
+            if (p.out_head) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + nb + 32 * nt + 8 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s += acc[nt][4 * q + e] * hw[e];
+                        }
+                    s = row_total(s, 4 + k);
+                    if (live && h == 0 && wn == 0) p.out_head[m * 3 + k] = s + p.head_b[k];
+                }
+            }
+        }
+        PAFUSE_STAMP(2);
+        return;
+    }
+}
+
 // Workgroup = WM x WN waves, each wave a 32 x (32*NT) strip of the BM x BN tile, K streamed in 32-wide chunks:
 // global -> registers (issued before the MFMAs of the current chunk) -> LDS (after them), NSTAGE LDS buffers.
 // Fragment reads are ds_read_b128: lane (r = lane&31, h = lane>>5) takes k = 8g+4h..8g+4h+3 of row r, and MFMA
@@ -351,157 +513,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
 
     PAFUSE_STAMP(1);
     if constexpr (TR) {
-        // lane (r, h) owns row m = m0 + 32*wm + r; acc[nt][4q..4q+3] are columns 32*(wn*NT+nt) + 8q + 4h + {0,1,2,3}
-        const int64_t m = m0 + wm * 32 + r;
-        const bool live = m < p.M;
-        const int64_t mo = (live ? m : p.M - 1) * p.N;
-        const int nb = n0 + wn * NT * 32 + 4 * h;  // + 32*nt + 8*q
-        if constexpr (EPI == EPI_BIAS) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + 32 * nt + 8 * q;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[nt][4 * q + e] + b4[e];
-                        if (p.act) v[e] = gelu_erf(v[e]);
-                    }
-                    if (live) *reinterpret_cast<f32x4*>(p.out + mo + n) = v;
-                }
-            PAFUSE_STAMP(2);
-            return;
-        } else {
-            float* red = smem;  // [slot][BM][WN] cross-wave partial sums (staging LDS is dead after the last barrier)
-            const float invC = 1.0f / (float)p.N;
-            auto row_total = [&](float s, int slot) {
-                s += __shfl_xor(s, 32);
-                if (WN > 1) {
-                    float* rs = red + slot * BM * WN + (wm * 32 + r) * WN;
-                    if (h == 0) rs[wn] = s;
-                    __syncthreads();
-                    s = rs[0];
-#pragma unroll
-                    for (int w = 1; w < WN; ++w) s += rs[w];
-                }
-                return s;
-            };
-            auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot) {
-                float s = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) s += acc[nt][i];
-                const float mean = row_total(s, slot) * invC;
-                float qv = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float d = acc[nt][i] - mean;
-                        qv += d * d;
-                    }
-                const float rstd = 1.0f / sqrtf(row_total(qv, slot + 1) * invC + eps);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = nb + 32 * nt + 8 * q;
-                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + n);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
-                    }
-            };
-            float rs = 1.0f;
-            if constexpr (EPI == EPI_ROWLN_TRAIN) {
-                if (p.rowscale) {
-                    const int64_t mm = live ? m : p.M - 1;
-                    rs = p.rowscale[p.rs_temporal ? (mm / p.rs_FJ) * p.rs_J + mm % p.rs_J : mm / p.rs_J];
-                }
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = nb + 32 * nt + 8 * q;
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.resid + mo + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if constexpr (EPI == EPI_ROWLN_TRAIN)
-                            acc[nt][4 * q + e] = r4[e] + rs * (acc[nt][4 * q + e] + b4[e]);
-                        else
-                            acc[nt][4 * q + e] = (acc[nt][4 * q + e] + b4[e]) + r4[e];
-                    }
-                    if constexpr (EPI == EPI_ROWLN_TRAIN) {
-                        if (p.out_pre && live) {
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
-                            *reinterpret_cast<f32x4*>(p.out_pre + mo + n) = v;
-                        }
-                    }
-                }
-            if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
-            if (p.pos) {  // only the first spatial block of a pass
-                const int f = (int)(((live ? m : p.M - 1) / p.posJ) % p.posF);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (int64_t)f * p.N + nb + 32 * nt + 8 * q);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] += pe[e];
-                    }
-            }
-            if (p.out_x && live) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
-                        *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
-                    }
-            }
-            if (p.next_w) {
-                layer_norm(p.next_w, p.next_b, p.next_eps, 2);
-                if (p.out_n && live) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
-                            *reinterpret_cast<f32x4*>(p.out_n + mo + nb + 32 * nt + 8 * q) = v;
-                        }
-                }
-                if (p.out_head) {
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + nb + 32 * nt + 8 * q);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) s += acc[nt][4 * q + e] * hw[e];
-                            }
-                        s = row_total(s, 4 + k);
-                        if (live && h == 0 && wn == 0) p.out_head[m * 3 + k] = s + p.head_b[k];
-                    }
-                }
-            }
-            PAFUSE_STAMP(2);
-            return;
-        }
+        epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem);
+        return;
     }
     // accumulator element (nt, reg) of this lane is  row = (reg&3) + 8*(reg>>2) + 4*h,  col = 32*nt + r  of the strip
     if constexpr (EPI == EPI_BIAS) {
@@ -549,6 +562,151 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     } else {
         static_assert(TR, "the whole-row epilogue exists in row-per-lane (TR) form only");
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Split-precision linear layer, LDS-DMA pipelined form:  out = epilogue(A[M,K] @ W[N,K]^T + bias)  with bf16x3 products.
+//
+// Same arithmetic and the same W' image as gemm_kernel<.., BF16 = 2>; what changes is how operands reach the matrix
+// cores.  With the MFMA time cut to 3/8 the kernel is bound by the bytes a CU can pull in per clock, so (i) tiles are
+// as tall as the register file allows (WM waves x 32 rows share one W' stream; 256 x 128: 37 FLOP per staged byte
+// against 26 for 128 x 128), (ii) nothing is staged through registers: both operands go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 1 KiB per wave instruction) into an NSTAGE ring that runs ahead of the MFMAs behind a
+// counted vmcnt, one raw s_barrier per 32-deep chunk, one workgroup per CU.
+//   A stage : [BM rows][128 B] unpadded; 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7), applied on the
+//             SOURCE address of the DMA (its LDS side is lane-linear) and again on the fragment reads: with 128-byte
+//             rows even and odd rows own the two halves of the 64 banks, and (r >> 1) & 7 spreads the 8 rows of a
+//             half over its 8 bank quads - conflict-free ds_read_b128.
+//   W stage : [BN rows][192 B], the W' image as it lies (rotated sub-blocks, see split_weights_kernel).
+// Accumulators are row-per-lane (operand roles swapped) and the epilogues are epilogue_row_per_lane.
+// ----------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int NT>
+struct DmaTile {
+    static constexpr int NW = WM * WN, NTHR = NW * 64;
+    static constexpr int BM = WM * 32, BN = WN * NT * 32;
+    static constexpr int A_BYTES = BM * 128, W_BYTES = BN * WSPLIT_ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int IA = A_BYTES / 1024, IW = W_BYTES / 1024;  // DMA wave-instructions per chunk
+    static constexpr int CNT = (IA + IW + NW - 1) / NW;              // per wave (uniform: surplus slots re-issue the last)
+    static_assert(W_BYTES % 1024 == 0 && A_BYTES % 1024 == 0, "whole DMA pieces");
+    static_assert(NW % 2 == 0, "the A swizzle of a wave's DMA lanes must not depend on the instruction index");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW>
+__global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
+    using T = DmaTile<WM, WN, NT>;
+    constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW;
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+    static_assert(CNT * (NSTAGE - 1) < 64, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, h = lane >> 5;
+    const int tiles_n = p.N / BN;
+    int tile;
+    {
+        const int nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, rem = nb & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int K = p.K, nk = K / BK;
+
+    // ---- DMA sources.  Instruction i of a chunk (0 .. IA + IW - 1) belongs to wave i % NW; A instruction ia covers
+    // rows 8 ia .. 8 ia + 7 (lane l: row 8 ia + (l >> 3), LDS position l & 7), W instruction iw the iw-th KiB of the tile's
+    // chunk of the image.
+    const float* Abase = p.A + m0 * K;
+    const uint8_t* Wbase = p.Wsplit + (int64_t)n0 * WSPLIT_ROW_BYTES + lane * 16;
+    const int64_t ws_chunk = (int64_t)p.N * WSPLIT_ROW_BYTES;
+    const int sw_src = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);  // source chunk of this lane's LDS position
+    int a_off[CNT];   // float offset of this lane's source in instruction slot j (if that slot is an A instruction)
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        int i = wave + j * NW;
+        i = i < IA + IW ? i : IA + IW - 1;
+        const int row = 8 * (i < IA ? i : 0) + (lane >> 3);
+        const int64_t lim = p.M - 1 - m0;  // >= 0: tail rows read a valid row (never stored)
+        const int grow = row < lim ? row : (int)lim;
+        a_off[j] = grow * K + sw_src * 4;
+    }
+    auto issue = [&](int kc, int st) {
+        uint8_t* const sa = lds + st * T::STAGE_BYTES;
+        const float* Ak = Abase + kc * BK;
+        const uint8_t* Wk = Wbase + kc * ws_chunk;
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) {
+            int i = wave + j * NW;  // wave-uniform
+            i = i < IA + IW ? i : IA + IW - 1;
+            if (i < IA)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ak + a_off[j]),
+                                                 (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wk + (i - IA) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(sa + T::A_BYTES + (i - IA) * 1024),
+                                                 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+
+    // fragment addresses (bytes inside a stage)
+    const int sw = (r >> 1) & 7;
+    const int a_row = (wm * 32 + r) * 128;
+    int a_pos[4];  // step s2, half e: position of logical chunk 4 s2 + 2 h + e
+#pragma unroll
+    for (int x = 0; x < 4; ++x) a_pos[x] = a_row + (((4 * (x >> 1) + 2 * h + (x & 1)) ^ sw) * 16);
+    const int w_row = T::A_BYTES + (wn * NT * 32 + r) * WSPLIT_ROW_BYTES;
+    const int w_sub[2] = {w_row + wsplit_sub_offset(r, h), w_row + wsplit_sub_offset(r, 2 + h)};
+
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) issue(s, s);
+
+    for (int kc = 0; kc < nk; ++kc) {
+        // chunk kc has landed once at most the NSTAGE - 2 younger chunks of this wave are still in flight
+        if (kc + NSTAGE - 2 < nk)
+            wait_vmcnt<CNT*(NSTAGE - 2)>();
+        else
+            wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // chunk kc visible to every wave; every wave is done reading chunk kc - 1
+        if (kc + NSTAGE - 1 < nk) issue(kc + NSTAGE - 1, (kc + NSTAGE - 1) % NSTAGE);
+        const uint8_t* st = lds + (kc % NSTAGE) * T::STAGE_BYTES;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8x3 a = split3(*reinterpret_cast<const f32x4*>(st + a_pos[2 * s2]),
+                                      *reinterpret_cast<const f32x4*>(st + a_pos[2 * s2 + 1]));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint8_t* wp = st + w_sub[s2] + nt * 32 * WSPLIT_ROW_BYTES;
+                const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+                const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 16);
+                const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 32);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s2, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a.s0, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s1, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s1, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s0, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s0, acc[nt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();  // the staging LDS becomes the epilogue's scratch
+    epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

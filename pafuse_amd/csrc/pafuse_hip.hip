@@ -90,6 +90,25 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm_kernel");
 }
 
+// split-precision GEMM, LDS-DMA pipelined form (one workgroup per CU, NSTAGE ring of 32-deep chunks)
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW>
+int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
+    using T = DmaTile<WM, WN, NT>;
+    constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
+    if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    if (lds > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, s, p);
+    return check_launch("gemm_dma_kernel");
+}
+
 int gemm_bias(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)

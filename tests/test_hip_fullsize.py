@@ -215,6 +215,7 @@ def test_unit_entry_points_refuse_bad_operands():
     assert b"joint list" in lib.pafuse_last_error()
     assert lib.pafuse_embed(p, p, None, None, None, p, p, p, p, p, p, 1e-6, 1, 1, 1, 4, 4, 66, 1, 0, 1.0, p, p, None) == -2
     st = _lib.DDIMStep()
+    st.last = 1
     arr, cnt = (C.c_void_p * 1)(p), (C.c_int32 * 1)(3)
     assert lib.pafuse_ddim_finalize(arr, cnt, 1, p, p, None, p, None, p, 1, 1, 1, 4, 1, 0, 0, 1.0, C.byref(st), None) == -2
     assert b"cover" in lib.pafuse_last_error()

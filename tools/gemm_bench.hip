@@ -40,15 +40,16 @@ float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double us = ms * 1e3 / reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
-    // plain-bias runs: keep the f32 result of a shape as the reference, report how far a split run is from it
+    // keep the f32 result of a shape as the reference, report how far a split run is from it (whole-row kernels: out_n)
     double maxd = -1.0, meand = 0.0;
-    if (EPI == EPI_BIAS && p.out) {
+    const float* res = EPI == EPI_BIAS ? p.out : p.out_n;
+    if (res) {
         const size_t n = (size_t)p.M * p.N;
         if (n > g_out_elems) { free(g_ref); free(g_out_host); g_ref = (float*)malloc(n * 4); g_out_host = (float*)malloc(n * 4); g_out_elems = n; }
         if (MODE == 0) {
-            CK(hipMemcpy(g_ref, p.out, n * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(g_ref, res, n * 4, hipMemcpyDeviceToHost));
         } else {
-            CK(hipMemcpy(g_out_host, p.out, n * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(g_out_host, res, n * 4, hipMemcpyDeviceToHost));
             maxd = 0.0;
             for (size_t i = 0; i < n; ++i) { double d = fabs((double)g_out_host[i] - g_ref[i]); meand += d; if (d > maxd) maxd = d; }
             meand /= n;
@@ -62,14 +63,54 @@ float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     return us;
 }
 
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW>
+float time_dma(const char* tag, GemmParams p, int reps = 20) {
+    using T = DmaTile<WM, WN, NT>;
+    if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
+    if (const char* r = getenv("GB_REPS")) reps = atoi(r);
+    size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    p.bf16 = 2;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
+                       (uint8_t*)p.Wsplit, p.N, p.K);
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    double maxd = -1.0, meand = 0.0;
+    const float* res = EPI == EPI_BIAS ? p.out : p.out_n;
+    if (res && g_ref) {
+        const size_t n = (size_t)p.M * p.N;
+        CK(hipMemcpy(g_out_host, res, n * 4, hipMemcpyDeviceToHost));
+        maxd = 0.0;
+        for (size_t i = 0; i < n; ++i) { double d = fabs((double)g_out_host[i] - g_ref[i]); meand += d; if (d > maxd) maxd = d; }
+        meand /= n;
+    }
+    printf("%-34s M=%6ld N=%4d K=%3d tiles=%5ld lds=%6zu : %8.1f us  %6.1f TF/s (%.1f%% of f32 peak)", tag, (long)p.M, p.N, p.K,
+           (long)tiles, lds, us, tf, tf / 157.3 * 100);
+    if (maxd >= 0) printf("  |d vs f32| max %.2e mean %.2e", maxd, meand);
+    printf("\n");
+    fflush(stdout);
+    return us;
+}
+
 int main() {
     const int64_t Mmax = 73440;
-    float *A, *W, *bias, *out, *x, *xn, *vec;
+    float *A, *W, *bias, *out, *x, *xn, *vec, *xo;
     uint8_t* Wsp;
     CK(hipMalloc(&Wsp, 1152 * 768 * 6));
     CK(hipMalloc(&A, Mmax * 768 * 4)); CK(hipMalloc(&W, 1152 * 768 * 4)); CK(hipMalloc(&bias, 1152 * 4));
     CK(hipMalloc(&out, Mmax * 1152 * 4)); CK(hipMalloc(&x, Mmax * 384 * 4)); CK(hipMalloc(&xn, Mmax * 384 * 4));
     CK(hipMalloc(&vec, 1152 * 4));
+    CK(hipMalloc(&xo, Mmax * 384 * 4));
     std::vector<float> h(Mmax * 768);
     for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
     CK(hipMemcpy(A, h.data(), Mmax * 768 * 4, hipMemcpyHostToDevice));
@@ -81,64 +122,70 @@ int main() {
     p.A = A, p.W = W, p.bias = bias, p.out = out, p.Wsplit = Wsp;
     p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
     { const char* f = getenv("GB_FILTER"); if (!f) time_gemm<4, 1, 4, EPI_BIAS, 2>("(warm-up, ignore)", p, 200); }
-    // ---- production f32 tiles vs the split-precision (bf16x3) mode, shape by shape (MODE: 0 f32, 2 split)
+    // ---- f32 production tile (reference result) / best register-staged split tile / LDS-DMA pipelined split kernel
     p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body qkv  f32   <4,1,2> s1 minw5", p);
-    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("body qkv  split <4,1,2> s1 minw4", p);
-    time_gemm<4, 1, 2, EPI_BIAS, 1, 3, 0, 2>("body qkv  split <4,1,2> s1 minw3", p);
-    time_gemm<4, 1, 2, EPI_BIAS, 2, 2, 0, 2>("body qkv  split <4,1,2> s2 minw2", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <4,1,4> s1 minw2", p);
-    time_gemm<4, 1, 4, EPI_BIAS, 1, 3, 0, 2>("body qkv  split <4,1,4> s1 minw3", p);
-    time_gemm<4, 1, 4, EPI_BIAS, 2, 2, 0, 2>("body qkv  split <4,1,4> s2 minw2", p);
-    time_gemm<4, 1, 3, EPI_BIAS, 1, 3, 1, 2>("body qkv  split <4,1,3> s1 TR minw3", p);
-    time_gemm<4, 2, 2, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <4,2,2> s1 minw2", p);
-    time_gemm<8, 1, 2, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <8,1,2> s1 minw2", p);
-    time_gemm<8, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <8,1,4> s1 minw2", p);
-    time_gemm<4, 1, 2, EPI_BIAS, 1, 5, 0, 1>("body qkv  bf16  <4,1,2> s1 minw5", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2>("body qkv  dma <8,1,4> st2", p);
+    time_dma<4, 1, 4, EPI_BIAS, 3, 1>("body qkv  dma <4,1,4> st3", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 2>("body qkv  dma <4,1,4> st2", p);
+    time_dma<4, 1, 2, EPI_BIAS, 2, 2>("body qkv  dma <4,1,2> st2", p);
+    time_dma<4, 1, 2, EPI_BIAS, 3, 1>("body qkv  dma <4,1,2> st3", p);
+    time_dma<8, 1, 2, EPI_BIAS, 3, 2>("body qkv  dma <8,1,2> st3", p);
+    time_dma<8, 1, 3, EPI_BIAS, 2, 2>("body qkv  dma <8,1,3> st2", p);
+    time_dma<8, 1, 3, EPI_BIAS, 3, 2>("body qkv  dma <8,1,3> st3", p);
+    time_dma<4, 2, 2, EPI_BIAS, 3, 2>("body qkv  dma <4,2,2> st3", p);
+    time_dma<8, 2, 2, EPI_BIAS, 2, 4>("body qkv  dma <8,2,2> st2 (16 waves)", p);
     p.N = 768, p.act = 1;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body fc1+gelu f32   <4,1,2> s1", p);
-    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("body fc1+gelu split <4,1,2> s1", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body fc1+gelu split <4,1,4> s1", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2>("body fc1+gelu dma <8,1,4> st2", p);
+    time_dma<4, 1, 4, EPI_BIAS, 3, 1>("body fc1+gelu dma <4,1,4> st3", p);
+    time_dma<8, 1, 2, EPI_BIAS, 3, 2>("body fc1+gelu dma <8,1,2> st3", p);
     p.M = 73440, p.N = 672, p.K = 224, p.act = 0;
     time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>("face qkv  f32   <4,1,3> s1 TR", p);
     time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>("face qkv  split <4,1,3> s1 TR", p);
-    time_gemm<4, 1, 3, EPI_BIAS, 1, 3, 0, 2>("face qkv  split <4,1,3> s1 minw3", p);
+    time_dma<8, 1, 3, EPI_BIAS, 2, 2>("face qkv  dma <8,1,3> st2", p);
+    time_dma<8, 1, 3, EPI_BIAS, 3, 2>("face qkv  dma <8,1,3> st3", p);
+    time_dma<4, 1, 3, EPI_BIAS, 3, 1>("face qkv  dma <4,1,3> st3", p);
+    time_dma<8, 1, 7, EPI_BIAS, 2, 2>("face qkv  dma <8,1,7> st2", p);
     p.N = 448, p.act = 1;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("face fc1+gelu f32   <4,1,2> s1", p);
     time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("face fc1+gelu split <4,1,2> s1", p);
+    time_dma<8, 1, 2, EPI_BIAS, 3, 2>("face fc1+gelu dma <8,1,2> st3", p);
+    time_dma<8, 1, 7, EPI_BIAS, 2, 2>("face fc1+gelu dma <8,1,7> st2", p);
     p.M = 45360, p.N = 768, p.K = 256, p.act = 0;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("hands qkv f32   <4,1,2> s1", p);
     time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("hands qkv split <4,1,2> s1", p);
-    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("hands qkv split <4,1,4> s1", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2>("hands qkv dma <8,1,4> st2", p);
+    time_dma<4, 1, 4, EPI_BIAS, 3, 1>("hands qkv dma <4,1,4> st3", p);
     // whole-row kernels
     GemmParams q{};
-    q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn, q.Wsplit = Wsp;
+    q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = xo, q.out_n = xn, q.Wsplit = Wsp;
     q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
     q.M = 25920, q.N = 384, q.K = 768;
     time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2  rowln f32   <1,4,3>", q);
-    time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body fc2  rowln split <1,4,3>", q);
-    time_gemm<2, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body fc2  rowln split <2,4,3>", q);
-    time_gemm<2, 2, 6, EPI_ROWLN, 1, 1, 1, 2>("body fc2  rowln split <2,2,6>", q);
-    time_gemm<4, 2, 6, EPI_ROWLN, 1, 1, 1, 2>("body fc2  rowln split <4,2,6>", q);
     time_gemm<4, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body fc2  rowln split <4,4,3>", q);
+    time_dma<2, 4, 3, EPI_ROWLN, 2, 2>("body fc2  rowln dma <2,4,3> st2", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 2, 1>("body fc2  rowln dma <2,2,6> st2", q);
+    time_dma<2, 1, 12, EPI_ROWLN, 2, 1>("body fc2  rowln dma <2,1,12> st2", q);
     q.K = 384;
     time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln f32   <1,4,3>", q);
-    time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body proj rowln split <1,4,3>", q);
-    time_gemm<2, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body proj rowln split <2,4,3>", q);
     time_gemm<4, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body proj rowln split <4,4,3>", q);
+    time_dma<2, 4, 3, EPI_ROWLN, 2, 2>("body proj rowln dma <2,4,3> st2", q);
     q.M = 45360, q.N = 256, q.K = 512;
-    time_gemm<2, 2, 4, EPI_ROWLN, 1, 3, 1>("hands fc2 rowln f32   <2,2,4> minw3 (spills)", q);
     time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1>("hands fc2 rowln f32   <2,2,4> minw2", q);
     time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1, 2>("hands fc2 rowln split <2,2,4>", q);
-    time_gemm<2, 4, 2, EPI_ROWLN, 1, 1, 1, 2>("hands fc2 rowln split <2,4,2>", q);
-    time_gemm<4, 2, 4, EPI_ROWLN, 1, 1, 1, 2>("hands fc2 rowln split <4,2,4>", q);
-    time_gemm<4, 4, 2, EPI_ROWLN, 1, 1, 1, 2>("hands fc2 rowln split <4,4,2>", q);
+    time_dma<4, 2, 4, EPI_ROWLN, 2, 2>("hands fc2 rowln dma <4,2,4> st2", q);
+    time_dma<4, 4, 2, EPI_ROWLN, 2, 4>("hands fc2 rowln dma <4,4,2> st2", q);
+    time_dma<2, 2, 4, EPI_ROWLN, 2, 1>("hands fc2 rowln dma <2,2,4> st2", q);
+    time_dma<4, 1, 8, EPI_ROWLN, 2, 1>("hands fc2 rowln dma <4,1,8> st2", q);
+    time_dma<8, 1, 8, EPI_ROWLN, 2, 2>("hands fc2 rowln dma <8,1,8> st2", q);
     q.M = 73440, q.N = 224, q.K = 448;
     time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln f32   <1,7,1>", q);
-    time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1, 2>("face fc2  rowln split <1,7,1>", q);
-    time_gemm<2, 7, 1, EPI_ROWLN, 1, 1, 1, 2>("face fc2  rowln split <2,7,1>", q);
-    time_gemm<4, 7, 1, EPI_ROWLN, 1, 1, 1, 2>("face fc2  rowln split <4,7,1>", q);
     time_gemm<2, 1, 7, EPI_ROWLN, 1, 1, 1, 2>("face fc2  rowln split <2,1,7>", q);
-    time_gemm<4, 1, 7, EPI_ROWLN, 1, 1, 1, 2>("face fc2  rowln split <4,1,7>", q);
+    time_dma<4, 1, 7, EPI_ROWLN, 2, 1>("face fc2  rowln dma <4,1,7> st2", q);
+    time_dma<8, 1, 7, EPI_ROWLN, 2, 2>("face fc2  rowln dma <8,1,7> st2", q);
+    time_dma<2, 7, 1, EPI_ROWLN, 3, 3>("face fc2  rowln dma <2,7,1> st3", q);
     return 0;
 }
