@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace pafuse {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,6 +50,31 @@ __device__ __forceinline__ bf16x8x3 split3(const f32x4 lo, const f32x4 hi) {
     }
     return o;
 }
+
+// The same split in stages, for hand-placed software pipelines: two fp32 values -> three packed bf16 pairs (low half = the
+// first value).  Stage k consumes stage k-1; the stages are spread over the gaps of an MFMA chain by the caller.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+struct SplitPair {
+    float x0, x1;                    // what is left of the two values
+    uint32_t s0 = 0, s1 = 0, s2 = 0;  // the three slices, packed {bf16(x0), bf16(x1)}
+    __device__ __forceinline__ static uint32_t pack(float a, float b) {
+        const bf16x2 v = {(__bf16)a, (__bf16)b};  // one v_cvt_pk_bf16_f32 (RNE)
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    __device__ __forceinline__ void sub(uint32_t sl) {
+        x0 -= __builtin_bit_cast(float, sl << 16);          // exact
+        x1 -= __builtin_bit_cast(float, sl & 0xffff0000u);  // exact
+    }
+    template <int STAGE>
+    __device__ __forceinline__ void stage() {
+        if constexpr (STAGE == 0) s0 = pack(x0, x1);
+        if constexpr (STAGE == 1) sub(s0);
+        if constexpr (STAGE == 2) s1 = pack(x0, x1);
+        if constexpr (STAGE == 3) sub(s1);
+        if constexpr (STAGE == 4) s2 = pack(x0, x1);
+    }
+};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Pre-split weight image W' of a [N,K] fp32 matrix (K % 32 == 0): [K/32 chunks][N rows][192 bytes].  A row of a chunk
 // holds four sub-blocks (s2, h) of 8 consecutive k (k = 32*chunk + 16*s2 + 8*h + 0..7 - exactly what MFMA lane half h
@@ -591,13 +618,34 @@ struct DmaTile {
     static_assert(NW % 2 == 0, "the A swizzle of a wave's DMA lanes must not depend on the instruction index");
 };
 
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// LDS read hipcc does not know about: no compiler wait is ever inserted for it - the caller waits (counted) with an
+// asm s_waitcnt that names the destination as "+v" before the first use (cdna_hip_programming.md section 5.7, form ii).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW>
+// ABL (diagnostic builds of tools/gemm_bench.hip only; results wrong by design): 1 = no fragment reads / split / MFMAs
+// (the operand stream alone), 2 = no DMA (the compute side alone, on whatever the LDS holds), 3 = 2 without the split
+// arithmetic (raw fragment bits as slices: LDS reads + MFMAs only), 4 = 3 without the epilogue.
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
     using T = DmaTile<WM, WN, NT>;
     constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW;
@@ -605,6 +653,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
     static_assert(CNT * (NSTAGE - 1) < 64, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;  // LDS byte address of the ring
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -638,22 +687,22 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
         const int grow = row < lim ? row : (int)lim;
         a_off[j] = grow * K + sw_src * 4;
     }
-    auto issue = [&](int kc, int st) {
+    auto issue_piece = [&](int kc, int st, int j) {  // DMA instruction slot j (0 .. CNT - 1) of chunk kc into stage st
+        if constexpr (ABL >= 2) return;
         uint8_t* const sa = lds + st * T::STAGE_BYTES;
-        const float* Ak = Abase + kc * BK;
-        const uint8_t* Wk = Wbase + kc * ws_chunk;
+        int i = wave + j * NW;  // wave-uniform
+        i = i < IA + IW ? i : IA + IW - 1;
+        if (i < IA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Abase + kc * BK + a_off[j]),
+                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(Wbase + kc * ws_chunk + (i - IA) * 1024),
+                (__attribute__((address_space(3))) void*)(sa + T::A_BYTES + (i - IA) * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int kc, int st) {
 #pragma unroll
-        for (int j = 0; j < CNT; ++j) {
-            int i = wave + j * NW;  // wave-uniform
-            i = i < IA + IW ? i : IA + IW - 1;
-            if (i < IA)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ak + a_off[j]),
-                                                 (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-            else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wk + (i - IA) * 1024),
-                                                 (__attribute__((address_space(3))) void*)(sa + T::A_BYTES + (i - IA) * 1024),
-                                                 16, 0, 0);
-        }
+        for (int j = 0; j < CNT; ++j) issue_piece(kc, st, j);
     };
 
     f32x16 acc[NT];
@@ -682,30 +731,148 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
         else
             wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // chunk kc visible to every wave; every wave is done reading chunk kc - 1
-        if (kc + NSTAGE - 1 < nk) issue(kc + NSTAGE - 1, (kc + NSTAGE - 1) % NSTAGE);
+        // the refill of the stage chunk kc - 1 occupied (chunk kc + NSTAGE - 1) is issued piece by piece inside the MFMA
+        // groups below: a DMA instruction costs its wave 60-180 cycles of issue, which a burst here would take from
+        // the matrix pipe of every SIMD at once (all waves leave the barrier together)
+        const bool refill = kc + NSTAGE - 1 < nk;
+        const int kn = kc + NSTAGE - 1, stn = kn % NSTAGE;
         const uint8_t* st = lds + (kc % NSTAGE) * T::STAGE_BYTES;
+        if constexpr (ABL == 1) continue;
+        // ---- one 32-deep chunk = NG = 2 NT groups (s2, nt) of six MFMAs on one accumulator.  Hand-placed pipeline
+        // (sched_barrier fences pin the order): the W' fragments of group g + 1 are read while group g's MFMAs run; the
+        // A fragment of step s2 = 1 is split in the gaps of the s2 = 0 MFMA chains, one pair-stage per gap; only the
+        // split of step 0 (44 VALU instructions) runs with the matrix pipe idle, once per chunk.
+        constexpr int NG = 2 * NT;
         __builtin_amdgcn_s_setprio(1);
+        // Order pins.  hipcc moves loads and register-only instructions freely across __builtin_amdgcn_sched_barrier and
+        // waits lgkmcnt(0) where a counted wait would do, so (i) every LDS read of the loop is an asm ds_read_b128 and
+        // every wait an asm s_waitcnt that names the registers it makes valid (nothing of hipcc's own is in flight on
+        // lgkmcnt inside the loop), (ii) the order is pinned through data: an empty volatile asm that "rewrites" the
+        // accumulator sits between consecutive MFMAs of a chain, one that rewrites a SplitPair's registers between
+        // consecutive split stages.  (The accumulator pins need it in VGPRs: MINW >= 2, no AGPR allocation.)
+#define PAFUSE_PIN_ACC(A) asm volatile("" : "+v"(A))
+#define PAFUSE_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
+        const uint32_t sbase = lds0 + (uint32_t)((kc % NSTAGE) * T::STAGE_BYTES);
+        u32x4 wf[2][3];
+        auto load_w = [&](auto G) {  // the three slices of group G's W' fragment
+            constexpr int g = decltype(G)::value;
+            constexpr int full = (g % NT) * 32 * WSPLIT_ROW_BYTES;
+            constexpr int off = full + 32 < 65536 ? full : 0;  // ds_read immediates are 16 bits: fold the rest into the address
+            const uint32_t addr = sbase + (uint32_t)w_sub[g / NT] + (uint32_t)(full - off);
+            wf[g & 1][0] = lds_read128<off>(addr);
+            wf[g & 1][1] = lds_read128<off + 16>(addr);
+            wf[g & 1][2] = lds_read128<off + 32>(addr);
+        };
+        u32x4 a_lo = lds_read128<0>(sbase + (uint32_t)a_pos[0]);
+        u32x4 a_hi = lds_read128<0>(sbase + (uint32_t)a_pos[1]);
+        load_w(std::integral_constant<int, 0>{});
+        u32x4 b_lo = lds_read128<0>(sbase + (uint32_t)a_pos[2]);
+        u32x4 b_hi = lds_read128<0>(sbase + (uint32_t)a_pos[3]);
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a_lo), "+v"(a_hi));  // the five younger reads stay in flight
+        SplitPair sp[4];
+        u32x4 cur[3], nxt[3];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8x3 a = split3(*reinterpret_cast<const f32x4*>(st + a_pos[2 * s2]),
-                                      *reinterpret_cast<const f32x4*>(st + a_pos[2 * s2 + 1]));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const uint8_t* wp = st + w_sub[s2] + nt * 32 * WSPLIT_ROW_BYTES;
-                const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
-                const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 16);
-                const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 32);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s2, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a.s0, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s1, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s1, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s0, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s0, acc[nt], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            sp[q].x0 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q] : a_hi[2 * q - 4]);
+            sp[q].x1 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q + 1] : a_hi[2 * q - 3]);
+            if constexpr (ABL >= 3) {
+                cur[0][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
+                cur[2][q] = cur[0][q];
+                continue;
             }
+            sp[q].template stage<0>(), sp[q].template stage<1>(), sp[q].template stage<2>(), sp[q].template stage<3>();
+            sp[q].template stage<4>();
+            cur[0][q] = sp[q].s0, cur[1][q] = sp[q].s1, cur[2][q] = sp[q].s2;
         }
+        static_for<NG>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int nt = g % NT;
+            // pairs of the s2 = 1 fragment split inside this group (all of them are done when group NT - 1 ends)
+            constexpr int q0 = (g < NT && ABL < 3) ? (4 * nt) / NT : 0, q1 = (g < NT && ABL < 3) ? (4 * (nt + 1)) / NT : 0;
+            if constexpr (g + 1 < NG) {
+                load_w(std::integral_constant<int, g + 1>{});  // in flight during this group's MFMAs
+                if constexpr (g == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(3)"
+                                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[0][2]), "+v"(b_lo), "+v"(b_hi));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sp[q].x0 = __builtin_bit_cast(float, q < 2 ? b_lo[2 * q] : b_hi[2 * q - 4]);
+                        sp[q].x1 = __builtin_bit_cast(float, q < 2 ? b_lo[2 * q + 1] : b_hi[2 * q - 3]);
+                    }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
+                }
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
+            }
+            const u32x4(&w)[3] = wf[g & 1];
+            auto mm = [&](int wi, int ai) {
+                PAFUSE_PIN_ACC(acc[nt]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[wi]),
+                                                                  __builtin_bit_cast(bf16x8, cur[ai]), acc[nt], 0, 0, 0);
+            };
+            auto pins = [&]() {
+#pragma unroll
+                for (int q = q0; q < q1; ++q) PAFUSE_PIN_PAIR(sp[q]);
+            };
+            // small terms first, the leading product last; one split stage per gap
+            pins();
+            mm(0, 2);
+            {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
+                constexpr int PER = (CNT + NG - 1) / NG, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
+                if constexpr (j0 < j1 && ABL < 2) {
+                    asm volatile("" ::: "memory");
+                    if (refill) {
+#pragma unroll
+                        for (int j = j0; j < j1; ++j) issue_piece(kn, stn, j);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+#pragma unroll
+            for (int q = q0; q < q1; ++q) sp[q].template stage<0>();
+            pins();
+            mm(2, 0);
+#pragma unroll
+            for (int q = q0; q < q1; ++q) sp[q].template stage<1>();
+            pins();
+            mm(1, 1);
+#pragma unroll
+            for (int q = q0; q < q1; ++q) sp[q].template stage<2>();
+            pins();
+            mm(0, 1);
+#pragma unroll
+            for (int q = q0; q < q1; ++q) sp[q].template stage<3>();
+            pins();
+            mm(1, 0);
+#pragma unroll
+            for (int q = q0; q < q1; ++q) {
+                sp[q].template stage<4>();
+                nxt[0][q] = sp[q].s0, nxt[1][q] = sp[q].s1, nxt[2][q] = sp[q].s2;
+            }
+            pins();
+            mm(0, 0);
+            if constexpr (g == NT - 1 && ABL < 3) cur[0] = nxt[0], cur[1] = nxt[1], cur[2] = nxt[2];
+            if constexpr (g == NT - 1 && ABL >= 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    cur[0][q] = cur[2][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
+            }
+        });
+#undef PAFUSE_PIN_ACC
+#undef PAFUSE_PIN_PAIR
         __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();  // the staging LDS becomes the epilogue's scratch
+    if constexpr (ABL == 4) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc += acc[nt][i];
+        if (sacc == 123.456f) p.out[0] = sacc;  // keeps the accumulators alive, stores nothing
+        return;
+    }
     epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem);
 }
 

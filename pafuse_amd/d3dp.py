@@ -111,6 +111,10 @@ class D3DP(nn.Module):
         #                                 the clip axis (clips are independent, results are bit-identical); bounds the
         #                                 workspace (0.9 GB per 40 rows) and keeps activations cache-resident
         self._graphs = {}
+        # matrix-product mode: inference defaults to the split-precision products (fp32-equivalent: the same parity
+        # bounds as the fp32 matrix cores hold, tests/test_hip_parity.py), training to the fp32 matrix cores
+        for m in self.pose_estimator.values():
+            m.operand_bf16 = self.PRECISIONS["f32" if is_train else "bf16x3"]
 
     PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
 

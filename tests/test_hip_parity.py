@@ -206,11 +206,11 @@ def test_g5_flip_loop_golden(g5, precision):
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=2, n=2, seed=1)
     model.noise_fn = lambda k, shape, device: noises[k]
-    model.precision = precision
+    before, model.precision = model.precision, precision
     try:
         out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     finally:
-        model.precision = "f32"
+        model.precision = before
     assert out.shape == (1, 2, 2, 27, 134, 3)
     assert torch.allclose(out, z["flip_out"], rtol=0, atol=1e-5), (out - z["flip_out"]).abs().max()
 
@@ -546,6 +546,7 @@ def test_torch_custom_ops_equal_the_modules():
     g, be = _seeded((256,), 4).to(DEV), _seeded((256,), 5).to(DEV)
     assert torch.equal(ops.layer_norm(x, g, be, 1e-6), wrap.layer_norm(x, g, be, 1e-6))
     model, _ = make_model(3, 2, seed=91)
+    model.precision = "f32"                     # the schema'd ops take the fp32 parameters only: the fp32 matrix cores
     body = model.pose_estimator["body"]
     x2d = _seeded((2, 27, 24, 2), 6).to(DEV)
     x3d = _seeded((2, 3, 27, 24, 3), 7).to(DEV)
@@ -670,15 +671,23 @@ def test_linear_bf16_operands(M, N, K):
     assert not torch.equal(plain, out)                                   # it really is the other arithmetic
 
 
+# |MPJPE_bf16 - MPJPE_f32| bound (mm) for the opt-in bf16-operand mode at BASELINE configs[1] (P=5, T=5).  Measured on
+# MI355X (profiles/r02_parity_report.json, case "5,5,1,bf16", against the oracle): J-Best 3.9, P-Best 3.3, P-Agg 3.4,
+# J-Agg 3.5 mm (max over the five steps); pointwise mean 2.0e-3 m, max 0.11 m (single joints of single hypotheses at the
+# noisiest step).  Rounding every matrix operand to 8 significant bits costs that much on random weights - bf16 autocast
+# of the reference itself sits at the same distance (hard part 1).
+BF16_MPJPE_TOL_MM = 6.0
+
+
 def test_bf16_precision_mode_end_to_end():
-    """model.precision = 'bf16' (BASELINE configs[1]: P=5, T=5): finite, close to the fp32 result at bf16 accuracy,
-    and switching back restores the fp32 path bit for bit.  Reported, not a parity claim (tests/reports/parity_report.py
-    ... bf16 prints the distances): only gross failure is caught here."""
+    """model.precision = 'bf16' (BASELINE configs[1]: P=5, T=5): the documented distance from the fp32 path holds per
+    protocol, and switching back restores the fp32 path bit for bit."""
     from __graft_entry__ import make_model
     model, _ = make_model(5, 5, seed=61)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=5, n=5, seed=21)
     model.noise_fn = lambda k, shape, device: noises[k]
+    model.precision = "f32"
     f32 = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
     model.precision = "bf16"
     assert model.precision == "bf16"
@@ -687,4 +696,8 @@ def test_bf16_precision_mode_end_to_end():
     again = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
     assert torch.equal(f32, again)
     err = (low - f32).abs()
-    assert bool(torch.isfinite(low).all()) and 0 < float(err.max()) < 0.5 and float(err.mean()) < 2e-2, (err.max(), err.mean())
+    assert bool(torch.isfinite(low).all()) and 0 < float(err.mean()) < 4e-3 and float(err.max()) < 0.25, (err.max(), err.mean())
+    target = orc.center_pose_parts(gu.synthetic_target_3d(1))
+    got, want = _mpjpe_report(low.cpu(), target, x2d), _mpjpe_report(f32.cpu(), target, x2d)
+    for k in want:
+        assert (got[k] - want[k]).abs().max() <= BF16_MPJPE_TOL_MM, (k, (got[k] - want[k]).abs())

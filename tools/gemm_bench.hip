@@ -63,7 +63,7 @@ float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     return us;
 }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0>
 float time_dma(const char* tag, GemmParams p, int reps = 20) {
     using T = DmaTile<WM, WN, NT>;
     if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
@@ -72,7 +72,7 @@ float time_dma(const char* tag, GemmParams p, int reps = 20) {
     p.bf16 = 2;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
                        (uint8_t*)p.Wsplit, p.N, p.K);
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, ABL>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     hipEvent_t e0, e1;
@@ -127,10 +127,19 @@ int main() {
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body qkv  f32   <4,1,2> s1 minw5", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <4,1,4> s1 minw2", p);
     time_dma<8, 1, 4, EPI_BIAS, 2, 2>("body qkv  dma <8,1,4> st2", p);
-    time_dma<4, 1, 4, EPI_BIAS, 3, 1>("body qkv  dma <4,1,4> st3", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2, 1>("body qkv  dma <8,1,4> st2 ABL1 stream only", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2, 2>("body qkv  dma <8,1,4> st2 ABL2 compute only", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2, 3>("body qkv  dma <8,1,4> st2 ABL3 lds+mfma only", p);
+    time_dma<8, 1, 4, EPI_BIAS, 2, 2, 4>("body qkv  dma <8,1,4> st2 ABL4 lds+mfma, no epilogue", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 2, 3>("body qkv  dma <4,1,4> st2 ABL3 lds+mfma only", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 2, 4>("body qkv  dma <4,1,4> st2 ABL4 lds+mfma, no epilogue", p);
+    time_dma<4, 1, 2, EPI_BIAS, 2, 2, 4>("body qkv  dma <4,1,2> st2 ABL4 lds+mfma, no epilogue", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 2, 1>("body qkv  dma <4,1,4> st2 ABL1 stream only", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 2, 2>("body qkv  dma <4,1,4> st2 ABL2 compute only", p);
+    time_dma<4, 1, 4, EPI_BIAS, 3, 2>("body qkv  dma <4,1,4> st3", p);
     time_dma<4, 1, 4, EPI_BIAS, 2, 2>("body qkv  dma <4,1,4> st2", p);
     time_dma<4, 1, 2, EPI_BIAS, 2, 2>("body qkv  dma <4,1,2> st2", p);
-    time_dma<4, 1, 2, EPI_BIAS, 3, 1>("body qkv  dma <4,1,2> st3", p);
+    time_dma<4, 1, 2, EPI_BIAS, 3, 2>("body qkv  dma <4,1,2> st3", p);
     time_dma<8, 1, 2, EPI_BIAS, 3, 2>("body qkv  dma <8,1,2> st3", p);
     time_dma<8, 1, 3, EPI_BIAS, 2, 2>("body qkv  dma <8,1,3> st2", p);
     time_dma<8, 1, 3, EPI_BIAS, 3, 2>("body qkv  dma <8,1,3> st3", p);
