@@ -167,6 +167,7 @@ def main():
                                            "performance number)") if world > 1 else None),
                    "single_device_rehearsal": bool(args.single_device),
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
+        "kernel_source_sha256": _lib.kernel_source_digest(),
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
         "allgather_ms": gather_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,

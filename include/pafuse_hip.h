@@ -120,11 +120,13 @@ int pafuse_linear(const float *A, const float *W, const float *bias, float *out,
                   int32_t act, void *stream);
 
 /* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K bytes
- * ([K/32][N][192 B]: per row and 32-wide K chunk, 4 sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels' LDS
- * image).  pafuse_linear_split is pafuse_linear on such an image (act: 0 none, 1 GELU): the unit entry of the
- * split-precision products, which replace the same nn.Linear call sites (common/mixste.py:38-42,65,80). */
+ * ([K/c][N][6c B] with c = 32 or 16: per row and K chunk, sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels'
+ * LDS image; the library picks c from the shape and from `whole_row`: 1 for a weight used by a whole-row layer - attn.proj,
+ * mlp.fc2 - 0 for attn.qkv, mlp.fc1 and pafuse_linear_split).  pafuse_linear_split is pafuse_linear on such an image
+ * (made with whole_row = 0; act: 0 none, 1 GELU): the unit entry of the split-precision products, which replace the same
+ * nn.Linear call sites (common/mixste.py:38-42,65,80). */
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K);
-int pafuse_split_weights(const float *W, int32_t N, int32_t K, void *out, void *stream);
+int pafuse_split_weights(const float *W, int32_t N, int32_t K, int32_t whole_row, void *out, void *stream);
 int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, float *out, int64_t M, int32_t N,
                         int32_t K, int32_t act, void *stream);
 
@@ -162,7 +164,10 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights *w, const float *x2d, co
  * `aux_streams` (may be NULL / n_aux 0): extra HIP streams; a step's work is cut into (part, hypothesis-group) lanes,
  * one stream each, groups = (n_aux + 1) / parts (>= 1): 2 aux streams = the three parts side by side (fastest
  * measured; more lanes cost more in small launches than they gain in overlap).  Events are created and destroyed
- * inside the call only when aux streams are given. */
+ * inside the call only when aux streams are given.  Aux streams are IGNORED when any part runs a bf16-MFMA mode
+ * (operand_bf16 != 0): those kernels must not share the GPU with kernels of other hardware queues (erratum-like
+ * behaviour of v_mfma_f32_32x32x16_bf16 under multi-queue concurrency, profiles/r02_bf16_mfma_concurrency.md);
+ * pafuse_d3dp_lanes then returns 1. */
 size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config *cfg, int32_t B, int32_t P);
 int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *steps, int32_t nsteps,
                        const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,

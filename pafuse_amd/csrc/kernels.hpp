@@ -29,6 +29,28 @@ __device__ __forceinline__ bf16x8 to_bf16x8(const f32x4 lo, const f32x4 hi) {
     return v;
 }
 
+// One 16-deep bf16 MFMA step on a 32x32 accumulator.  -DPAFUSE_MFMA_K8 (diagnostic build) issues it as two 8-deep
+// v_mfma_f32_32x32x8_bf16_1k on the lower / upper four elements of both fragments (same k pairing for A and B).
+#ifdef PAFUSE_MFMA_K8
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_bf16_k16(const bf16x8 a, const bf16x8 b, f32x16 c) {
+    const bf16x4_t a0 = {a[0], a[1], a[2], a[3]}, a1 = {a[4], a[5], a[6], a[7]};
+    const bf16x4_t b0 = {b[0], b[1], b[2], b[3]}, b1 = {b[4], b[5], b[6], b[7]};
+    c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4_t, a0), __builtin_bit_cast(s16x4_t, b0), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4_t, a1), __builtin_bit_cast(s16x4_t, b1), c, 0, 0, 0);
+}
+#else
+__device__ __forceinline__ f32x16 mfma_bf16_k16(const bf16x8 a, const bf16x8 b, f32x16 c) {
+#ifdef PAFUSE_MFMA_NOP
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop %0" ::"n"(PAFUSE_MFMA_NOP));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
+
 // ---- split precision ("bf16x3"): an fp32 value as the sum of three bf16 numbers, x = s0 + s1 + s2 (exact up to
 // 2^-24 |x|: each slice takes the next 8 significand bits of what is left, round-to-nearest).  A product of two split
 // operands keeps the six terms of order <= 2^-16 (s0*t0; s0*t1, s1*t0; s1*t1, s0*t2, s2*t0) on the bf16 matrix cores
@@ -76,25 +98,34 @@ struct SplitPair {
 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Pre-split weight image W' of a [N,K] fp32 matrix (K % 32 == 0): [K/32 chunks][N rows][192 bytes].  A row of a chunk
-// holds four sub-blocks (s2, h) of 8 consecutive k (k = 32*chunk + 16*s2 + 8*h + 0..7 - exactly what MFMA lane half h
-// feeds to 16-deep step s2) x three slices, 16 bytes each: sub-block sb = 2*s2 + h sits at position
-// (sb + (n >> 2)) & 3 of the row (a rotation that makes the ds_read_b128 fragment reads of 16 consecutive rows hit 16
-// different bank quads with unpadded 192-byte rows), its slices at +0, +16, +32.  The image is read as it lies: a
-// tile's chunk is one contiguous run of BN * 192 bytes in HBM and in LDS.
-constexpr int WSPLIT_ROW_BYTES = 192;
+// Pre-split weight image W' of a [N,K] fp32 matrix, in chunks of BKC = 32 or 16 along K:
+// [K/BKC chunks][N rows][6*BKC bytes].  A row of a chunk holds BKC/8 sub-blocks of 8 consecutive k (sub-block sb covers
+// k = BKC*chunk + 8*sb + 0..7; sb = 2*s2 + h is exactly what MFMA lane half h feeds to 16-deep step s2) x three slices,
+// 16 bytes each, slices at +0, +16, +32 of the sub-block.  Sub-blocks are rotated inside the row so that the
+// ds_read_b128 fragment reads of 16 consecutive rows hit 16 different bank quads with UNPADDED rows:
+//   BKC = 32 (192-byte rows): sub-block sb at position (sb + (n >> 2)) & 3;   BKC = 16 (96-byte rows): (sb + (n >> 3)) & 1.
+// The image is read as it lies: a tile's chunk is one contiguous run of BN * 6 * BKC bytes in HBM and in LDS.
+// BKC = 32 serves the plain linear layers (qkv, fc1), BKC = 16 the whole-row ones (proj, fc2), whose W' stage
+// (N = C rows) would not fit a multi-stage LDS ring at 32.
+constexpr int WSPLIT_ROW_BYTES = 192;  // BKC = 32
 __host__ __device__ inline size_t wsplit_bytes(int64_t N, int64_t K) { return (size_t)N * (size_t)K * 6; }
-__device__ __forceinline__ int wsplit_sub_offset(int n, int sb) { return ((sb + (n >> 2)) & 3) * 48; }
+template <int BKC = 32>
+__device__ __forceinline__ int wsplit_sub_offset(int n, int sb) {
+    static_assert(BKC == 32 || BKC == 16, "chunk depth");
+    return BKC == 32 ? ((sb + (n >> 2)) & 3) * 48 : ((sb + (n >> 3)) & 1) * 48;
+}
 
+template <int BKC>
 __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint8_t* out, int N, int K) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one (n, group of 8 k) per thread
     const int groups = K / 8;
     if (idx >= (int64_t)N * groups) return;
+    constexpr int SUBS = BKC / 8, ROW = 6 * BKC;
     const int n = (int)(idx / groups), g8 = (int)(idx % groups);
-    const int chunk = g8 >> 2, sb = g8 & 3;
+    const int chunk = g8 / SUBS, sb = g8 % SUBS;
     const float* src = W + (int64_t)n * K + g8 * 8;
     const bf16x8x3 s = split3(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
-    uint8_t* dst = out + ((int64_t)chunk * N + n) * WSPLIT_ROW_BYTES + wsplit_sub_offset(n, sb);
+    uint8_t* dst = out + ((int64_t)chunk * N + n) * ROW + wsplit_sub_offset<BKC>(n, sb);
     *reinterpret_cast<bf16x8*>(dst) = s.s0;
     *reinterpret_cast<bf16x8*>(dst + 16) = s.s1;
     *reinterpret_cast<bf16x8*>(dst + 32) = s.s2;
@@ -463,7 +494,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     const int a_frag = (wm * 32 + r) * LDK + (SPLIT ? 8 : 4) * h;
     const int w_frag = (wn * NT * 32 + r) * W_ROW + (SPLIT ? 0 : 4 * h);
     // split mode: float offset of this lane's sub-block (s2, h) inside a W' row (rotation by row, see split_weights_kernel)
-    const int ws_sub[2] = {wsplit_sub_offset(r, h) / 4, wsplit_sub_offset(r, 2 + h) / 4};
+    const int ws_sub[2] = {wsplit_sub_offset<32>(r, h) / 4, wsplit_sub_offset<32>(r, 2 + h) / 4};
     const int nk = K / BK;
     for (int kc = 0; kc < nk; ++kc) {
         const int cur = (NSTAGE == 2) ? (kc & 1) : 0;
@@ -485,19 +516,19 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
                     const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 8);
                     // small terms first, the leading product last
                     if constexpr (TR) {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s2, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a.s0, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s1, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s1, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a.s0, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a.s0, acc[nt], 0, 0, 0);
+                        acc[nt] = mfma_bf16_k16(w0, a.s2, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(w2, a.s0, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(w1, a.s1, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(w0, a.s1, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(w1, a.s0, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(w0, a.s0, acc[nt]);
                     } else {
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s2, w0, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s0, w2, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s1, w1, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s1, w0, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s0, w1, acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s0, w0, acc[nt], 0, 0, 0);
+                        acc[nt] = mfma_bf16_k16(a.s2, w0, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(a.s0, w2, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(a.s1, w1, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(a.s1, w0, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(a.s0, w1, acc[nt]);
+                        acc[nt] = mfma_bf16_k16(a.s0, w0, acc[nt]);
                     }
                 }
             }
@@ -510,8 +541,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
                 for (int nt = 0; nt < NT; ++nt) {
                     const bf16x8 w8 = to_bf16x8(*reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 16 * s2),
                                                 *reinterpret_cast<const f32x4*>(Wc + nt * 32 * LDK + 16 * s2 + 8));
-                    acc[nt] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w8, a8, acc[nt], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, w8, acc[nt], 0, 0, 0);
+                    acc[nt] = TR ? mfma_bf16_k16(w8, a8, acc[nt])
+                                 : mfma_bf16_k16(a8, w8, acc[nt]);
                 }
             }
         } else {
@@ -607,15 +638,17 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
 //   W stage : [BN rows][192 B], the W' image as it lies (rotated sub-blocks, see split_weights_kernel).
 // Accumulators are row-per-lane (operand roles swapped) and the epilogues are epilogue_row_per_lane.
 // ----------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT>
+template <int WM, int WN, int NT, int BKC = 32>
 struct DmaTile {
+    static_assert(BKC == 32 || BKC == 16, "chunk depth");
     static constexpr int NW = WM * WN, NTHR = NW * 64;
     static constexpr int BM = WM * 32, BN = WN * NT * 32;
-    static constexpr int A_BYTES = BM * 128, W_BYTES = BN * WSPLIT_ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int A_ROW = BKC * 4, W_ROW = BKC * 6;  // bytes per row of a stage
+    static constexpr int A_BYTES = BM * A_ROW, W_BYTES = BN * W_ROW, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int IA = A_BYTES / 1024, IW = W_BYTES / 1024;  // DMA wave-instructions per chunk
     static constexpr int CNT = (IA + IW + NW - 1) / NW;              // per wave (uniform: surplus slots re-issue the last)
     static_assert(W_BYTES % 1024 == 0 && A_BYTES % 1024 == 0, "whole DMA pieces");
-    static_assert(NW % 2 == 0, "the A swizzle of a wave's DMA lanes must not depend on the instruction index");
+    static_assert(BKC == 16 || NW % 2 == 0, "the A swizzle of a wave's DMA lanes must not depend on the instruction index");
 };
 
 template <int... Is, class F>
@@ -645,10 +678,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ABL (diagnostic builds of tools/gemm_bench.hip only; results wrong by design): 1 = no fragment reads / split / MFMAs
 // (the operand stream alone), 2 = no DMA (the compute side alone, on whatever the LDS holds), 3 = 2 without the split
 // arithmetic (raw fragment bits as slices: LDS reads + MFMAs only), 4 = 3 without the epilogue.
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
-    using T = DmaTile<WM, WN, NT>;
+    using T = DmaTile<WM, WN, NT, BKC>;
     constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW;
+    constexpr int NS2 = BKC / 16;                 // 16-deep MFMA steps per chunk
+    constexpr int RPI = 1024 / T::A_ROW;          // A rows per DMA instruction (8 at BKC = 32, 16 at BKC = 16)
+    constexpr int CPR = T::A_ROW / 16;            // 16-byte chunks per A row
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(CNT * (NSTAGE - 1) < 64, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -668,21 +704,23 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     const int n0 = tile_n * BN;
-    const int K = p.K, nk = K / BK;
+    const int K = p.K, nk = K / BKC;
 
     // ---- DMA sources.  Instruction i of a chunk (0 .. IA + IW - 1) belongs to wave i % NW; A instruction ia covers
-    // rows 8 ia .. 8 ia + 7 (lane l: row 8 ia + (l >> 3), LDS position l & 7), W instruction iw the iw-th KiB of the tile's
-    // chunk of the image.
+    // rows RPI ia .. RPI ia + RPI - 1 (lane l: row RPI ia + l / CPR, LDS position l % CPR), W instruction iw the iw-th KiB
+    // of the tile's chunk of the image.  A-stage swizzle: chunk c of row r at position c ^ ((r >> 1) & 7) (128-byte
+    // rows) / c ^ ((r >> 2) & 3) (64-byte rows): both depend on the lane only, not on the instruction index.
     const float* Abase = p.A + m0 * K;
-    const uint8_t* Wbase = p.Wsplit + (int64_t)n0 * WSPLIT_ROW_BYTES + lane * 16;
-    const int64_t ws_chunk = (int64_t)p.N * WSPLIT_ROW_BYTES;
-    const int sw_src = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);  // source chunk of this lane's LDS position
+    const uint8_t* Wbase = p.Wsplit + (int64_t)n0 * T::W_ROW + lane * 16;
+    const int64_t ws_chunk = (int64_t)p.N * T::W_ROW;
+    const int sw_src = BKC == 32 ? (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)   // source chunk of this lane's
+                                 : (lane & 3) ^ ((lane >> 4) & 3);                     // LDS position
     int a_off[CNT];   // float offset of this lane's source in instruction slot j (if that slot is an A instruction)
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
         int i = wave + j * NW;
         i = i < IA + IW ? i : IA + IW - 1;
-        const int row = 8 * (i < IA ? i : 0) + (lane >> 3);
+        const int row = RPI * (i < IA ? i : 0) + lane / CPR;
         const int64_t lim = p.M - 1 - m0;  // >= 0: tail rows read a valid row (never stored)
         const int grow = row < lim ? row : (int)lim;
         a_off[j] = grow * K + sw_src * 4;
@@ -693,7 +731,7 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
         int i = wave + j * NW;  // wave-uniform
         i = i < IA + IW ? i : IA + IW - 1;
         if (i < IA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Abase + kc * BK + a_off[j]),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Abase + kc * BKC + a_off[j]),
                                              (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
         else
             __builtin_amdgcn_global_load_lds(
@@ -712,156 +750,287 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
     // fragment addresses (bytes inside a stage)
-    const int sw = (r >> 1) & 7;
-    const int a_row = (wm * 32 + r) * 128;
-    int a_pos[4];  // step s2, half e: position of logical chunk 4 s2 + 2 h + e
+    const int sw = BKC == 32 ? (r >> 1) & 7 : (r >> 2) & 3;
+    const int a_row = (wm * 32 + r) * T::A_ROW;
+    int a_pos[4];  // step s2, half e: position of logical chunk 4 s2 + 2 h + e (entries 2, 3 unused at BKC = 16)
 #pragma unroll
-    for (int x = 0; x < 4; ++x) a_pos[x] = a_row + (((4 * (x >> 1) + 2 * h + (x & 1)) ^ sw) * 16);
-    const int w_row = T::A_BYTES + (wn * NT * 32 + r) * WSPLIT_ROW_BYTES;
-    const int w_sub[2] = {w_row + wsplit_sub_offset(r, h), w_row + wsplit_sub_offset(r, 2 + h)};
+    for (int x = 0; x < 4; ++x) a_pos[x] = a_row + (((4 * (x >> 1) + 2 * h + (x & 1)) ^ sw) & (CPR - 1)) * 16;
+    const int w_row = T::A_BYTES + (wn * NT * 32 + r) * T::W_ROW;
+    const int w_sub[2] = {w_row + wsplit_sub_offset<BKC>(r, h), w_row + wsplit_sub_offset<BKC>(r, (2 + h) % (BKC / 8))};
 
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) issue(s, s);
-
-    for (int kc = 0; kc < nk; ++kc) {
-        // chunk kc has landed once at most the NSTAGE - 2 younger chunks of this wave are still in flight
-        if (kc + NSTAGE - 2 < nk)
-            wait_vmcnt<CNT*(NSTAGE - 2)>();
-        else
-            wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // chunk kc visible to every wave; every wave is done reading chunk kc - 1
-        // the refill of the stage chunk kc - 1 occupied (chunk kc + NSTAGE - 1) is issued piece by piece inside the MFMA
-        // groups below: a DMA instruction costs its wave 60-180 cycles of issue, which a burst here would take from
-        // the matrix pipe of every SIMD at once (all waves leave the barrier together)
-        const bool refill = kc + NSTAGE - 1 < nk;
-        const int kn = kc + NSTAGE - 1, stn = kn % NSTAGE;
-        const uint8_t* st = lds + (kc % NSTAGE) * T::STAGE_BYTES;
-        if constexpr (ABL == 1) continue;
-        // ---- one 32-deep chunk = NG = 2 NT groups (s2, nt) of six MFMAs on one accumulator.  Hand-placed pipeline
-        // (sched_barrier fences pin the order): the W' fragments of group g + 1 are read while group g's MFMAs run; the
-        // A fragment of step s2 = 1 is split in the gaps of the s2 = 0 MFMA chains, one pair-stage per gap; only the
-        // split of step 0 (44 VALU instructions) runs with the matrix pipe idle, once per chunk.
-        constexpr int NG = 2 * NT;
-        __builtin_amdgcn_s_setprio(1);
-        // Order pins.  hipcc moves loads and register-only instructions freely across __builtin_amdgcn_sched_barrier and
-        // waits lgkmcnt(0) where a counted wait would do, so (i) every LDS read of the loop is an asm ds_read_b128 and
-        // every wait an asm s_waitcnt that names the registers it makes valid (nothing of hipcc's own is in flight on
-        // lgkmcnt inside the loop), (ii) the order is pinned through data: an empty volatile asm that "rewrites" the
-        // accumulator sits between consecutive MFMAs of a chain, one that rewrites a SplitPair's registers between
-        // consecutive split stages.  (The accumulator pins need it in VGPRs: MINW >= 2, no AGPR allocation.)
+    if constexpr (NS2 == 1 && NSTAGE == 3 && ABL != 1) {
+        // ---- cross-chunk software pipeline (16-deep chunks, three stages: chunk kc being multiplied, chunk kc + 1 landed
+        // and visible, chunk kc + 2 in flight).  Everything chunk kc + 1 needs from LDS before its first MFMA - its A
+        // fragment, split into slices, and the W' fragment of its group 0 - is fetched and computed inside the MFMA
+        // gaps of chunk kc, so a wave leaves the barrier with its operands in registers and the matrix pipe never
+        // waits for a split (one split per tile is exposed, in the prologue).
+        static_assert(NT >= 1, "groups");
 #define PAFUSE_PIN_ACC(A) asm volatile("" : "+v"(A))
 #define PAFUSE_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
-        const uint32_t sbase = lds0 + (uint32_t)((kc % NSTAGE) * T::STAGE_BYTES);
-        u32x4 wf[2][3];
-        auto load_w = [&](auto G) {  // the three slices of group G's W' fragment
-            constexpr int g = decltype(G)::value;
-            constexpr int full = (g % NT) * 32 * WSPLIT_ROW_BYTES;
-            constexpr int off = full + 32 < 65536 ? full : 0;  // ds_read immediates are 16 bits: fold the rest into the address
-            const uint32_t addr = sbase + (uint32_t)w_sub[g / NT] + (uint32_t)(full - off);
-            wf[g & 1][0] = lds_read128<off>(addr);
-            wf[g & 1][1] = lds_read128<off + 16>(addr);
-            wf[g & 1][2] = lds_read128<off + 32>(addr);
-        };
-        u32x4 a_lo = lds_read128<0>(sbase + (uint32_t)a_pos[0]);
-        u32x4 a_hi = lds_read128<0>(sbase + (uint32_t)a_pos[1]);
-        load_w(std::integral_constant<int, 0>{});
-        u32x4 b_lo = lds_read128<0>(sbase + (uint32_t)a_pos[2]);
-        u32x4 b_hi = lds_read128<0>(sbase + (uint32_t)a_pos[3]);
-        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a_lo), "+v"(a_hi));  // the five younger reads stay in flight
+        issue(0, 0);
+        if (1 < nk) issue(1, 1);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        u32x4 wf[2][3], cur[3], nxt[3];
         SplitPair sp[4];
-        u32x4 cur[3], nxt[3];
+        auto load_w = [&](auto SLOT, auto NTI, uint32_t stage_addr) {  // W' fragment of column block NTI into wf[SLOT]
+            constexpr int slot = decltype(SLOT)::value, nti = decltype(NTI)::value;
+            constexpr int full = nti * 32 * T::W_ROW;
+            constexpr int off = full + 32 < 65536 ? full : 0;
+            const uint32_t addr = stage_addr + (uint32_t)w_sub[0] + (uint32_t)(full - off);
+            wf[slot][0] = lds_read128<off>(addr);
+            wf[slot][1] = lds_read128<off + 16>(addr);
+            wf[slot][2] = lds_read128<off + 32>(addr);
+        };
+        {   // chunk 0: the one exposed fragment read + split of the tile
+            u32x4 a_lo = lds_read128<0>(lds0 + (uint32_t)a_pos[0]);
+            u32x4 a_hi = lds_read128<0>(lds0 + (uint32_t)a_pos[1]);
+            load_w(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, lds0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(a_lo), "+v"(a_hi), "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[0][2]));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            sp[q].x0 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q] : a_hi[2 * q - 4]);
-            sp[q].x1 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q + 1] : a_hi[2 * q - 3]);
-            if constexpr (ABL >= 3) {
-                cur[0][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
-                cur[2][q] = cur[0][q];
-                continue;
+            for (int q = 0; q < 4; ++q) {
+                sp[q].x0 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q] : a_hi[2 * q - 4]);
+                sp[q].x1 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q + 1] : a_hi[2 * q - 3]);
+                sp[q].template stage<0>(), sp[q].template stage<1>(), sp[q].template stage<2>();
+                sp[q].template stage<3>(), sp[q].template stage<4>();
+                cur[0][q] = sp[q].s0, cur[1][q] = sp[q].s1, cur[2][q] = sp[q].s2;
             }
-            sp[q].template stage<0>(), sp[q].template stage<1>(), sp[q].template stage<2>(), sp[q].template stage<3>();
-            sp[q].template stage<4>();
-            cur[0][q] = sp[q].s0, cur[1][q] = sp[q].s1, cur[2][q] = sp[q].s2;
         }
-        static_for<NG>([&](auto G) {
-            constexpr int g = decltype(G)::value;
-            constexpr int nt = g % NT;
-            // pairs of the s2 = 1 fragment split inside this group (all of them are done when group NT - 1 ends)
-            constexpr int q0 = (g < NT && ABL < 3) ? (4 * nt) / NT : 0, q1 = (g < NT && ABL < 3) ? (4 * (nt + 1)) / NT : 0;
-            if constexpr (g + 1 < NG) {
-                load_w(std::integral_constant<int, g + 1>{});  // in flight during this group's MFMAs
+        for (int kc = 0; kc < nk; ++kc) {
+            if (kc > 0) {
+                wait_vmcnt<0>();               // chunk kc + 1 (issued during chunk kc - 1) has landed
+                __builtin_amdgcn_s_barrier();  // ... for every wave; every wave is done with chunk kc - 1
+            }
+            const bool refill = kc + 2 < nk;
+            const int kn = kc + 2, stn = kn % 3;
+            const uint32_t s_cur = lds0 + (uint32_t)((kc % 3) * T::STAGE_BYTES);
+            const uint32_t s_nxt = lds0 + (uint32_t)(((kc + 1) % 3) * T::STAGE_BYTES);  // stale on the last chunk: unused
+            __builtin_amdgcn_s_setprio(1);
+            u32x4 n_lo = lds_read128<0>(s_nxt + (uint32_t)a_pos[0]);
+            u32x4 n_hi = lds_read128<0>(s_nxt + (uint32_t)a_pos[1]);
+            static_for<NT>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                constexpr int q0 = ABL < 3 ? (4 * g) / NT : 0, q1 = ABL < 3 ? (4 * (g + 1)) / NT : 0;
+                // the fragment the NEXT group needs: column block g + 1 of this chunk, or block 0 of the next chunk
+                if constexpr (g + 1 < NT)
+                    load_w(std::integral_constant<int, (g + 1) & 1>{}, std::integral_constant<int, g + 1>{}, s_cur);
+                else
+                    load_w(std::integral_constant<int, (g + 1) & 1>{}, std::integral_constant<int, 0>{}, s_nxt);
                 if constexpr (g == 0) {
-                    asm volatile("s_waitcnt lgkmcnt(3)"
-                                 : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[0][2]), "+v"(b_lo), "+v"(b_hi));
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(n_lo), "+v"(n_hi));  // only the three reads just issued fly
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        sp[q].x0 = __builtin_bit_cast(float, q < 2 ? b_lo[2 * q] : b_hi[2 * q - 4]);
-                        sp[q].x1 = __builtin_bit_cast(float, q < 2 ? b_lo[2 * q + 1] : b_hi[2 * q - 3]);
+                        sp[q].x0 = __builtin_bit_cast(float, q < 2 ? n_lo[2 * q] : n_hi[2 * q - 4]);
+                        sp[q].x1 = __builtin_bit_cast(float, q < 2 ? n_lo[2 * q + 1] : n_hi[2 * q - 3]);
                     }
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
                 }
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
-            }
-            const u32x4(&w)[3] = wf[g & 1];
-            auto mm = [&](int wi, int ai) {
-                PAFUSE_PIN_ACC(acc[nt]);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[wi]),
-                                                                  __builtin_bit_cast(bf16x8, cur[ai]), acc[nt], 0, 0, 0);
-            };
-            auto pins = [&]() {
+                const u32x4(&w)[3] = wf[g & 1];
+                auto mm = [&](int wi, int ai) {
+                    PAFUSE_PIN_ACC(acc[g]);
+                    acc[g] = mfma_bf16_k16(__builtin_bit_cast(bf16x8, w[wi]), __builtin_bit_cast(bf16x8, cur[ai]), acc[g]);
+                };
+                auto pins = [&]() {
 #pragma unroll
-                for (int q = q0; q < q1; ++q) PAFUSE_PIN_PAIR(sp[q]);
-            };
-            // small terms first, the leading product last; one split stage per gap
-            pins();
-            mm(0, 2);
-            {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
-                constexpr int PER = (CNT + NG - 1) / NG, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
-                if constexpr (j0 < j1 && ABL < 2) {
-                    asm volatile("" ::: "memory");
-                    if (refill) {
+                    for (int q = q0; q < q1; ++q) PAFUSE_PIN_PAIR(sp[q]);
+                };
+                pins();
+                mm(0, 2);
+                {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
+                    constexpr int PER = (CNT + NT - 1) / NT, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
+                    if constexpr (j0 < j1 && ABL < 2) {
+                        asm volatile("" ::: "memory");
+                        if (refill) {
 #pragma unroll
-                        for (int j = j0; j < j1; ++j) issue_piece(kn, stn, j);
+                            for (int j = j0; j < j1; ++j) issue_piece(kn, stn, j);
+                        }
+                        asm volatile("" ::: "memory");
                     }
-                    asm volatile("" ::: "memory");
                 }
-            }
 #pragma unroll
-            for (int q = q0; q < q1; ++q) sp[q].template stage<0>();
-            pins();
-            mm(2, 0);
+                for (int q = q0; q < q1; ++q) sp[q].template stage<0>();
+                pins();
+                mm(2, 0);
 #pragma unroll
-            for (int q = q0; q < q1; ++q) sp[q].template stage<1>();
-            pins();
-            mm(1, 1);
+                for (int q = q0; q < q1; ++q) sp[q].template stage<1>();
+                pins();
+                mm(1, 1);
 #pragma unroll
-            for (int q = q0; q < q1; ++q) sp[q].template stage<2>();
-            pins();
-            mm(0, 1);
+                for (int q = q0; q < q1; ++q) sp[q].template stage<2>();
+                pins();
+                mm(0, 1);
 #pragma unroll
-            for (int q = q0; q < q1; ++q) sp[q].template stage<3>();
-            pins();
-            mm(1, 0);
+                for (int q = q0; q < q1; ++q) sp[q].template stage<3>();
+                pins();
+                mm(1, 0);
 #pragma unroll
-            for (int q = q0; q < q1; ++q) {
-                sp[q].template stage<4>();
-                nxt[0][q] = sp[q].s0, nxt[1][q] = sp[q].s1, nxt[2][q] = sp[q].s2;
-            }
-            pins();
-            mm(0, 0);
-            if constexpr (g == NT - 1 && ABL < 3) cur[0] = nxt[0], cur[1] = nxt[1], cur[2] = nxt[2];
-            if constexpr (g == NT - 1 && ABL >= 3) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    cur[0][q] = cur[2][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
-            }
-        });
+                for (int q = q0; q < q1; ++q) {
+                    sp[q].template stage<4>();
+                    nxt[0][q] = sp[q].s0, nxt[1][q] = sp[q].s1, nxt[2][q] = sp[q].s2;
+                }
+                pins();
+                mm(0, 0);
+            });
+            // the last group left the next chunk's group-0 fragment in wf[NT & 1]: wait for it, hand everything over
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[NT & 1][0]), "+v"(wf[NT & 1][1]), "+v"(wf[NT & 1][2]));
+            if constexpr ((NT & 1) != 0) wf[0][0] = wf[1][0], wf[0][1] = wf[1][1], wf[0][2] = wf[1][2];
+            if constexpr (ABL < 3) cur[0] = nxt[0], cur[1] = nxt[1], cur[2] = nxt[2];
+            __builtin_amdgcn_s_setprio(0);
+        }
 #undef PAFUSE_PIN_ACC
 #undef PAFUSE_PIN_PAIR
-        __builtin_amdgcn_s_setprio(0);
+        wait_vmcnt<0>();
+    } else {
+    #pragma unroll
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nk) issue(s, s);
+
+        for (int kc = 0; kc < nk; ++kc) {
+            // chunk kc has landed once at most the NSTAGE - 2 younger chunks of this wave are still in flight
+            if (kc + NSTAGE - 2 < nk)
+                wait_vmcnt<CNT*(NSTAGE - 2)>();
+            else
+                wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();  // chunk kc visible to every wave; every wave is done reading chunk kc - 1
+            // the refill of the stage chunk kc - 1 occupied (chunk kc + NSTAGE - 1) is issued piece by piece inside the MFMA
+            // groups below: a DMA instruction costs its wave 60-180 cycles of issue, which a burst here would take from
+            // the matrix pipe of every SIMD at once (all waves leave the barrier together)
+            const bool refill = kc + NSTAGE - 1 < nk;
+            const int kn = kc + NSTAGE - 1, stn = kn % NSTAGE;
+            const uint8_t* st = lds + (kc % NSTAGE) * T::STAGE_BYTES;
+            if constexpr (ABL == 1) continue;
+            // ---- one 32-deep chunk = NG = 2 NT groups (s2, nt) of six MFMAs on one accumulator.  Hand-placed pipeline
+            // (sched_barrier fences pin the order): the W' fragments of group g + 1 are read while group g's MFMAs run; the
+            // A fragment of step s2 = 1 is split in the gaps of the s2 = 0 MFMA chains, one pair-stage per gap; only the
+            // split of step 0 (44 VALU instructions) runs with the matrix pipe idle, once per chunk.
+            constexpr int NG = NS2 * NT;
+            __builtin_amdgcn_s_setprio(1);
+            // Order pins.  hipcc moves loads and register-only instructions freely across __builtin_amdgcn_sched_barrier and
+            // waits lgkmcnt(0) where a counted wait would do, so (i) every LDS read of the loop is an asm ds_read_b128 and
+            // every wait an asm s_waitcnt that names the registers it makes valid (nothing of hipcc's own is in flight on
+            // lgkmcnt inside the loop), (ii) the order is pinned through data: an empty volatile asm that "rewrites" the
+            // accumulator sits between consecutive MFMAs of a chain, one that rewrites a SplitPair's registers between
+            // consecutive split stages.  (The accumulator pins need it in VGPRs: MINW >= 2, no AGPR allocation.)
+    #define PAFUSE_PIN_ACC(A) asm volatile("" : "+v"(A))
+    #define PAFUSE_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
+            const uint32_t sbase = lds0 + (uint32_t)((kc % NSTAGE) * T::STAGE_BYTES);
+            u32x4 wf[2][3];
+            auto load_w = [&](auto G) {  // the three slices of group G's W' fragment
+                constexpr int g = decltype(G)::value;
+                constexpr int full = (g % NT) * 32 * T::W_ROW;
+                constexpr int off = full + 32 < 65536 ? full : 0;  // ds_read immediates are 16 bits: fold the rest into the address
+                const uint32_t addr = sbase + (uint32_t)w_sub[g / NT] + (uint32_t)(full - off);
+                wf[g & 1][0] = lds_read128<off>(addr);
+                wf[g & 1][1] = lds_read128<off + 16>(addr);
+                wf[g & 1][2] = lds_read128<off + 32>(addr);
+            };
+            u32x4 a_lo = lds_read128<0>(sbase + (uint32_t)a_pos[0]);
+            u32x4 a_hi = lds_read128<0>(sbase + (uint32_t)a_pos[1]);
+            load_w(std::integral_constant<int, 0>{});
+            u32x4 b_lo, b_hi;
+            if constexpr (NS2 == 2) {
+                b_lo = lds_read128<0>(sbase + (uint32_t)a_pos[2]);
+                b_hi = lds_read128<0>(sbase + (uint32_t)a_pos[3]);
+                asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a_lo), "+v"(a_hi));  // the five younger reads stay in flight
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a_lo), "+v"(a_hi));
+            }
+            SplitPair sp[4];
+            u32x4 cur[3], nxt[3];
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sp[q].x0 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q] : a_hi[2 * q - 4]);
+                sp[q].x1 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q + 1] : a_hi[2 * q - 3]);
+                if constexpr (ABL >= 3) {
+                    cur[0][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
+                    cur[2][q] = cur[0][q];
+                    continue;
+                }
+                sp[q].template stage<0>(), sp[q].template stage<1>(), sp[q].template stage<2>(), sp[q].template stage<3>();
+                sp[q].template stage<4>();
+                cur[0][q] = sp[q].s0, cur[1][q] = sp[q].s1, cur[2][q] = sp[q].s2;
+            }
+            static_for<NG>([&](auto G) {
+                constexpr int g = decltype(G)::value;
+                constexpr int nt = g % NT;
+                // pairs of the s2 = 1 fragment split inside this group (all of them are done when group NT - 1 ends)
+                constexpr bool SPL = g < NT && ABL < 3 && NS2 == 2;
+                constexpr int q0 = SPL ? (4 * nt) / NT : 0, q1 = SPL ? (4 * (nt + 1)) / NT : 0;
+                if constexpr (g + 1 < NG) {
+                    load_w(std::integral_constant<int, g + 1>{});  // in flight during this group's MFMAs
+                    if constexpr (g == 0 && NS2 == 2) {
+                        asm volatile("s_waitcnt lgkmcnt(3)"
+                                     : "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[0][2]), "+v"(b_lo), "+v"(b_hi));
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            sp[q].x0 = __builtin_bit_cast(float, q < 2 ? b_lo[2 * q] : b_hi[2 * q - 4]);
+                            sp[q].x1 = __builtin_bit_cast(float, q < 2 ? b_lo[2 * q + 1] : b_hi[2 * q - 3]);
+                        }
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
+                    }
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
+                }
+                const u32x4(&w)[3] = wf[g & 1];
+                auto mm = [&](int wi, int ai) {
+                    PAFUSE_PIN_ACC(acc[nt]);
+                    acc[nt] = mfma_bf16_k16(__builtin_bit_cast(bf16x8, w[wi]), __builtin_bit_cast(bf16x8, cur[ai]), acc[nt]);
+                };
+                auto pins = [&]() {
+    #pragma unroll
+                    for (int q = q0; q < q1; ++q) PAFUSE_PIN_PAIR(sp[q]);
+                };
+                // small terms first, the leading product last; one split stage per gap
+                pins();
+                mm(0, 2);
+                {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
+                    constexpr int PER = (CNT + NG - 1) / NG, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
+                    if constexpr (j0 < j1 && ABL < 2) {
+                        asm volatile("" ::: "memory");
+                        if (refill) {
+    #pragma unroll
+                            for (int j = j0; j < j1; ++j) issue_piece(kn, stn, j);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+    #pragma unroll
+                for (int q = q0; q < q1; ++q) sp[q].template stage<0>();
+                pins();
+                mm(2, 0);
+    #pragma unroll
+                for (int q = q0; q < q1; ++q) sp[q].template stage<1>();
+                pins();
+                mm(1, 1);
+    #pragma unroll
+                for (int q = q0; q < q1; ++q) sp[q].template stage<2>();
+                pins();
+                mm(0, 1);
+    #pragma unroll
+                for (int q = q0; q < q1; ++q) sp[q].template stage<3>();
+                pins();
+                mm(1, 0);
+    #pragma unroll
+                for (int q = q0; q < q1; ++q) {
+                    sp[q].template stage<4>();
+                    nxt[0][q] = sp[q].s0, nxt[1][q] = sp[q].s1, nxt[2][q] = sp[q].s2;
+                }
+                pins();
+                mm(0, 0);
+                if constexpr (g == NT - 1 && ABL < 3 && NS2 == 2) cur[0] = nxt[0], cur[1] = nxt[1], cur[2] = nxt[2];
+                if constexpr (g == NT - 1 && ABL >= 3 && NS2 == 2) {
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        cur[0][q] = cur[2][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
+                }
+            });
+    #undef PAFUSE_PIN_ACC
+    #undef PAFUSE_PIN_PAIR
+            __builtin_amdgcn_s_setprio(0);
+        }
     }
     __syncthreads();  // the staging LDS becomes the epilogue's scratch
     if constexpr (ABL == 4) {

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.hpp"
@@ -76,10 +77,14 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     constexpr size_t stage_bytes = (size_t)NSTAGE * (BF16 == 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * sizeof(float);
     if (BF16 == 2 && !p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     static_assert(EPI == EPI_BIAS || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
-    constexpr size_t lds = stage_bytes;
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(stage_bytes <= 160 * 1024, "LDS budget");
+    size_t lds = stage_bytes;
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, BF16>;
-    if (lds > 64 * 1024) {
+    static const int dbg_pad = [] { const char* e = getenv("PAFUSE_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
+    if (dbg_pad && BF16 == 2 && EPI == EPI_BIAS) {  // diagnostic: keep other kernels off this workgroup's CU
+        lds = std::max(lds, (size_t)dbg_pad);
+        hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    } else if (lds > 64 * 1024) {
         static DeviceOnce once;  // the attribute is per device (one-process multi-device callers: nn.DataParallel)
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
@@ -91,14 +96,20 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 // split-precision GEMM, LDS-DMA pipelined form (one workgroup per CU, NSTAGE ring of 32-deep chunks)
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW>
+// K-chunk depth of the pre-split image of a weight (the image format is a property of the weight, fixed when it is
+// split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384 and 224
+// run on the LDS-DMA pipelined kernel with 16-deep chunks, everything else on 32-deep chunks.
+int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 224)) ? 16 : 32; }
+
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32>
 int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
-    using T = DmaTile<WM, WN, NT>;
+    using T = DmaTile<WM, WN, NT, BKC>;
     constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
     if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW>;
+    if (p.K % BKC) return fail(PAFUSE_E_SHAPE, "split GEMM: K=%d is not a multiple of %d", p.K, BKC);
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, 0, BKC>;
     if (lds > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -109,7 +120,24 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm_dma_kernel");
 }
 
-int gemm_bias(const GemmParams& p, hipStream_t s) {
+// diagnostic switch (environment PAFUSE_DEBUG_F32_MASK, read once): bit 0 = plain linear layers, bit 1 = whole-row
+// layers fall back to the fp32 matrix cores even in split-precision mode
+int debug_f32_mask() {
+    static const int mask = [] {
+        const char* e = getenv("PAFUSE_DEBUG_F32_MASK");
+        return e ? atoi(e) : 0;
+    }();
+    return mask;
+}
+
+int gemm_bias(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    if (p.bf16 == 2 && (debug_f32_mask() & 1)) p.bf16 = 0;
+    if (p.bf16 == 2 && (debug_f32_mask() & 4) && !p.act) p.bf16 = 0;   // qkv only
+    if (p.bf16 == 2 && (debug_f32_mask() & 8) && p.act) p.bf16 = 0;    // fc1 only
+    if (p.bf16 == 2 && (debug_f32_mask() & 16)) {                        // split arithmetic, small 128x64 tiles only
+        if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>(p, s);
+    }
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
@@ -135,17 +163,23 @@ int gemm_bias(const GemmParams& p, hipStream_t s) {
 }
 
 template <int EPI>
-int gemm_rowln_as(const GemmParams& p, hipStream_t s) {
+int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    if (p.bf16 == 2 && (debug_f32_mask() & 2)) p.bf16 = 0;
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
     if constexpr (EPI == EPI_ROWLN) {
         if (p.bf16 == 2) {
             switch (p.N) {
-                // taller whole-row tiles than the fp32 path: with the MFMA time cut to 3/8 the operand stream (72 KB of
-                // W' per 32-deep chunk at C = 384) is what counts, and 128 rows per workgroup read it 4x less often
-                case 384: return p.M >= 4096 ? launch_gemm<4, 4, 3, EPI, 1, 1, 1, 2>(p, s) : launch_gemm<1, 4, 3, EPI, 1, 1, 1, 2>(p, s);
+                // picked per width with tools/gemm_bench.hip (profiles/r02_gemm_bench_*.log).  Widths 384 and 224: the
+                // LDS-DMA pipelined kernel on 16-deep chunks (their W' stage, 36 / 21 KB, then fits a ring) with tall
+                // tiles - with the MFMA time cut to 3/8 the W' stream is what counts, and 128 rows per workgroup read
+                // it 4x less often than the fp32 path's 32; width 256 is fastest on the register-staged kernel.
+                case 384:
+                    return p.M >= 4096 ? launch_gemm_dma<4, 2, 6, EPI, 3, 2, 16>(p, s) : launch_gemm_dma<2, 2, 6, EPI, 3, 2, 16>(p, s);
                 case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1, 2>(p, s);
-                case 224: return p.M >= 4096 ? launch_gemm<2, 1, 7, EPI, 1, 1, 1, 2>(p, s) : launch_gemm<1, 7, 1, EPI, 1, 1, 1, 2>(p, s);
+                case 224:
+                    return p.M >= 4096 ? launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16>(p, s) : launch_gemm_dma<2, 1, 7, EPI, 2, 2, 16>(p, s);
                 case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 2>(p, s);
                 case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 2>(p, s);
                 default: break;
@@ -393,13 +427,16 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
 
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
 
-int pafuse_split_weights(const float* W, int32_t N, int32_t K, void* out, void* stream) {
+int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t whole_row, void* out, void* stream) {
     StreamDevice on_stream_device(stream);
     if (!W || !out) return fail(PAFUSE_E_ARG, "split_weights: null pointer");
     if (N <= 0 || K <= 0 || K % BK) return fail(PAFUSE_E_SHAPE, "split_weights: N=%d, K=%d (K must be a positive multiple of 32)", N, K);
     const int64_t n = (int64_t)N * (K / 8);
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W,
-                       (uint8_t*)out, N, K);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (wsplit_chunk(N, whole_row != 0) == 16)
+        hipLaunchKernelGGL(split_weights_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, W, (uint8_t*)out, N, K);
+    else
+        hipLaunchKernelGGL(split_weights_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, W, (uint8_t*)out, N, K);
     return check_launch("split_weights_kernel");
 }
 
@@ -494,7 +531,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
     if ((rc = check_launch("embed_kernel"))) return rc;
-    if ((rc = run_mixste_layers(w, pb, R, s))) return rc;
+    if ((rc = run_mixste_layers(w, pb, R, s, (debug_f32_mask() & 32) != 0))) return rc;
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((M * 3 + 255) / 256)), dim3(256), 0, s, pb.pred, out, M * 3);
     return check_launch("copy_kernel");
 }
@@ -508,6 +545,13 @@ size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config* cfg, int32_t B, int
         total += part_buffer_bytes((int64_t)nflip * B * P * w.frames * w.joints, w.channels, B);
     }
     return total;
+}
+
+// side streams only for the fp32 matrix cores (see pafuse_d3dp_sample)
+static bool lanes_allowed(const pafuse_d3dp_config* cfg) {
+    for (int i = 0; i < cfg->num_parts; ++i)
+        if (cfg->part[i].operand_bf16 != 0) return false;
+    return true;
 }
 
 static int d3dp_check(const pafuse_d3dp_config* cfg, int B, int P) {
@@ -554,6 +598,11 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     // Parts are independent inside a step, and so are hypotheses: with aux streams the work of a step is cut into
     // (part, hypothesis-group) lanes, each a chain of small launches on its own stream, so that the ramp-up and
     // tail of one lane's kernels are filled by the other lanes (groups = (n_aux + 1) / parts, at least 1).
+    // NOT in the bf16-MFMA modes (operand_bf16 != 0): kernels built on v_mfma_f32_32x32x16_bf16 return sporadically
+    // wrong tiles on MI355X when kernels of OTHER hardware queues run beside them (profiles/r02_bf16_mfma_concurrency.md:
+    // reproduced on every box, with the workgroup alone on its CU, with padded MFMAs; never with one queue, never with
+    // the fp32-input MFMAs, never with the legacy 8-deep v_mfma_f32_32x32x8_bf16_1k) - those modes run on `stream` only.
+    n_aux = lanes_allowed(cfg) ? n_aux : 0;
     const int n_lanes_max = 1 + (n_aux > 0 ? n_aux : 0);
     int groups = n_lanes_max / NP;
     if (groups < 1) groups = 1;
@@ -659,6 +708,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
 
 int pafuse_d3dp_lanes(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, int32_t n_aux) {
     if (!cfg || B <= 0 || P <= 0 || cfg->num_parts < 1) return fail(PAFUSE_E_ARG, "d3dp_lanes: bad argument");
+    if (!lanes_allowed(cfg)) return 1;
     const int64_t R = (int64_t)(cfg->flip ? 2 : 1) * B * P;
     int groups = (1 + (n_aux > 0 ? n_aux : 0)) / cfg->num_parts;
     if (groups < 1) groups = 1;

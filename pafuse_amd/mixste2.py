@@ -126,7 +126,8 @@ class MixSTE2(nn.Module):
             N, K = wt.shape
             img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=wt.device)
             with torch.cuda.device(wt.device):
-                _lib.check(lib.pafuse_split_weights(_ptr(wt.detach(), name), N, K, img.data_ptr(),
+                whole_row = int(name.endswith(("attn.proj.weight", "mlp.fc2.weight")))
+                _lib.check(lib.pafuse_split_weights(_ptr(wt.detach(), name), N, K, whole_row, img.data_ptr(),
                                                     torch.cuda.current_stream(wt.device).cuda_stream))
             images[name] = img
         self._split_cache = images          # keeps the storage alive as long as the struct that points into it

@@ -175,7 +175,7 @@ def split_weights(weight):
     N, K = weight.shape
     img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, img.data_ptr(), _stream(weight)))
+        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, 0, img.data_ptr(), _stream(weight)))
     return img
 
 

@@ -24,7 +24,7 @@ float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     if (EPI == EPI_ROWLN && !TR && (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4 > lds) lds = (size_t)(32 * (T::BN + 4) + 5 * T::BN) * 4;
     p.bf16 = MODE;
     if (MODE == 2) {
-        hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
+        hipLaunchKernelGGL(split_weights_kernel<32>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
                            (uint8_t*)p.Wsplit, p.N, p.K);
     }
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, MODE>;
@@ -63,16 +63,16 @@ float time_gemm(const char* tag, GemmParams p, int reps = 20) {
     return us;
 }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
 float time_dma(const char* tag, GemmParams p, int reps = 20) {
-    using T = DmaTile<WM, WN, NT>;
+    using T = DmaTile<WM, WN, NT, BKC>;
     if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
     if (const char* r = getenv("GB_REPS")) reps = atoi(r);
     size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
     p.bf16 = 2;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
+    hipLaunchKernelGGL(split_weights_kernel<BKC>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
                        (uint8_t*)p.Wsplit, p.N, p.K);
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, ABL>;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, ABL, BKC>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     hipEvent_t e0, e1;
@@ -126,6 +126,13 @@ int main() {
     p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body qkv  f32   <4,1,2> s1 minw5", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <4,1,4> s1 minw2", p);
+    time_dma<8, 1, 4, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <8,1,4> st3", p);
+    time_dma<4, 1, 4, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <4,1,4> st3 (2/CU)", p);
+    time_dma<4, 1, 2, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <4,1,2> st3 (3/CU)", p);
+    time_dma<8, 1, 2, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <8,1,2> st3", p);
+    time_dma<8, 1, 3, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <8,1,3> st3", p);
+    time_dma<8, 1, 4, EPI_BIAS, 3, 2, 2, 16>("body qkv  dma16p <8,1,4> st3 ABL2 compute", p);
+    time_dma<8, 1, 4, EPI_BIAS, 3, 2, 4, 16>("body qkv  dma16p <8,1,4> st3 ABL4 lds+mfma no epi", p);
     time_dma<8, 1, 4, EPI_BIAS, 2, 2>("body qkv  dma <8,1,4> st2", p);
     time_dma<8, 1, 4, EPI_BIAS, 2, 2, 1>("body qkv  dma <8,1,4> st2 ABL1 stream only", p);
     time_dma<8, 1, 4, EPI_BIAS, 2, 2, 2>("body qkv  dma <8,1,4> st2 ABL2 compute only", p);
@@ -175,26 +182,53 @@ int main() {
     q.M = 25920, q.N = 384, q.K = 768;
     time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2  rowln f32   <1,4,3>", q);
     time_gemm<4, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body fc2  rowln split <4,4,3>", q);
-    time_dma<2, 4, 3, EPI_ROWLN, 2, 2>("body fc2  rowln dma <2,4,3> st2", q);
-    time_dma<2, 2, 6, EPI_ROWLN, 2, 1>("body fc2  rowln dma <2,2,6> st2", q);
-    time_dma<2, 1, 12, EPI_ROWLN, 2, 1>("body fc2  rowln dma <2,1,12> st2", q);
+    time_dma<2, 4, 3, EPI_ROWLN, 2, 2>("body fc2  rowln dma32 <2,4,3> st2", q);
+    time_dma<4, 4, 3, EPI_ROWLN, 3, 4, 0, 16>("body fc2  rowln dma16 <4,4,3> st3", q);
+    time_dma<4, 4, 3, EPI_ROWLN, 2, 4, 0, 16>("body fc2  rowln dma16 <4,4,3> st2", q);
+    time_dma<2, 4, 3, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <2,4,3> st3", q);
+    time_dma<2, 4, 3, EPI_ROWLN, 2, 2, 0, 16>("body fc2  rowln dma16 <2,4,3> st2 (2/CU)", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <4,2,6> st3", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <2,2,6> st3", q);
+    time_dma<6, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <6,2,6> st3", q);
+    time_dma<4, 3, 4, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <4,3,4> st3", q);
+    time_dma<4, 4, 3, EPI_ROWLN, 3, 4, 1, 16>("body fc2  rowln dma16 <4,4,3> st3 ABL1 stream", q);
+    time_dma<4, 4, 3, EPI_ROWLN, 3, 4, 2, 16>("body fc2  rowln dma16 <4,4,3> st3 ABL2 compute", q);
     q.K = 384;
     time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln f32   <1,4,3>", q);
     time_gemm<4, 4, 3, EPI_ROWLN, 1, 1, 1, 2>("body proj rowln split <4,4,3>", q);
-    time_dma<2, 4, 3, EPI_ROWLN, 2, 2>("body proj rowln dma <2,4,3> st2", q);
+    time_dma<4, 4, 3, EPI_ROWLN, 3, 4, 0, 16>("body proj rowln dma16 <4,4,3> st3", q);
+    time_dma<2, 4, 3, EPI_ROWLN, 3, 2, 0, 16>("body proj rowln dma16 <2,4,3> st3", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body proj rowln dma16 <4,2,6> st3", q);
+    time_dma<4, 3, 4, EPI_ROWLN, 3, 2, 0, 16>("body proj rowln dma16 <4,3,4> st3", q);
     q.M = 45360, q.N = 256, q.K = 512;
     time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1>("hands fc2 rowln f32   <2,2,4> minw2", q);
     time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1, 2>("hands fc2 rowln split <2,2,4>", q);
-    time_dma<4, 2, 4, EPI_ROWLN, 2, 2>("hands fc2 rowln dma <4,2,4> st2", q);
-    time_dma<4, 4, 2, EPI_ROWLN, 2, 4>("hands fc2 rowln dma <4,4,2> st2", q);
-    time_dma<2, 2, 4, EPI_ROWLN, 2, 1>("hands fc2 rowln dma <2,2,4> st2", q);
-    time_dma<4, 1, 8, EPI_ROWLN, 2, 1>("hands fc2 rowln dma <4,1,8> st2", q);
-    time_dma<8, 1, 8, EPI_ROWLN, 2, 2>("hands fc2 rowln dma <8,1,8> st2", q);
+    time_dma<4, 4, 2, EPI_ROWLN, 3, 4, 0, 16>("hands fc2 rowln dma16 <4,4,2> st3", q);
+    time_dma<4, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands fc2 rowln dma16 <4,2,4> st3", q);
+    time_dma<4, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("hands fc2 rowln dma16 <4,2,4> st2", q);
+    time_dma<2, 4, 2, EPI_ROWLN, 3, 2, 0, 16>("hands fc2 rowln dma16 <2,4,2> st3", q);
+    time_dma<2, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands fc2 rowln dma16 <2,2,4> st3", q);
+    time_dma<8, 2, 4, EPI_ROWLN, 3, 4, 0, 16>("hands fc2 rowln dma16 <8,2,4> st3", q);
     q.M = 73440, q.N = 224, q.K = 448;
     time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln f32   <1,7,1>", q);
     time_gemm<2, 1, 7, EPI_ROWLN, 1, 1, 1, 2>("face fc2  rowln split <2,1,7>", q);
-    time_dma<4, 1, 7, EPI_ROWLN, 2, 1>("face fc2  rowln dma <4,1,7> st2", q);
-    time_dma<8, 1, 7, EPI_ROWLN, 2, 2>("face fc2  rowln dma <8,1,7> st2", q);
-    time_dma<2, 7, 1, EPI_ROWLN, 3, 3>("face fc2  rowln dma <2,7,1> st3", q);
+    time_dma<2, 7, 1, EPI_ROWLN, 3, 3, 0, 16>("face fc2  rowln dma16 <2,7,1> st3", q);
+    time_dma<4, 1, 7, EPI_ROWLN, 3, 2, 0, 16>("face fc2  rowln dma16 <4,1,7> st3", q);
+    time_dma<8, 1, 7, EPI_ROWLN, 3, 2, 0, 16>("face fc2  rowln dma16 <8,1,7> st3", q);
+    time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face fc2  rowln dma16 <4,1,7> st2", q);
+    time_dma<2, 1, 7, EPI_ROWLN, 3, 2, 0, 16>("face fc2  rowln dma16 <2,1,7> st3", q);
+    time_dma<2, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face fc2  rowln dma16 <2,1,7> st2", q);
+    time_dma<6, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face fc2  rowln dma16 <6,1,7> st2", q);
+    q.K = 224;
+    time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face proj rowln f32   <1,7,1>", q);
+    time_gemm<2, 1, 7, EPI_ROWLN, 1, 1, 1, 2>("face proj rowln split <2,1,7>", q);
+    time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face proj rowln dma16 <4,1,7> st2", q);
+    time_dma<4, 1, 7, EPI_ROWLN, 3, 2, 0, 16>("face proj rowln dma16 <4,1,7> st3", q);
+    q.M = 45360, q.N = 256, q.K = 256;
+    time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1>("hands proj rowln f32   <2,2,4> minw2", q);
+    time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1, 2>("hands proj rowln split <2,2,4>", q);
+    time_dma<2, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <2,2,4> st3", q);
+    time_dma<4, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <4,2,4> st3", q);
+    time_dma<2, 4, 2, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <2,4,2> st3", q);
     return 0;
 }
