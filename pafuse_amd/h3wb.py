@@ -217,10 +217,13 @@ def iter_sequences(cams, poses_3d, poses_2d):
                np.expand_dims(p2, 0))
 
 
-def evaluate(model, dataset, cams, poses_3d, poses_2d, kps_left, kps_right, batch_size=1024, group=None, log=print):
+def evaluate(model, dataset, cams, poses_3d, poses_2d, kps_left, kps_right, batch_size=1024, group=None, log=print,
+             action=None, log_dir=None):
     """evaluate() of main_h3wb.py:194-531 for an already loaded eval model: every video through
     harness.evaluate_sequence (flip-TTA, 27-frame clips, sharded sampling, device-side aggregation), frame-weighted
-    means in millimetres per protocol and sampling step."""
+    means in millimetres per protocol and sampling step, printed in the reference's log format (:406-509) and, with
+    `log_dir`, appended to ``h36m_test_log_H<P>_K<T>.txt`` there exactly as the reference writes it.  `action` is
+    the per-action header of the reference's run_evaluation loop (:1117-1362): call once per action's sequences."""
     from . import harness
     total, n = None, 0
     for cam, seq_3d, seq_2d in iter_sequences(cams, poses_3d, poses_2d):
@@ -229,8 +232,14 @@ def evaluate(model, dataset, cams, poses_3d, poses_2d, kps_left, kps_right, batc
         total = sums if total is None else {k: total[k] + sums[k] for k in sums}
         n += cnt
     rep = harness.report(total, n)
-    for k in harness.ACCUMULATORS:
-        log(f"{k:>22s}: " + " ".join(f"{v:8.3f}" for v in rep[k]) + " mm")
+    printed, written = harness.format_report(rep, bool(model.flip), action)
+    for line in printed:
+        log(line)
+    if log_dir is not None:
+        import os
+        path = os.path.join(log_dir, "h36m_test_log_H%d_K%d.txt" % (model.num_proposals, model.sampling_timesteps))
+        with open(path, mode="a") as f:
+            f.write("".join(line + "\n" for line in written))
     return rep
 
 

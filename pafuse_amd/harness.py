@@ -173,3 +173,38 @@ def evaluate_sequence(model, dataset, seq_2d, seq_3d, cam, kps_left, kps_right, 
 def report(sums, n):
     """mm per protocol and step, as evaluate() prints them (main_h3wb.py:415-509)."""
     return {k: (v / n * 1000.0).tolist() for k, v in sums.items()}
+
+
+def format_report(rep, test_time_augmentation=True, action=None):
+    """The reference's evaluation log, line for line (main_h3wb.py:406-509): returns ``(printed, written)`` - the lines
+    evaluate() prints and the lines it appends to ``h36m_test_log_H<P>_K<T>.txt`` (the reference prints P_Best but
+    does not write it, and writes each part-based header twice; both quirks are kept so files diff clean)."""
+    printed, written = [], []
+
+    def both(line):
+        printed.append(line), written.append(line)
+
+    if action is None:
+        printed.append("----------")
+    else:
+        both("----" + action + "----")
+    printed.append(f"Test time augmentation: {test_time_augmentation}")
+    for ii in range(len(rep["j_best"])):
+        hands = lambda key: (rep[key + "_right_hand"][ii] + rep[key + "_left_hand"][ii]) / 2.
+        both("step %d : Protocol #1 Error (MPJPE) J_Best: %f mm" % (ii, rep["j_best"][ii]))
+        printed.append("step %d : Protocol #1 Error (MPJPE) P_Best: %f mm" % (ii, rep["p_best"][ii]))
+        both("step %d : Protocol #1 Error (MPJPE) P_Agg: %f mm" % (ii, rep["p_agg"][ii]))
+        both("step %d : Protocol #1 Error (MPJPE) J_Agg: %f mm" % (ii, rep["j_agg"][ii]))
+        for header, key, name in (("-----------------> Part-Based Evaluation <-----------------", "p_best_pb", "P_Best"),
+                                  ("-----------------> Part-Based Evaluation Aggregation <-----------------", "p_agg_pb",
+                                   "P_Agg")):
+            both(header)
+            written.append(header)
+            both("step %d : Protocol #1 Error (MPJPE) %s Part-Based: %f mm" % (ii, name, rep[key][ii]))
+            both("step %d : Protocol #1 Error (MPJPE) %s Part-Based BODY: %f mm" % (ii, name, rep[key + "_body"][ii]))
+            both("step %d : Protocol #1 Error (MPJPE) %s Part-Based FACE: %f mm" % (ii, name, rep[key + "_face"][ii]))
+            both("step %d : Protocol #1 Error (MPJPE) %s Part-Based HANDS: %f mm" % (ii, name, hands(key)))
+            both("step %d : Protocol #1 Error (MPJPE) %s Part-Based LEFT HAND: %f mm" % (ii, name, rep[key + "_left_hand"][ii]))
+            both("step %d : Protocol #1 Error (MPJPE) %s Part-Based RIGHT HAND: %f mm" % (ii, name, rep[key + "_right_hand"][ii]))
+    both("----------")
+    return printed, written

@@ -297,3 +297,22 @@ def test_training_loss_variants_match_the_reference_formulas():
     assert torch.allclose(h3wb.mpjpe_loss(p, t, mse_loss=True), d.pow(2).mean())
     assert torch.allclose(h3wb.mpjpe_loss(p, t, w), (w * d).mean())
     assert torch.allclose(h3wb.mpjpe_loss(p, t, w, True), (w * d).pow(2).mean())
+
+
+def test_evaluation_log_lines_are_the_reference_s():
+    """harness.format_report against lines produced by the reference's own print / write statements
+    (main_h3wb.py:406-509, restated here as data: the format strings and their order are the contract)."""
+    from pafuse_amd import harness
+    rep = {k: [float(i + 1) + 0.125 * j for j in range(2)] for i, k in enumerate(harness.ACCUMULATORS)}
+    printed, written = harness.format_report(rep, True, action="Walking")
+    assert printed[0] == written[0] == "----Walking----" and printed[1] == "Test time augmentation: True"
+    assert printed[2] == "step 0 : Protocol #1 Error (MPJPE) J_Best: 1.000000 mm"
+    assert printed[3] == "step 0 : Protocol #1 Error (MPJPE) P_Best: 2.000000 mm" and printed[3] not in written
+    assert printed[4] == "step 0 : Protocol #1 Error (MPJPE) P_Agg: 3.000000 mm"
+    assert printed[5] == "step 0 : Protocol #1 Error (MPJPE) J_Agg: 4.000000 mm"
+    assert printed[6] == "-----------------> Part-Based Evaluation <-----------------" and written.count(printed[6]) == 4
+    assert "step 0 : Protocol #1 Error (MPJPE) P_Best Part-Based HANDS: 8.500000 mm" in written      # (9 + 8) / 2
+    assert "step 1 : Protocol #1 Error (MPJPE) P_Agg Part-Based RIGHT HAND: 14.125000 mm" in written
+    assert printed[-1] == written[-1] == "----------" and len(printed) == 2 + 2 * 18 + 1
+    p2, w2 = harness.format_report(rep, False)
+    assert p2[0] == "----------" and w2[0].startswith("step 0") and p2[1] == "Test time augmentation: False"
