@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence behind profiles/rNN_* on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh            -> gpurun_out/prof/*
+# One pass per counter group (FETCH_SIZE and WRITE_SIZE cannot share a pass; counters never together with --stats),
+# program directly after `--`, from /tmp with TMPDIR=/tmp as the pool requires.  Summaries are made afterwards in the
+# build container with tools/pmc_traffic.py, tools/pmc_mfma_util.py, tools/trace_by_grid.py.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+run() { echo "== $*" >&2; "$@"; }
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$O/stats_bench_line.json" 2> "$O/stats.err" || exit 1
+run rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/fetch_bench_line.json" 2> "$O/fetch.err" || exit 1
+run rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O" -o write -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/write_bench_line.json" 2> "$O/write.err" || exit 1
+run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O" -o mfma -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/mfma_bench_line.json" 2> "$O/mfma.err" || exit 1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o train -- python3 "$R/bench.py" --train --steps 3 --warmup 1 --no-cpu-baseline > "$O/train_bench_line.json" 2> "$O/train.err" || exit 1
+run python3 "$R/bench.py" > "$O/bench_line.json" 2> "$O/bench.err" || exit 1
+run python3 "$R/bench.py" --dtype f32 --no-cpu-baseline > "$O/bench_line_f32.json" 2>> "$O/bench.err" || exit 1
+run python3 "$R/bench.py" --train --no-cpu-baseline > "$O/train_bench_line_unprofiled.json" 2>> "$O/bench.err" || exit 1
+ls -la "$O" | head -40
