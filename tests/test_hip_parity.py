@@ -672,9 +672,8 @@ def test_linear_bf16_operands(M, N, K):
 
 
 # |MPJPE_bf16 - MPJPE_f32| bound (mm) for the opt-in bf16-operand mode at BASELINE configs[1] (P=5, T=5).  Measured on
-# MI355X (profiles/r02_parity_report.json, case "5,5,1,bf16", against the oracle): J-Best 3.9, P-Best 3.3, P-Agg 3.4,
-# J-Agg 3.5 mm (max over the five steps); pointwise mean 2.0e-3 m, max 0.11 m (single joints of single hypotheses at the
-# noisiest step).  Rounding every matrix operand to 8 significant bits costs that much on random weights - bf16 autocast
+# MI355X (profiles/r02_parity_report.json, case "5,5,1,bf16", against the oracle): J-Best 3.7, P-Best 3.2, P-Agg 3.3,
+# J-Agg 3.1 mm (max over the five steps); pointwise mean 1.9e-3 m, max 1.2e-2 m.  Rounding every matrix operand to 8 significant bits costs that much on random weights - bf16 autocast
 # of the reference itself sits at the same distance (hard part 1).
 BF16_MPJPE_TOL_MM = 6.0
 
@@ -696,7 +695,7 @@ def test_bf16_precision_mode_end_to_end():
     again = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
     assert torch.equal(f32, again)
     err = (low - f32).abs()
-    assert bool(torch.isfinite(low).all()) and 0 < float(err.mean()) < 4e-3 and float(err.max()) < 0.25, (err.max(), err.mean())
+    assert bool(torch.isfinite(low).all()) and 0 < float(err.mean()) < 4e-3 and float(err.max()) < 0.05, (err.max(), err.mean())
     target = orc.center_pose_parts(gu.synthetic_target_3d(1))
     got, want = _mpjpe_report(low.cpu(), target, x2d), _mpjpe_report(f32.cpu(), target, x2d)
     for k in want:
