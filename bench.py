@@ -12,9 +12,11 @@ sharded (weak scaling: P = 20*N, 20 per rank) and every step ends with the singl
 per-rank predictions.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel (f32-MFMA linear-layer GEMM, `gemm_kernel`): algorithmic FLOPs of the 192 GEMM
-                launches of one flip-TTA denoiser pass divided by their HIP-event time (launched back to back on
-                the stream torch uses), against the 157.3 TFLOP/s dense f32 matrix peak.
+  roofline      the dominant kernel family (the linear-layer GEMMs: `gemm_kernel`, and in the default split-precision
+                mode the grids that hold the same layer of all three parts, `grouped_bias_kernel` / `grouped_rowln_kernel`):
+                algorithmic FLOPs of the GEMM launches of one flip-TTA denoiser pass (192 part by part; 128 when proj,
+                fc1 and fc2 are grouped) divided by their HIP-event time (launched back to back on the stream torch
+                uses), against 416.7 TFLOP/s (bf16 matrix peak / 6 products) or the 157.3 TFLOP/s f32 matrix peak.
   roofline_loop the same fraction for the whole timed loop (2*T*69.38 GFLOP per hypothesis, everything included).
   cpu_baseline  the CPU oracle (a port of the reference's ATen path, oracle/) timed on the host cores of this box
                 on a bounded sample of the same workload.
@@ -176,7 +178,7 @@ def main():
                           "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"},
     }
 
-    # ---- dominant kernel: the 192 linear-layer GEMM launches of one flip-TTA denoiser pass, HIP-event timed ----
+    # ---- dominant kernel family: the linear-layer GEMM launches of one flip-TTA denoiser pass, HIP-event timed ----
     if not args.no_roofline and rank == 0:
         lib = _lib.load()
         cfg = model.config_struct(True)
@@ -203,9 +205,11 @@ def main():
         # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
         traffic, traffic_info = None, {"traffic_source": None}
         tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10) and args.dtype == "f32":
+        if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10):
             tj = json.load(open(tpath))
-            if tj.get("kernel_source_sha256") == _lib.kernel_source_digest():
+            if tj.get("dtype", "bf16x3") != args.dtype:
+                traffic_info = {"traffic_source": f"profiles/r02_pmc_traffic.json was collected in {tj.get('dtype', 'bf16x3')} mode: not quoted"}
+            elif tj.get("kernel_source_sha256") == _lib.kernel_source_digest():
                 traffic = round(tj["traffic_bytes_per_launch"])
                 traffic_info = {"traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                                   "FETCH doubled per the gfx950 correction)",
@@ -229,7 +233,7 @@ def main():
                      "bf16x3": "dense bf16 matrix peak 2500 / 6 products; the same FLOPs against the f32-input matrix "
                                f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
-        line["roofline"] = {"bound": "mfma", "kernel": f"pafuse::gemm_kernel ({mfma})",
+        line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: gemm_kernel, grouped_bias_kernel, grouped_rowln_kernel ({mfma})",
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(achieved / peak, 4), "peak_note": peak_note,
                             "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,

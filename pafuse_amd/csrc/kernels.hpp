@@ -392,14 +392,15 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
 // in LDS and is split into three bf16 slices in registers when a fragment is read (each wave owns its rows, so every A
 // element is split once per workgroup); W comes pre-split (p.Wsplit, the W' image above) and is staged as it lies.  Per
 // 16-deep step lane (r, h) multiplies k = 16*s2 + 8*h + 0..7 - six MFMAs per (A, W) fragment pair.
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
-__global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
+// (the body is a device function: gemm_kernel runs it for workgroup blockIdx.x of gridDim.x, grouped_bias_kernel for
+// workgroup b of the nb of one slot of a grouped launch; nb may exceed the tile count, surplus workgroups return)
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int TR = 0, int BF16 = 0>
+__device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, const int nb, float* smem) {
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
     constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;  // float4 per thread per chunk
     constexpr bool SPLIT = BF16 == 2;
     constexpr int W_ROW = SPLIT ? T::W_ROW_SPLIT : LDK;  // floats per W row of a stage
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Ws = smem + NSTAGE * BM * LDK;
 
@@ -412,11 +413,12 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     // contiguous run of tiles - the N-tiles of one M-tile then hit the same L2 for their A rows (speed only).
     int tile;
     {
-        const int nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, rem = nb & 7;
+        const int xcd = b & 7, q = nb >> 3, rem = nb & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
     }
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
+    if (m0 >= p.M) return;  // padded slot of a grouped launch (workgroup-uniform)
     const int n0 = tile_n * BN;
     const int K = p.K;
 
@@ -622,6 +624,12 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     }
 }
 
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
+__global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_tile<WM, WN, NT, EPI, NSTAGE, TR, BF16>(p, blockIdx.x, gridDim.x, smem);
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // Split-precision linear layer, LDS-DMA pipelined form:  out = epilogue(A[M,K] @ W[N,K]^T + bias)  with bf16x3 products.
 //
@@ -678,8 +686,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ABL (diagnostic builds of tools/gemm_bench.hip only; results wrong by design): 1 = no fragment reads / split / MFMAs
 // (the operand stream alone), 2 = no DMA (the compute side alone, on whatever the LDS holds), 3 = 2 without the split
 // arithmetic (raw fragment bits as slices: LDS reads + MFMAs only), 4 = 3 without the epilogue.
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
-__global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
+// One tile of the kernel as a device function: `b` of `nb` is the workgroup's index in its launch (or in its slot of a
+// grouped launch, see grouped_rowln_kernel); nb may exceed the tile count (slots are padded to multiples of 8 so that
+// b & 7 stays the XCD of the workgroup): surplus workgroups return at once.
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int ABL = 0, int BKC = 32>
+__device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, const int nb, float* smem) {
     using T = DmaTile<WM, WN, NT, BKC>;
     constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW;
     constexpr int NS2 = BKC / 16;                 // 16-deep MFMA steps per chunk
@@ -687,7 +698,6 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
     constexpr int CPR = T::A_ROW / 16;            // 16-byte chunks per A row
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
     static_assert(CNT * (NSTAGE - 1) < 64, "vmcnt range");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;  // LDS byte address of the ring
 
@@ -698,11 +708,12 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
     const int tiles_n = p.N / BN;
     int tile;
     {
-        const int nb = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nb >> 3, rem = nb & 7;
+        const int xcd = b & 7, q = nb >> 3, rem = nb & 7;
         tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
     }
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
+    if (m0 >= p.M) return;  // padded slot of a grouped launch (workgroup-uniform)
     const int n0 = tile_n * BN;
     const int K = p.K, nk = K / BKC;
 
@@ -1043,6 +1054,69 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
         return;
     }
     epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem);
+}
+
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
+__global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_dma_tile<WM, WN, NT, EPI, NSTAGE, ABL, BKC>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Grouped whole-row launch: the same layer (proj, or fc2) of up to GROUP_MAX independent body-part denoisers in ONE
+// grid.  Alone, each part's launch fills the 256 CUs badly - a part's 405 / 574 / 709 tiles on 512 workgroup slots run as
+// 0.79 / 1.12 / 1.38 rounds - and the bf16-MFMA kernels may not overlap on several queues
+// (profiles/r02_bf16_mfma_concurrency.md); inside one grid the hardware dispatcher hands the next tile of whichever part
+// to each CU as it frees.  Slot s owns workgroups first[s] .. first[s+1]-1 (multiples of 8, so b & 7 is still the XCD
+// and each slot keeps its XCD-contiguous tile order; surplus workgroups return at once), most expensive tiles first.
+// Every variant is a 4-wave LDS-DMA tile on the 16-deep image with a two-stage ring, two workgroups per CU (the LN
+// epilogue of one overlaps the K loop of the other): 384 -> 64 x 384, 256 -> 64 x 256, 224 -> 128 x 224 (7 column blocks
+// do not split over two waves).  A tile's arithmetic does not depend on the grid it runs in: results are bit-identical
+// to the per-part launches of the same variants.
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int GROUP_MAX = 4;
+struct GroupedGemmParams {
+    GemmParams p[GROUP_MAX];
+    int first[GROUP_MAX + 1];
+    int n;
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemmParams g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < g.n && b >= g.first[i]) s = i;
+    const GemmParams& p = g.p[s];
+    const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
+    switch (p.N) {  // workgroup-uniform
+        case 384: gemm_dma_tile<2, 2, 6, EPI, 2, 0, 16>(p, lb, nb, smem); break;
+        case 256: gemm_dma_tile<2, 2, 4, EPI, 2, 0, 16>(p, lb, nb, smem); break;
+        case 224: gemm_dma_tile<4, 1, 7, EPI, 2, 0, 16>(p, lb, nb, smem); break;
+        default: break;
+    }
+}
+
+// The plain layers (qkv, fc1 + GELU) of the parts in one grid, same slot scheme: split-precision register-staged tiles,
+// 128 x 128 where N allows, else 128 x 64, else 128 x 96 (row-per-lane epilogue); three workgroups per CU.
+template <int EPI>
+__global__ void __launch_bounds__(256, 3) grouped_bias_kernel(const GroupedGemmParams g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < g.n && b >= g.first[i]) s = i;
+    const GemmParams& p = g.p[s];
+    const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
+    if (p.N % 128 == 0)  // (the order of the per-part dispatch, gemm_bias in pafuse_hip.hip)
+        gemm_tile<4, 1, 4, EPI, 1, 0, 2>(p, lb, nb, smem);
+    else if (p.N % 64 == 0)
+        gemm_tile<4, 1, 2, EPI, 1, 0, 2>(p, lb, nb, smem);
+    else
+        gemm_tile<4, 1, 3, EPI, 1, 1, 2>(p, lb, nb, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

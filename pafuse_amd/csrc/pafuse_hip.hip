@@ -97,9 +97,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 
 // split-precision GEMM, LDS-DMA pipelined form (one workgroup per CU, NSTAGE ring of 32-deep chunks)
 // K-chunk depth of the pre-split image of a weight (the image format is a property of the weight, fixed when it is
-// split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384 and 224
-// run on the LDS-DMA pipelined kernel with 16-deep chunks, everything else on 32-deep chunks.
-int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 224)) ? 16 : 32; }
+// split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384, 256 and
+// 224 run on the LDS-DMA kernel with 16-deep chunks, everything else on 32-deep chunks.
+int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 256 || N == 224)) ? 16 : 32; }
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32>
 int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
@@ -171,13 +171,12 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
     if constexpr (EPI == EPI_ROWLN) {
         if (p.bf16 == 2) {
             switch (p.N) {
-                // picked per width with tools/gemm_bench.hip (profiles/r02_gemm_bench_*.log).  Widths 384 and 224: the
-                // LDS-DMA pipelined kernel on 16-deep chunks (their W' stage, 36 / 21 KB, then fits a ring) with tall
-                // tiles - with the MFMA time cut to 3/8 the W' stream is what counts, and 128 rows per workgroup read
-                // it 4x less often than the fp32 path's 32; width 256 is fastest on the register-staged kernel.
-                case 384:
-                    return p.M >= 4096 ? launch_gemm_dma<4, 2, 6, EPI, 3, 2, 16>(p, s) : launch_gemm_dma<2, 2, 6, EPI, 3, 2, 16>(p, s);
-                case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1, 2>(p, s);
+                // picked per width with tools/gemm_bench.hip (profiles/r02_gemm_bench_*.log): the LDS-DMA kernel on 16-deep
+                // chunks, four waves, a two-stage ring and TWO workgroups per CU - the LayerNorm epilogue of one tile
+                // (a third of a tile's time when nothing overlaps it) runs under the K loop of the other.  The same
+                // variants serve the grouped launches below, so both routes give bit-identical rows.
+                case 384: return launch_gemm_dma<2, 2, 6, EPI, 2, 2, 16>(p, s);
+                case 256: return launch_gemm_dma<2, 2, 4, EPI, 2, 2, 16>(p, s);
                 case 224:
                     return p.M >= 4096 ? launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16>(p, s) : launch_gemm_dma<2, 1, 7, EPI, 2, 2, 16>(p, s);
                 case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 2>(p, s);
@@ -210,6 +209,75 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
 int gemm_rowln(const GemmParams& p, hipStream_t s) { return gemm_rowln_as<EPI_ROWLN>(p, s); }
 // training forward: the same kernels with the DropPath row factor and the pre-norm sum as an extra output
 int gemm_rowln_train(const GemmParams& p, hipStream_t s) { return gemm_rowln_as<EPI_ROWLN_TRAIN>(p, s); }
+
+// ---- grouped launches: the same layer of several independent parts in one grid (kernels.hpp, grouped_*_kernel).
+// Only the split-precision mode has them (the fp32 mode overlaps parts on streams instead); anything a grouped kernel
+// has no variant for goes part by part through the dispatch above - same tiles, same arithmetic, same results.
+bool group_ok_rowln(const GemmParams& p) {
+    return p.bf16 == 2 && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 && p.K > 0 &&
+           !(debug_f32_mask() & 2);
+}
+bool group_ok_bias(const GemmParams& p) {
+    return p.bf16 == 2 && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 && !(debug_f32_mask() & 29);
+}
+bool grouping_enabled() {
+    static const bool on = [] { const char* e = getenv("PAFUSE_NO_GROUPED"); return !(e && atoi(e)); }();
+    return on;
+}
+
+template <bool ROWLN>
+int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
+    bool ok = grouping_enabled() && n >= 2 && n <= GROUP_MAX;
+    for (int i = 0; i < n && ok; ++i) ok = ps[i].M > 0 && (ROWLN ? group_ok_rowln(ps[i]) : group_ok_bias(ps[i]));
+    if (!ok) {
+        for (int i = 0; i < n; ++i) {
+            const int rc = ROWLN ? gemm_rowln(ps[i], s) : gemm_bias(ps[i], s);
+            if (rc) return rc;
+        }
+        return PAFUSE_OK;
+    }
+    // most expensive tiles first (the tail of the grid is then made of the cheapest ones)
+    int order[GROUP_MAX];
+    double cost[GROUP_MAX];
+    int64_t tiles[GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        const GemmParams& p = ps[i];
+        int bm, bn;
+        if (ROWLN) bm = p.N == 224 ? 128 : 64, bn = p.N;
+        else bm = 128, bn = p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 96);
+        tiles[i] = (p.M + bm - 1) / bm * (p.N / bn);
+        cost[i] = (double)bm * bn * p.K;
+        order[i] = i;
+    }
+    std::sort(order, order + n, [&](int a, int b) { return cost[a] > cost[b]; });
+    static const bool dbg_asc = [] { const char* e = getenv("PAFUSE_DEBUG_GROUP_ASC"); return e && atoi(e); }();
+    if (dbg_asc && !ROWLN) std::reverse(order, order + n);  // experiment: fc1 writes the part fc2 reads first last
+    GroupedGemmParams g{};
+    g.n = n;
+    int64_t first = 0;
+    for (int k = 0; k < n; ++k) {
+        g.p[k] = ps[order[k]];
+        g.first[k] = (int)first;
+        first += (tiles[order[k]] + 7) / 8 * 8;
+        if (first > 0x7fffffff) return fail(PAFUSE_E_ARG, "grouped gemm grid out of range");
+    }
+    g.first[n] = (int)first;
+    for (int k = n + 1; k <= GROUP_MAX; ++k) g.first[k] = (int)first;
+    if (ROWLN) {
+        constexpr size_t lds = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES;  // the widest variant's ring
+        static_assert(lds >= 2 * DmaTile<2, 2, 4, 16>::STAGE_BYTES && lds >= 2 * DmaTile<4, 1, 7, 16>::STAGE_BYTES && lds <= 80 * 1024, "LDS");
+        auto k = grouped_rowln_kernel<EPI_ROWLN>;
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)first), dim3(256), lds, s, g);
+        return check_launch("grouped_rowln_kernel");
+    } else {
+        constexpr size_t lds = GemmTile<4, 1, 4>::STAGE_FLOATS_SPLIT * sizeof(float);
+        static_assert(lds <= 64 * 1024, "LDS");
+        hipLaunchKernelGGL(grouped_bias_kernel<EPI_BIAS>, dim3((unsigned)first), dim3(256), lds, s, g);
+        return check_launch("grouped_bias_kernel");
+    }
+}
 
 bool width_supported(int C) { return C == 384 || C == 256 || C == 224 || C == 128 || C == 64; }
 
@@ -311,83 +379,144 @@ struct BlockTail {
     float* out_head;
 };
 
+// the five launches of one transformer block, as parameter blocks (run part by part, or grouped across parts)
+struct BlockLaunch {
+    GemmParams qkv, proj, fc1, fc2;
+    AttnParams attn;
+};
+
+BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
+                       int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
+                       int bf16) {
+    BlockLaunch b{};
+    // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
+    GemmParams& g = b.qkv;
+    g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
+    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws;
+    AttnParams& a = b.attn;
+    a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
+    a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
+    a.scale = 1.0f / sqrtf((float)(C / heads));  // head_dim ** -0.5                    mixste.py:52
+    // x = x + o Wproj^T + b ; xn = LN2(x)                                               mixste.py:80,114-115
+    GemmParams& pj = b.proj;
+    pj.A = pb.o, pj.W = bw.proj_w, pj.bias = bw.proj_b, pj.M = M, pj.N = C, pj.K = C;
+    pj.resid = pb.x, pj.out_x = pb.x, pj.out_n = pb.xn;
+    pj.next_w = bw.norm2_w, pj.next_b = bw.norm2_b, pj.next_eps = 1e-6f;
+    pj.bf16 = bf16, pj.Wsplit = (const uint8_t*)bw.proj_ws;
+    // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
+    GemmParams& f1 = b.fc1;
+    f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = 2 * C, f1.K = C, f1.act = 1;
+    f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
+    // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
+    GemmParams& f2 = b.fc2;
+    f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = 2 * C;
+    f2.resid = pb.x, f2.out_x = tail.out_head ? nullptr : pb.x, f2.out_n = tail.out_head ? nullptr : pb.xn;
+    f2.post_w = tail.post_w, f2.post_b = tail.post_b, f2.post_eps = tail.post_eps;
+    f2.pos = tail.pos, f2.posJ = tail.posJ, f2.posF = tail.posF;
+    f2.next_w = tail.next_w, f2.next_b = tail.next_b, f2.next_eps = tail.next_eps;
+    f2.head_w = tail.head_w, f2.head_b = tail.head_b, f2.out_head = tail.out_head;
+    if (!tail.next_w) f2.out_n = nullptr;
+    f2.bf16 = bf16, f2.Wsplit = (const uint8_t*)bw.fc2_ws;
+    return b;
+}
+
+// one block of n independent parts: the same layer of every part in one grid where the grouped kernels apply
+// (n == 1: the plain per-part launches)
+int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = false, double* flops = nullptr,
+               int* launches = nullptr) {
+    int rc;
+    GemmParams g[GROUP_MAX];
+    auto count = [&](int layers) {
+        if (!flops) return;
+        for (int i = 0; i < n; ++i) *flops += 2.0 * g[i].M * g[i].N * g[i].K;
+        *launches += layers;
+    };
+    const bool grouped = grouping_enabled() && n >= 2;
+    auto layer = [&](GemmParams BlockLaunch::*which, bool rowln) -> int {
+        bool all = grouped;
+        for (int i = 0; i < n; ++i) {
+            g[i] = bl[i].*which;
+            all = all && g[i].M > 0 && (rowln ? group_ok_rowln(g[i]) : group_ok_bias(g[i]));
+        }
+        const int r = rowln ? gemm_group<true>(g, n, s) : gemm_group<false>(g, n, s);
+        count(all ? 1 : n);
+        return r;
+    };
+    // qkv -> attention stays part by part: a part's qkv rows (119 - 197 MB at P = 20) are read back by its attention
+    // while they are still in the 256 MB Infinity Cache; written for all parts first (455 MB) they are not, and the six
+    // attention launches of a block pair get 21 us slower, more than the shared qkv grid saves (9 us; rocprofv3, r02)
+    for (int i = 0; i < n; ++i) {
+        g[i] = bl[i].qkv;
+        if ((rc = gemm_bias(g[i], s))) return rc;
+        if (!gemms_only && (rc = attention(bl[i].attn, s))) return rc;
+    }
+    count(n);
+    if ((rc = layer(&BlockLaunch::proj, true))) return rc;
+    if ((rc = layer(&BlockLaunch::fc1, false))) return rc;
+    return layer(&BlockLaunch::fc2, true);
+}
+
 int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
               int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
               hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr, int bf16 = 0) {
+    const BlockLaunch b = make_block(bw, pb, M, C, heads, nseq, L, group, group_stride, seq_stride, tok_stride, tail, bf16);
+    return run_blocks(&b, 1, s, gemms_only, flops, launches);
+}
+
+// the 2*depth blocks + head of n independent MixSTE2 denoisers of equal depth on rows already embedded in pb[i].x /
+// pb[i].xn; results in pb[i].pred [M_i,3].  Block k of every part is issued together (run_blocks).
+int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffers* pbs, const int64_t* Rs, int n,
+                        hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
+    if (n < 1 || n > GROUP_MAX) return fail(PAFUSE_E_ARG, "run_mixste_layers_n: %d parts", n);
+    for (int i = 1; i < n; ++i)
+        if (ws[i]->depth != ws[0]->depth) return fail(PAFUSE_E_ARG, "run_mixste_layers_n: parts of unequal depth");
     int rc;
-    GemmParams g{};
-    // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
-    g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
-    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws;
-    if ((rc = gemm_bias(g, s))) return rc;
-    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
-    if (!gemms_only) {
-        AttnParams a{};
-        a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
-        a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
-        a.scale = 1.0f / sqrtf((float)(C / heads));  // head_dim ** -0.5                    mixste.py:52
-        if ((rc = attention(a, s))) return rc;
+    BlockLaunch bl[GROUP_MAX];
+    for (int i = 0; i < ws[0]->depth; ++i) {
+        for (int k = 0; k < n; ++k) {
+            const pafuse_mixste2_weights* w = ws[k];
+            const int F = w->frames, J = w->joints, C = w->channels;
+            BlockTail t{};
+            // spatial block i: sequences = the J joints of one (r, f); then Spatial_norm; TTE block 0 first adds the
+            // temporal position embedding; the next LayerNorm is norm1 of temporal block i.
+            t.post_w = w->snorm_w, t.post_b = w->snorm_b, t.post_eps = 1e-6f;
+            if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
+            t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
+            bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16);
+        }
+        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches))) return rc;
+        for (int k = 0; k < n; ++k) {
+            const pafuse_mixste2_weights* w = ws[k];
+            const int F = w->frames, J = w->joints, C = w->channels;
+            // temporal block i: sequences = the F frames of one (r, j); then Temporal_norm; next is norm1 of spatial
+            // block i+1, or the head (LayerNorm eps 1e-5 + Linear(C,3)) after the last block.
+            BlockTail t{};
+            t.post_w = w->tnorm_w, t.post_b = w->tnorm_b, t.post_eps = 1e-6f;
+            if (i + 1 < w->depth) {
+                t.next_w = w->ste[i + 1].norm1_w, t.next_b = w->ste[i + 1].norm1_b, t.next_eps = 1e-6f;
+            } else {
+                t.next_w = w->hnorm_w, t.next_b = w->hnorm_b, t.next_eps = 1e-5f;
+                t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pbs[k].pred;
+            }
+            bl[k] = make_block(w->tte[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * J, F, J, (int64_t)F * J, 1, J, t,
+                               w->operand_bf16);
+        }
+        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches))) return rc;
     }
-    // x = x + o Wproj^T + b ; xn = LN2(x)                                               mixste.py:80,114-115
-    g = GemmParams{};
-    g.A = pb.o, g.W = bw.proj_w, g.bias = bw.proj_b, g.M = M, g.N = C, g.K = C;
-    g.resid = pb.x, g.out_x = pb.x, g.out_n = pb.xn;
-    g.next_w = bw.norm2_w, g.next_b = bw.norm2_b, g.next_eps = 1e-6f;
-    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.proj_ws;
-    if ((rc = gemm_rowln(g, s))) return rc;
-    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
-    // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
-    g = GemmParams{};
-    g.A = pb.xn, g.W = bw.fc1_w, g.bias = bw.fc1_b, g.out = pb.wide, g.M = M, g.N = 2 * C, g.K = C, g.act = 1;
-    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.fc1_ws;
-    if ((rc = gemm_bias(g, s))) return rc;
-    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
-    // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
-    g = GemmParams{};
-    g.A = pb.wide, g.W = bw.fc2_w, g.bias = bw.fc2_b, g.M = M, g.N = C, g.K = 2 * C;
-    g.resid = pb.x, g.out_x = tail.out_head ? nullptr : pb.x, g.out_n = tail.out_head ? nullptr : pb.xn;
-    g.post_w = tail.post_w, g.post_b = tail.post_b, g.post_eps = tail.post_eps;
-    g.pos = tail.pos, g.posJ = tail.posJ, g.posF = tail.posF;
-    g.next_w = tail.next_w, g.next_b = tail.next_b, g.next_eps = tail.next_eps;
-    g.head_w = tail.head_w, g.head_b = tail.head_b, g.out_head = tail.out_head;
-    if (!tail.next_w) g.out_n = nullptr;
-    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.fc2_ws;
-    if ((rc = gemm_rowln(g, s))) return rc;
-    if (flops) *flops += 2.0 * M * g.N * g.K, ++*launches;
     return PAFUSE_OK;
 }
 
-// the 2*depth blocks + head of one MixSTE2 on rows already embedded in pb.x / pb.xn; result in pb.pred [M,3]
 int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, int64_t R, hipStream_t s,
                       bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
-    const int F = w->frames, J = w->joints, C = w->channels;
-    const int64_t M = R * F * J;
-    int rc;
-    for (int i = 0; i < w->depth; ++i) {
-        BlockTail t{};
-        // spatial block i: sequences = the J joints of one (r, f); then Spatial_norm; TTE block 0 first adds the
-        // temporal position embedding; the next LayerNorm is norm1 of temporal block i.
-        t.post_w = w->snorm_w, t.post_b = w->snorm_b, t.post_eps = 1e-6f;
-        if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
-        t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
-        if ((rc = run_block(w->ste[i], pb, M, C, w->heads, R * F, J, 1, J, 0, 1, t, s, gemms_only, flops, launches,
-                            w->operand_bf16)))
-            return rc;
-        // temporal block i: sequences = the F frames of one (r, j); then Temporal_norm; next is norm1 of spatial
-        // block i+1, or the head (LayerNorm eps 1e-5 + Linear(C,3)) after the last block.
-        t = BlockTail{};
-        t.post_w = w->tnorm_w, t.post_b = w->tnorm_b, t.post_eps = 1e-6f;
-        if (i + 1 < w->depth) {
-            t.next_w = w->ste[i + 1].norm1_w, t.next_b = w->ste[i + 1].norm1_b, t.next_eps = 1e-6f;
-        } else {
-            t.next_w = w->hnorm_w, t.next_b = w->hnorm_b, t.next_eps = 1e-5f;
-            t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pb.pred;
-        }
-        if ((rc = run_block(w->tte[i], pb, M, C, w->heads, R * J, F, J, (int64_t)F * J, 1, J, t, s, gemms_only, flops,
-                            launches, w->operand_bf16)))
-            return rc;
-    }
-    return PAFUSE_OK;
+    return run_mixste_layers_n(&w, &pb, &R, 1, s, gemms_only, flops, launches);
+}
+
+// parts of one configuration may share grids when they all run split-precision products and have the same depth
+bool parts_groupable(const pafuse_d3dp_config* cfg) {
+    if (!grouping_enabled() || cfg->num_parts < 2 || cfg->num_parts > GROUP_MAX) return false;
+    for (int i = 0; i < cfg->num_parts; ++i)
+        if (cfg->part[i].operand_bf16 != 2 || cfg->part[i].depth != cfg->part[0].depth) return false;
+    return true;
 }
 
 int launch_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int64_t t_scalar, int B, float* out,
@@ -656,6 +785,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
                 break;
             }
         }
+        const bool together = !multi && parts_groupable(cfg);  // one stream: block k of every part in shared grids
         for (int lane = 0; lane < lanes && rc == PAFUSE_OK; ++lane) {
             const int i = lane % NP, gi = lane / NP;
             const pafuse_mixste2_weights* w = &cfg->part[i];
@@ -672,9 +802,15 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)),
                                dim3(256), 0, ls, e);
             if ((rc = check_launch("embed_kernel"))) break;
-            rc = run_mixste_layers(w, offset_rows(pb[i], row0, w->channels), r1 - r0, ls);
+            if (!together) rc = run_mixste_layers(w, offset_rows(pb[i], row0, w->channels), r1 - r0, ls);
         }
         if (rc) break;
+        if (together) {
+            const pafuse_mixste2_weights* ws[PAFUSE_MAX_PARTS];
+            int64_t Rs[PAFUSE_MAX_PARTS];
+            for (int i = 0; i < NP; ++i) ws[i] = &cfg->part[i], Rs[i] = R;
+            if ((rc = run_mixste_layers_n(ws, pb, Rs, NP, s0))) break;
+        }
         if (multi) {
             join();
             if (sync_err != hipSuccess) {
@@ -802,10 +938,18 @@ int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P
     char* base = (char*)workspace + align_up((size_t)B * P * cfg->frames * cfg->num_kps * 3 * 4);
     int launches = 0;
     double fl = 0.0;
+    PartBuffers pb[PAFUSE_MAX_PARTS];
+    const pafuse_mixste2_weights* ws[PAFUSE_MAX_PARTS];
+    int64_t Rs[PAFUSE_MAX_PARTS];
     for (int i = 0; i < cfg->num_parts; ++i) {
-        PartBuffers pb;
-        base = carve_part(base, R * cfg->frames * cfg->part[i].joints, cfg->part[i].channels, B, pb);
-        if ((rc = run_mixste_layers(&cfg->part[i], pb, R, (hipStream_t)stream, true, &fl, &launches))) return rc;
+        base = carve_part(base, R * cfg->frames * cfg->part[i].joints, cfg->part[i].channels, B, pb[i]);
+        ws[i] = &cfg->part[i], Rs[i] = R;
+    }
+    if (parts_groupable(cfg)) {  // the schedule pafuse_d3dp_sample runs: block k of every part in shared grids
+        if ((rc = run_mixste_layers_n(ws, pb, Rs, cfg->num_parts, (hipStream_t)stream, true, &fl, &launches))) return rc;
+    } else {
+        for (int i = 0; i < cfg->num_parts; ++i)
+            if ((rc = run_mixste_layers(&cfg->part[i], pb[i], R, (hipStream_t)stream, true, &fl, &launches))) return rc;
     }
     if (flops) *flops += fl;
     return launches;

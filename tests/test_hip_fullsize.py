@@ -224,6 +224,37 @@ def test_unit_entry_points_refuse_bad_operands():
                   torch.zeros(1, 64, device=DEV), *_selector_embed(4)[3:])
 
 
+def test_grouped_launches_equal_part_by_part_launches(tmp_path):
+    """The default schedule puts proj / fc1 / fc2 of the three parts into shared grids (grouped_*_kernel).  A tile's
+    arithmetic must not depend on the grid it runs in: the same loop in a process started with PAFUSE_NO_GROUPED=1
+    (every layer launched part by part) gives the same bits."""
+    import os
+    import subprocess
+    import sys
+    from __graft_entry__ import make_model
+    from tests.conftest import ROOT
+    script = (
+        "import sys, torch\n"
+        "from __graft_entry__ import make_model\n"
+        "from pafuse_amd import synthetic as gu\n"
+        "model, _ = make_model(20, 2, seed=52)\n"
+        "x2d, x2f = gu.synthetic_inputs_2d(B=1)\n"
+        "noises = gu.synthetic_noises(B=1, P=20, n=2, seed=7)\n"
+        "model.noise_fn = lambda k, shape, device: noises[k]\n"
+        "torch.save(model(x2d.cuda(), None, input_2d_flip=x2f.cuda()).cpu(), sys.argv[1])\n")
+    out_file = str(tmp_path / "part_by_part.pt")
+    env = dict(os.environ, PAFUSE_NO_GROUPED="1", PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, "-c", script, out_file], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    model, _ = make_model(20, 2, seed=52)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=20, n=2, seed=7)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    assert model.precision == "bf16x3" and "PAFUSE_NO_GROUPED" not in os.environ
+    grouped = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    assert torch.equal(grouped, torch.load(out_file))
+
+
 def test_bench_two_rank_rehearsal_on_one_gpu():
     """bench.py's N > 1 code path (rank census, hypothesis sharding, the all-gather and its timing, max-over-ranks
     clock) run as two real ranks under torch.distributed.run - sharing this box's single GPU over gloo, which is a

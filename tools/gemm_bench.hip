@@ -189,6 +189,7 @@ int main() {
     time_dma<2, 4, 3, EPI_ROWLN, 2, 2, 0, 16>("body fc2  rowln dma16 <2,4,3> st2 (2/CU)", q);
     time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <4,2,6> st3", q);
     time_dma<2, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <2,2,6> st3", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("body fc2  rowln dma16 <2,2,6> st2 (2/CU)", q);
     time_dma<6, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <6,2,6> st3", q);
     time_dma<4, 3, 4, EPI_ROWLN, 3, 2, 0, 16>("body fc2  rowln dma16 <4,3,4> st3", q);
     time_dma<4, 4, 3, EPI_ROWLN, 3, 4, 1, 16>("body fc2  rowln dma16 <4,4,3> st3 ABL1 stream", q);
@@ -208,6 +209,7 @@ int main() {
     time_dma<4, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("hands fc2 rowln dma16 <4,2,4> st2", q);
     time_dma<2, 4, 2, EPI_ROWLN, 3, 2, 0, 16>("hands fc2 rowln dma16 <2,4,2> st3", q);
     time_dma<2, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands fc2 rowln dma16 <2,2,4> st3", q);
+    time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("hands fc2 rowln dma16 <2,2,4> st2 (2/CU)", q);
     time_dma<8, 2, 4, EPI_ROWLN, 3, 4, 0, 16>("hands fc2 rowln dma16 <8,2,4> st3", q);
     q.M = 73440, q.N = 224, q.K = 448;
     time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2  rowln f32   <1,7,1>", q);
@@ -220,6 +222,7 @@ int main() {
     time_dma<2, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face fc2  rowln dma16 <2,1,7> st2", q);
     time_dma<6, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face fc2  rowln dma16 <6,1,7> st2", q);
     q.K = 224;
+    time_dma<8, 1, 7, EPI_ROWLN, 3, 2, 0, 16>("face proj rowln dma16 <8,1,7> st3", q);
     time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face proj rowln f32   <1,7,1>", q);
     time_gemm<2, 1, 7, EPI_ROWLN, 1, 1, 1, 2>("face proj rowln split <2,1,7>", q);
     time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("face proj rowln dma16 <4,1,7> st2", q);
@@ -230,5 +233,77 @@ int main() {
     time_dma<2, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <2,2,4> st3", q);
     time_dma<4, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <4,2,4> st3", q);
     time_dma<2, 4, 2, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <2,4,2> st3", q);
+    // ---- grouped whole-row launch (body + face + hands in one grid) against the per-part launches
+    if (!getenv("GB_FILTER") || strstr("grouped", getenv("GB_FILTER"))) {
+        struct Part { int64_t M; int N, K; uint8_t* ws; float *xo, *xn; };
+        for (int fc2 = 1; fc2 >= 0; --fc2) {
+            Part pt[3] = {{25920, 384, fc2 ? 768 : 384}, {73440, 224, fc2 ? 448 : 224}, {45360, 256, fc2 ? 512 : 256}};
+            GemmParams gp[3];
+            for (int i = 0; i < 3; ++i) {
+                CK(hipMalloc(&pt[i].ws, (size_t)pt[i].N * pt[i].K * 6));
+                CK(hipMalloc(&pt[i].xo, pt[i].M * pt[i].N * 4)); CK(hipMalloc(&pt[i].xn, pt[i].M * pt[i].N * 4));
+                hipLaunchKernelGGL(split_weights_kernel<16>, dim3((unsigned)(((int64_t)pt[i].N * (pt[i].K / 8) + 255) / 256)), dim3(256), 0, 0,
+                                   W + i * 1000, pt[i].ws, pt[i].N, pt[i].K);
+                gp[i] = q;
+                gp[i].W = W + i * 1000, gp[i].Wsplit = pt[i].ws, gp[i].M = pt[i].M, gp[i].N = pt[i].N, gp[i].K = pt[i].K;
+                gp[i].out_x = pt[i].xo, gp[i].out_n = pt[i].xn, gp[i].bf16 = 2;
+            }
+            auto k0 = gemm_dma_kernel<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>;
+            auto k1 = gemm_dma_kernel<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>;
+            auto k2 = gemm_dma_kernel<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>;
+            auto kp0 = gemm_dma_kernel<4, 2, 6, EPI_ROWLN, 3, 2, 0, 16>;   // production, round-2 profile
+            auto kp2 = gemm_kernel<2, 2, 4, EPI_ROWLN, 1, 2, 1, 2>;
+            auto kg = grouped_rowln_kernel<EPI_ROWLN>;
+            const size_t l0 = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES, l1 = 2 * DmaTile<4, 1, 7, 16>::STAGE_BYTES, l2 = 2 * DmaTile<2, 2, 4, 16>::STAGE_BYTES;
+            const size_t lp0 = 3 * DmaTile<4, 2, 6, 16>::STAGE_BYTES, lp2 = GemmTile<2, 2, 4>::STAGE_FLOATS_SPLIT * 4;
+            CK(hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0));
+            CK(hipFuncSetAttribute((const void*)kp0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp0));
+            CK(hipFuncSetAttribute((const void*)kg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0));
+            const int t0 = (25920 + 63) / 64, t1 = (73440 + 127) / 128, t2 = (45360 + 63) / 64;
+            auto pad8 = [](int t) { return (t + 7) / 8 * 8; };
+            GroupedGemmParams g{};
+            g.p[0] = gp[0], g.p[1] = gp[1], g.p[2] = gp[2], g.n = 3;
+            g.first[0] = 0, g.first[1] = pad8(t0), g.first[2] = g.first[1] + pad8(t1), g.first[3] = g.first[2] + pad8(t2);
+            uint8_t* ws32; CK(hipMalloc(&ws32, (size_t)256 * 512 * 6));   // hands image in the 32-deep format of the production kernel
+            hipLaunchKernelGGL(split_weights_kernel<32>, dim3((unsigned)(((int64_t)256 * (pt[2].K / 8) + 255) / 256)), dim3(256), 0, 0, gp[2].W, ws32, 256, pt[2].K);
+            GemmParams gh = gp[2]; gh.Wsplit = ws32;
+            auto production = [&]() {
+                hipLaunchKernelGGL(kp0, dim3((25920 + 127) / 128), dim3(512), lp0, 0, gp[0]);
+                hipLaunchKernelGGL(k1, dim3(t1), dim3(256), l1, 0, gp[1]);
+                hipLaunchKernelGGL(kp2, dim3(t2), dim3(256), lp2, 0, gh);
+            };
+            auto separate = [&]() {
+                hipLaunchKernelGGL(k0, dim3(t0), dim3(256), l0, 0, gp[0]);
+                hipLaunchKernelGGL(k1, dim3(t1), dim3(256), l1, 0, gp[1]);
+                hipLaunchKernelGGL(k2, dim3(t2), dim3(256), l2, 0, gp[2]);
+            };
+            auto grouped = [&]() { hipLaunchKernelGGL(kg, dim3(g.first[3]), dim3(256), l0, 0, g); };
+            auto timeit = [&](const char* tag, auto&& f) {
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                for (int i = 0; i < 3; ++i) f();
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 20; ++i) f();
+                CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                double fl = 0; for (int i = 0; i < 3; ++i) fl += 2.0 * pt[i].M * pt[i].N * pt[i].K;
+                printf("grouped %s %-40s : %8.1f us  %6.1f TF/s\n", fc2 ? "fc2 " : "proj", tag, ms * 1e3 / 20, fl / (ms * 1e-3 / 20) / 1e12);
+                fflush(stdout);
+            };
+            // results: grouped == separate launches of the same variants, bit for bit
+            std::vector<float> ref[3], got;
+            separate(); CK(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) { ref[i].resize(pt[i].M * pt[i].N); CK(hipMemcpy(ref[i].data(), pt[i].xn, ref[i].size() * 4, hipMemcpyDeviceToHost)); CK(hipMemset(pt[i].xn, 0, ref[i].size() * 4)); }
+            grouped(); CK(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) {
+                got.resize(ref[i].size()); CK(hipMemcpy(got.data(), pt[i].xn, got.size() * 4, hipMemcpyDeviceToHost));
+                printf("grouped %s part %d: %s\n", fc2 ? "fc2 " : "proj", i, memcmp(got.data(), ref[i].data(), got.size() * 4) ? "DIFFERENT" : "bit-identical");
+            }
+            timeit("three launches, round-2 production kernels", production);
+            timeit("three launches, 4-wave st2 variants (2/CU)", separate);
+            timeit("one grouped launch", grouped);
+            for (int i = 0; i < 3; ++i) { CK(hipFree(pt[i].ws)); CK(hipFree(pt[i].xo)); CK(hipFree(pt[i].xn)); }
+        }
+    }
     return 0;
 }

@@ -21,7 +21,7 @@ def main():
         d = by[int(r["Dispatch_Id"])]
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["name"], d["grid"], d["wg"] = r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"])
-    gemm = [v for _, v in sorted(by.items()) if ("gemm_kernel" in v["name"] or "gemm_dma_kernel" in v["name"])][-last:]
+    gemm = [v for _, v in sorted(by.items()) if any(k in v["name"] for k in ("gemm_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "grouped_bias_kernel"))][-last:]
     groups = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for v in gemm:
         g = groups[(v["name"].split("(")[0].replace("void ", ""), v["grid"] // v["wg"])]

@@ -5,14 +5,15 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
     python tools/pmc_traffic.py OUT/fetch_counter_collection.csv OUT/write_counter_collection.csv OUT/fetch_kernel_trace.csv \
-        [--sha256 DIGEST] [--git GITSHA] > profiles/r02_pmc_traffic.json
+        [--sha256 DIGEST] [--git GITSHA] [--dtype bf16x3] > profiles/r02_pmc_traffic.json
 
 Units and corrections exactly as MI355X_MICROARCH.md (HBM / rocprofv3 section) prescribes: both counters are in KiB of
 fabric requests; on gfx950 FETCH_SIZE tallies the 128-byte requests of wide coalesced streams at 64 bytes, so it is
 DOUBLED; WRITE_SIZE is exact for 16-byte-per-lane streaming stores.  Durations come from the same (counter-collecting,
 hence serialised) run, so GB/s per family = bytes / summed kernel time is a per-kernel figure, not a whole-loop one.
 `--sha256` is the kernel-source digest the profiled bench.py printed (`kernel_source_sha256` of its JSON line); bench.py
-only quotes this file when it equals the digest of the tree it runs from.
+only quotes this file when it equals the digest of the tree it runs from and `--dtype` (the product mode of the
+profiled run, default bf16x3 = bench.py's default) is the mode it is timing.
 """
 import collections
 import csv
@@ -21,7 +22,7 @@ import sys
 
 
 def family(name):
-    for key, fam in (("gemm_dma_kernel", "gemm"), ("tn_gemm_kernel", "gemm_dw"), ("gemm_kernel", "gemm"),
+    for key, fam in (("grouped_rowln_kernel", "gemm"), ("grouped_bias_kernel", "gemm"), ("gemm_dma_kernel", "gemm"), ("tn_gemm_kernel", "gemm_dw"), ("gemm_kernel", "gemm"),
                      ("attn_backward", "attention_bwd"), ("attn_kernel", "attention"), ("embed_kernel", "embed"),
                      ("finalize_kernel", "finalize"), ("time_embed", "time_embed"), ("split_weights", "split_weights"),
                      ("ln_backward", "ln_bwd")):
@@ -69,7 +70,7 @@ def main():
     doc = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, each with --kernel-trace) over "
                   "python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline (P=20, T=10); all dispatches of the process",
-        "kernel_source_sha256": opts.get("--sha256"), "git_sha": opts.get("--git"),
+        "kernel_source_sha256": opts.get("--sha256"), "git_sha": opts.get("--git"), "dtype": opts.get("--dtype", "bf16x3"),
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 64 B per 128-B request on 16-B/lane streams); "
                 "WRITE_SIZE exact for dwordx4 stores; counters are fabric-side: Infinity-Cache hits are included",
         "gemm_launches": g["launches"],
