@@ -250,8 +250,6 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
         order[i] = i;
     }
     std::sort(order, order + n, [&](int a, int b) { return cost[a] > cost[b]; });
-    static const bool dbg_asc = [] { const char* e = getenv("PAFUSE_DEBUG_GROUP_ASC"); return e && atoi(e); }();
-    if (dbg_asc && !ROWLN) std::reverse(order, order + n);  // experiment: fc1 writes the part fc2 reads first last
     GroupedGemmParams g{};
     g.n = n;
     int64_t first = 0;
