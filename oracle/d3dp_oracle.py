@@ -267,9 +267,15 @@ def flip_permutation(joints_left: Sequence[int], joints_right: Sequence[int], nu
     return perm
 
 
+# pass as `part_joints` for the single-model variant: one MixSTE2 over all keypoints, keys `pose_estimator.<parameter>`
+SINGLE_MODEL = {"all": list(range(NUM_KPS))}
+
+
 def predict_parts(sd, inputs_2d: Tensor, x_t: Tensor, t: Tensor, part_joints=None, depth=8, heads=8) -> Tensor:
     """split by part, run each part's denoiser, concatenate (reference common/diffusionpose.py:163-172, 328-335)."""
     part_joints = part_joints or PART_JOINTS
+    if part_joints is SINGLE_MODEL:      # general.part_based_model = False (reference common/diffusionpose.py:182-183, 203-205)
+        return mixste2_eval(sd, "pose_estimator.", inputs_2d, x_t, t, depth=depth, heads=heads)
     outs = []
     for part, idx in part_joints.items():
         outs.append(mixste2_eval(sd, f"pose_estimator.{part}.", inputs_2d[..., idx, :], x_t[..., idx, :], t,

@@ -97,9 +97,9 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 
 // split-precision GEMM, LDS-DMA pipelined form (one workgroup per CU, NSTAGE ring of 32-deep chunks)
 // K-chunk depth of the pre-split image of a weight (the image format is a property of the weight, fixed when it is
-// split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384, 256 and
-// 224 run on the LDS-DMA kernel with 16-deep chunks, everything else on 32-deep chunks.
-int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 256 || N == 224)) ? 16 : 32; }
+// split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384, 288, 256
+// and 224 run on the LDS-DMA kernel with 16-deep chunks, everything else on 32-deep chunks.
+int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 288 || N == 256 || N == 224)) ? 16 : 32; }
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32>
 int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
@@ -176,6 +176,7 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
                 // (a third of a tile's time when nothing overlaps it) runs under the K loop of the other.  The same
                 // variants serve the grouped launches below, so both routes give bit-identical rows.
                 case 384: return launch_gemm_dma<2, 2, 6, EPI, 2, 2, 16>(p, s);
+                case 288: return launch_gemm_dma<2, 3, 3, EPI, 2, 2, 16>(p, s);  // the single-model variant (cs = 288)
                 case 256: return launch_gemm_dma<2, 2, 4, EPI, 2, 2, 16>(p, s);
                 case 224:
                     return p.M >= 4096 ? launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16>(p, s) : launch_gemm_dma<2, 1, 7, EPI, 2, 2, 16>(p, s);
@@ -186,6 +187,7 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
         } else if (p.bf16) {
             switch (p.N) {
                 case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1, 1>(p, s);
+                case 288: return launch_gemm<1, 3, 3, EPI, 1, 1, 1, 1>(p, s);
                 case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1, 1>(p, s);
                 case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1, 1>(p, s);
                 case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 1>(p, s);
@@ -198,11 +200,12 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
         // row-per-lane accumulators (TR): LayerNorm statistics are in-lane sums + one shuffle + a tiny cross-wave
         // exchange, all global traffic is dwordx4, no LDS transposition (picked with tools/gemm_bench.hip)
         case 384: return launch_gemm<1, 4, 3, EPI, 1, 1, 1>(p, s);
+        case 288: return launch_gemm<1, 3, 3, EPI, 1, 1, 1>(p, s);
         case 256: return launch_gemm<2, 2, 4, EPI, 1, 2, 1>(p, s);  // (MINW 3 capped it at 168 VGPRs: 6 spilled, -2 %)
         case 224: return launch_gemm<1, 7, 1, EPI, 1, 1, 1>(p, s);
         case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1>(p, s);
         case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1>(p, s);
-        default: return fail(PAFUSE_E_SHAPE, "no whole-row kernel for channel width %d (have 64,128,224,256,384)", p.N);
+        default: return fail(PAFUSE_E_SHAPE, "no whole-row kernel for channel width %d (have 64,128,224,256,288,384)", p.N);
     }
 }
 
@@ -277,7 +280,7 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
     }
 }
 
-bool width_supported(int C) { return C == 384 || C == 256 || C == 224 || C == 128 || C == 64; }
+bool width_supported(int C) { return C == 384 || C == 288 || C == 256 || C == 224 || C == 128 || C == 64; }
 
 // ------------------------------------------------------------------------------------------- attention dispatch
 template <int LP, int DP, int NW>
@@ -293,10 +296,12 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 
 int attention(const AttnParams& p, hipStream_t s) {
     if (p.nseq <= 0) return PAFUSE_OK;
-    if (p.d % 4 || p.d > 48 || p.L > 80 || p.L <= 0)
-        return fail(PAFUSE_E_SHAPE, "attention: head dim %d (need %%4, <=48) / length %d (need <=80)", p.d, p.L);
+    if (p.d % 4 || p.d > 48 || p.L > 144 || p.L <= 0)
+        return fail(PAFUSE_E_SHAPE, "attention: head dim %d (need %%4, <=48) / length %d (need <=144)", p.d, p.L);
     const int dp = p.d <= 32 ? 32 : 48;
-    const int lp = p.L <= 32 ? 32 : (p.L <= 48 ? 48 : 80);
+    const int lp = p.L <= 32 ? 32 : (p.L <= 48 ? 48 : (p.L <= 80 ? 80 : 144));
+    if (lp == 144)  // the single-model variant: one sequence of all 134 keypoints (common/diffusionpose.py:150-153)
+        return dp == 32 ? launch_attn<144, 32, 9>(p, s) : launch_attn<144, 48, 9>(p, s);
     if (dp == 32) {
         if (lp == 32) return launch_attn<32, 32, 4>(p, s);
         if (lp == 48) return launch_attn<48, 32, 6>(p, s);
@@ -353,8 +358,8 @@ int check_weights(const pafuse_mixste2_weights* w) {
     if (w->heads <= 0 || w->channels % w->heads) return fail(PAFUSE_E_SHAPE, "heads %d !| C %d", w->heads, w->channels);
     const int d = w->channels / w->heads;
     if (d % 4 || d > 48) return fail(PAFUSE_E_SHAPE, "head dim %d unsupported", d);
-    if (w->joints < 1 || w->joints > 80 || w->frames < 1 || w->frames > 80)
-        return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..80", w->joints, w->frames);
+    if (w->joints < 1 || w->joints > 144 || w->frames < 1 || w->frames > 144)
+        return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..144", w->joints, w->frames);
     if (w->operand_bf16 < 0 || w->operand_bf16 > 2) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
     if (w->operand_bf16 == 2)
         for (int i = 0; i < w->depth; ++i)
@@ -966,6 +971,9 @@ int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x
     int rc = check_weights(w);
     if (rc) return rc;
     if (!x2d || !x3d || !t || !out || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_forward: bad argument");
+    if (w->joints > 80 || w->frames > 80)  // attn_backward_kernel keeps one item in LDS (train_kernels.hpp)
+        return fail(PAFUSE_E_SHAPE, "training: sequence lengths J=%d F=%d must be <= 80 (the single-model variant is inference only)",
+                    w->joints, w->frames);
     if (saved_bytes < train_bytes(w, B)) return fail(PAFUSE_E_WORKSPACE, "mixste2_train_forward: buffer too small");
     TrainBuffers tb;
     carve_train((char*)saved, w, B, tb);

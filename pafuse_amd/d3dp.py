@@ -1,7 +1,7 @@
 """D3DP - drop-in for the reference diffusion wrapper (common/diffusionpose.py:54-388) on the HIP library.
 
 Same constructor, ``forward(input_2d, input_3d, input_2d_flip=None)`` and state-dict layout (12 fp64 schedule
-buffers + ``pose_estimator.{body,face,hands}.*``).  Eval: the whole DDIM loop - flip-TTA, per-part denoisers,
+buffers + ``pose_estimator.{body,face,hands}.*``, or ``pose_estimator.*`` for ``general.part_based_model=False``).  Eval: the whole DDIM loop - flip-TTA, per-part denoisers,
 fp64 epsilon, stochastic update - is one call into ``pafuse_d3dp_sample`` (include/pafuse_hip.h).  Train: per-sample
 (t, noise) draws, ``pafuse_d3dp_qsample`` and the three train-mode denoisers (differentiable, HIP forward and backward).
 """
@@ -50,8 +50,7 @@ class D3DP(nn.Module):
                                                  self.parts_joint_indices.pop("right_hand"))
         if self.diff_model != 'MixSTE2':
             raise Exception(f"The model {self.diff_model} does not exist")
-        if not args.general.part_based_model:
-            raise NotImplementedError("the HIP path implements the part-based PAFUSE model")
+        self.part_based = bool(args.general.part_based_model)
 
         timesteps = args.ft2d.timestep
         self.objective = 'pred_x0'
@@ -79,16 +78,26 @@ class D3DP(nn.Module):
             self.register_buffer(name, val)
 
         drop_path_rate = 0.1 if is_train else 0
-        self.pose_estimator = nn.ModuleDict({
-            part: MixSTE2(num_frame=self.frames, num_joints=len(idx), in_chans=args.model.input_size,
-                          embed_dim_ratio=PART_WIDTH[part], depth=args.model.dep, num_heads=8, mlp_ratio=2.,
-                          qkv_bias=True, qk_scale=None, drop_path_rate=drop_path_rate, is_train=is_train)
-            for part, idx in self.parts_joint_indices.items()})
+        if self.part_based:
+            self.pose_estimator = nn.ModuleDict({
+                part: MixSTE2(num_frame=self.frames, num_joints=len(idx), in_chans=args.model.input_size,
+                              embed_dim_ratio=PART_WIDTH[part], depth=args.model.dep, num_heads=8, mlp_ratio=2.,
+                              qkv_bias=True, qk_scale=None, drop_path_rate=drop_path_rate, is_train=is_train)
+                for part, idx in self.parts_joint_indices.items()})
+            self._denoiser_joints = dict(self.parts_joint_indices)
+        else:
+            # general.part_based_model = False (common/diffusionpose.py:150-153): ONE MixSTE2 over all keypoints, width
+            # model.cs; state-dict keys `pose_estimator.<parameter>`.  To the library it is a one-part configuration
+            # whose joint list is the identity (sequences of 134 joints: the 144-key attention tiles).
+            self.pose_estimator = MixSTE2(num_frame=self.frames, num_joints=self.num_kps, in_chans=args.model.input_size,
+                                          embed_dim_ratio=args.model.cs, depth=args.model.dep, num_heads=8, mlp_ratio=2.,
+                                          qkv_bias=True, qk_scale=None, drop_path_rate=drop_path_rate, is_train=is_train)
+            self._denoiser_joints = {"all": list(range(self.num_kps))}
 
         # index tables of the path (int32, follow the module across devices, not part of the state dict)
         joint_part = torch.full((self.num_kps,), -1, dtype=torch.int32)
         joint_local = torch.zeros(self.num_kps, dtype=torch.int32)
-        for pi, (part, idx) in enumerate(self.parts_joint_indices.items()):
+        for pi, (part, idx) in enumerate(self._denoiser_joints.items()):
             self.register_buffer(f"_joints_{part}", torch.tensor(idx, dtype=torch.int32), persistent=False)
             joint_part[idx] = pi
             joint_local[idx] = torch.arange(len(idx), dtype=torch.int32)
@@ -115,10 +124,14 @@ class D3DP(nn.Module):
         self._graphs = {}
         # matrix-product mode: inference defaults to the split-precision products (fp32-equivalent: the same parity
         # bounds as the fp32 matrix cores hold, tests/test_hip_parity.py), training to the fp32 matrix cores
-        for m in self.pose_estimator.values():
+        for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS["f32" if is_train else "bf16x3"]
 
     PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+
+    def denoisers(self):
+        """{name: MixSTE2} in the order of the library's part table: the per-part models, or {'all': the single model}."""
+        return dict(self.pose_estimator.items()) if self.part_based else {"all": self.pose_estimator}
 
     @property
     def precision(self):
@@ -127,7 +140,7 @@ class D3DP(nn.Module):
         'bf16x3' split precision (inference): fp32 operands as three bf16 slices, six bf16 MFMA products, fp32
                  accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h);
         'bf16'   opt-in reduced precision: operands rounded to one bf16 (BASELINE configs[1])."""
-        modes = {int(m.operand_bf16) for m in self.pose_estimator.values()}
+        modes = {int(m.operand_bf16) for m in self.denoisers().values()}
         if len(modes) != 1:
             return "mixed"
         return {v: k for k, v in self.PRECISIONS.items()}[modes.pop()]
@@ -138,7 +151,7 @@ class D3DP(nn.Module):
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         if self.is_train and value != "f32":
             raise ValueError("training runs the fp32 matrix cores: precision must stay 'f32'")
-        for m in self.pose_estimator.values():
+        for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS[value]
         self._graphs.clear()
 
@@ -169,9 +182,10 @@ class D3DP(nn.Module):
 
     def config_struct(self, flip):
         cfg = _lib.D3DPConfig()
-        cfg.num_parts, cfg.num_kps, cfg.frames = len(self.pose_estimator), self.num_kps, self.frames
+        models = self.denoisers()
+        cfg.num_parts, cfg.num_kps, cfg.frames = len(models), self.num_kps, self.frames
         cfg.flip, cfg.scale = int(flip), float(self.scale)
-        for i, (part, model) in enumerate(self.pose_estimator.items()):
+        for i, (part, model) in enumerate(models.items()):
             cfg.part[i] = model.weights_struct()
             cfg.part_joints[i] = getattr(self, f"_joints_{part}").data_ptr()
         cfg.joint_part, cfg.joint_local = self._joint_part.data_ptr(), self._joint_local.data_ptr()
@@ -339,6 +353,8 @@ class D3DP(nn.Module):
         """common/diffusionpose.py:163-172 (training caller: every part's MixSTE2 in train mode)."""
         if tuple(input_2d.shape) != tuple(x_poses.shape[:-1]) + (2,) or input_2d.device != x_poses.device:
             raise ValueError(f"2-D input {tuple(input_2d.shape)} does not match the poses {tuple(x_poses.shape)}")
+        if not self.part_based:                             # common/diffusionpose.py:352-353 (train branch)
+            return self.pose_estimator(input_2d.contiguous(), x_poses.contiguous(), t)
         data_2d, data_3d = self.split_data(input_2d, x_poses)
         dev = x_poses.device
         cur = torch.cuda.current_stream(dev)

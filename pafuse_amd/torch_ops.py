@@ -258,10 +258,10 @@ def ddim_loop_args(model):
     """The (weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale) tail of pafuse::ddim_loop for a
     pafuse_amd.D3DP instance."""
     weights, joints = [], []
-    for part, m in model.pose_estimator.items():
+    for part, m in model.denoisers().items():
         weights += list(m.parameters())
         joints.append(getattr(model, f"_joints_{part}"))
-    first = next(iter(model.pose_estimator.values()))
+    first = next(iter(model.denoisers().values()))
     steps = model.ddim_steps()
     times = [int(s.time) for s in steps]
     sched = [v for s in steps for v in (s.sqrt_recip_acp, s.sqrt_recipm1_acp, s.sqrt_alpha_next, s.c, s.sigma)]

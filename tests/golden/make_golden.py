@@ -315,6 +315,38 @@ def g11_scale():
     save("g11_scale.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8), out=out)
 
 
+# ------------------------------------------------------------------------------------------------- G17
+def g17_single_model():
+    """general.part_based_model = False: ONE MixSTE2 over the 134 keypoints at width model.cs = 288
+    (common/diffusionpose.py:150-153), flip loop P=2, T=2 and the no-flip loop P=1, T=1."""
+    from common.diffusionpose import D3DP
+
+    def build(P, T, flip):
+        args = make_args()
+        args.general.part_based_model = False
+        args.model.test_time_augmentation = flip
+        m = D3DP(args, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, FakeDataset(), is_train=False, num_proposals=P,
+                 sampling_timesteps=T)
+        m.device = "cpu"
+        return m.eval()
+
+    m = build(2, 2, True)
+    sd = gu.seeded_state_dict(m.state_dict(), seed=171)
+    m.load_state_dict(sd)
+    x2d, x2d_flip = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=2, n=2, seed=17)
+    with NoiseTape(noises) as tape, torch.no_grad():
+        out = m(x2d, None, input_2d_flip=x2d_flip)
+        assert tape.k == 2
+    m1 = build(1, 1, False)
+    m1.load_state_dict(sd)
+    noises1 = gu.synthetic_noises(B=1, P=1, n=1, seed=18)
+    with NoiseTape(noises1), torch.no_grad():
+        out1 = m1(x2d, None)
+    save("g17_single_model.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8), flip_out=out, noflip_out=out1,
+         n_keys=np.asarray(len(sd)))
+
+
 # ------------------------------------------------------------------------------------------------- G12
 def _grad_stats(g):
     """compact pin of one gradient tensor: sum, L2 norm, first 8 entries"""
@@ -573,11 +605,11 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
                  g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train,
                  g14=g14_h3wb_loader, g15=g15_camera_to_world,
-                 g16=g16_chunked_generator)
+                 g16=g16_chunked_generator, g17=g17_single_model)
     for w in which:
         table[w]()

@@ -224,6 +224,59 @@ def test_unit_entry_points_refuse_bad_operands():
                   torch.zeros(1, 64, device=DEV), *_selector_embed(4)[3:])
 
 
+# ------------------------------------------------------------------------- general.part_based_model = False (G17)
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_g17_single_model_variant_golden(precision):
+    """One MixSTE2 over all 134 keypoints at width 288 (common/diffusionpose.py:150-153): 134-token spatial sequences
+    (the 144-key attention tiles), whole-row kernels of width 288; against the reference's own outputs."""
+    from __graft_entry__ import make_model
+    z = load_golden("g17_single_model.npz")
+    model, sd = make_model(2, 2, seed=171, part_based=False)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    model.precision = precision
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=2, n=2, seed=17)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    assert out.shape == z["flip_out"].shape
+    assert torch.allclose(out, z["flip_out"], rtol=0, atol=1e-5), (out - z["flip_out"]).abs().max()
+    # no-flip sampler, P = 1, T = 1
+    m1, _ = make_model(1, 1, seed=171, part_based=False, flip=False)
+    m1.precision = precision
+    n1 = gu.synthetic_noises(B=1, P=1, n=1, seed=18)
+    m1.noise_fn = lambda k, shape, device: n1[k]
+    o1 = m1(x2d.to(DEV), None).cpu()
+    assert torch.allclose(o1, z["noflip_out"], rtol=0, atol=1e-5), (o1 - z["noflip_out"]).abs().max()
+
+
+def test_single_model_variant_vs_oracle_and_hypothesis_independence():
+    from __graft_entry__ import make_model
+    model, sd = make_model(4, 3, seed=172, part_based=False)
+    x2d, x2f = gu.synthetic_inputs_2d(B=2)
+    noises = gu.synthetic_noises(B=2, P=4, n=3, seed=19)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    ref = orc.ddim_sample(sd, x2d, noises, 3, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f,
+                          part_joints=orc.SINGLE_MODEL)
+    assert (out.cpu() - ref).abs().max() <= 1e-5
+    try:
+        model.proposal_shard = (1, 3)                     # a rank's slice of the hypothesis axis: same bits
+        part = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    finally:
+        model.proposal_shard = None
+    assert torch.equal(part, out[:, :, 1:3])
+
+
+def test_single_model_variant_training_is_refused_loudly():
+    """attn_backward_kernel keeps one sequence in LDS (<= 80 tokens): the 134-joint model is inference only and says so."""
+    from __graft_entry__ import make_model
+    from pafuse_amd._lib import PafuseError
+    model, _ = make_model(1, 1, seed=173, part_based=False, is_train=True)
+    x2d, _ = gu.synthetic_inputs_2d(B=1)
+    with pytest.raises(PafuseError, match="inference only"):
+        model(x2d.to(DEV), torch.zeros(1, 27, 134, 3, device=DEV))
+
+
 def test_grouped_launches_equal_part_by_part_launches(tmp_path):
     """The default schedule puts proj / fc1 / fc2 of the three parts into shared grids (grouped_*_kernel).  A tile's
     arithmetic must not depend on the grid it runs in: the same loop in a process started with PAFUSE_NO_GROUPED=1

@@ -148,6 +148,24 @@ def test_g11_scale():
     assert torch.allclose(out, z["out"], rtol=0, atol=2e-5), (out - z["out"]).abs().max()
 
 
+def test_g17_single_model_variant():
+    """general.part_based_model = False (one MixSTE2 over the 134 keypoints, width cs = 288): the module's state dict has
+    the reference's keys and shapes (the seeded weights hash to the fixture's digest), and the oracle reproduces the
+    reference's flip (P=2, T=2) and no-flip (P=1, T=1) loops."""
+    from __graft_entry__ import make_model
+    z = load_golden("g17_single_model.npz")
+    model, sd = make_model(2, 2, seed=171, device="cpu", part_based=False)
+    assert len(sd) == int(z["n_keys"]) and gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    assert all(k.startswith("pose_estimator.") and k.split(".")[1] not in ("body", "face", "hands")
+               for k, v in sd.items() if v.dtype == torch.float32)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    out = orc.ddim_sample(sd, x2d, gu.synthetic_noises(B=1, P=2, n=2, seed=17), 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT,
+                          inputs_2d_flip=x2f, part_joints=orc.SINGLE_MODEL)
+    assert torch.allclose(out, z["flip_out"], rtol=0, atol=2e-5), (out - z["flip_out"]).abs().max()
+    o1 = orc.ddim_sample(sd, x2d, gu.synthetic_noises(B=1, P=1, n=1, seed=18), 1, part_joints=orc.SINGLE_MODEL)
+    assert torch.allclose(o1, z["noflip_out"], rtol=0, atol=2e-5), (o1 - z["noflip_out"]).abs().max()
+
+
 # ------------------------------------------------------------------------------------------------ training (n2)
 def drops_from_tape(tape, rates):
     """[(attn, mlp)] per block in execution order from the factors in the order the reference drew them."""
