@@ -52,8 +52,8 @@ typedef struct pafuse_block_weights {
     const float *qkv_w, *qkv_b;     /* [3C,C], [3C] */
     const float *proj_w, *proj_b;   /* [C,C], [C] */
     const float *norm2_w, *norm2_b; /* [C] */
-    const float *fc1_w, *fc1_b;     /* [2C,C], [2C] */
-    const float *fc2_w, *fc2_b;     /* [C,2C], [C] */
+    const float *fc1_w, *fc1_b;     /* [H,C], [H]   (H = mlp hidden width, 2C by default) */
+    const float *fc2_w, *fc2_b;     /* [C,H], [C] */
     /* split-precision mode only (pafuse_mixste2_weights.operand_bf16 == 2): the pre-split images of the four linear
      * weights, made by pafuse_split_weights from the fp32 tensors above (a cache - remake after a weight changes);
      * NULL otherwise */
@@ -61,7 +61,7 @@ typedef struct pafuse_block_weights {
 } pafuse_block_weights;
 
 /* One MixSTE2 (common/mixste.py:141-210): F frames, J joints of this part, C channels, `depth` spatial +
- * `depth` temporal blocks, `heads` heads (C % heads == 0), mlp hidden = 2C. */
+ * `depth` temporal blocks, `heads` heads (C % heads == 0), mlp hidden = 2C unless mlp_hidden says otherwise. */
 typedef struct pafuse_mixste2_weights {
     int32_t frames, joints, channels, depth, heads, in_chans; /* in_chans must be 5 (2-D + 3-D) */
     int32_t operand_bf16; /* matrix-product mode of the linear layers (activations, LayerNorm, softmax, attention and
@@ -73,6 +73,10 @@ typedef struct pafuse_mixste2_weights {
                                 FMA chain) at 2.7x the matrix rate; needs the *_ws weight images.
                              1: opt-in reduced precision - operands rounded to ONE bf16 (RNE), fp32 accumulate
                                 (BASELINE configs[1]; inference only) */
+    int32_t mlp_hidden;   /* MixSTE2(mlp_ratio=...): hidden width int(C * mlp_ratio) of every block's MLP, a multiple of 32,
+                             at most 3C; 0 = 2C (PAFUSE: mlp_ratio = 2, common/diffusionpose.py:146).  Inference only. */
+    float qk_scale;       /* MixSTE2(qk_scale=...): attention logit scale; 0 = head_dim^-0.5 (common/mixste.py:52).
+                             Inference only.  (qkv_bias=False: point qkv_b at zeros.) */
     const float *patch_w, *patch_b;                           /* Spatial_patch_to_embedding [C,5], [C] */
     const float *pos_spatial;                                 /* Spatial_pos_embed [J,C] */
     const float *pos_temporal;                                /* Temporal_pos_embed [F,C] */

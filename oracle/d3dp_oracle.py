@@ -133,22 +133,24 @@ def _layer_norm(sd, key: str, x: Tensor, eps: float) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[key + ".weight"], sd[key + ".bias"], eps)
 
 
-def _self_attention(sd, pre: str, x: Tensor, heads: int) -> Tensor:
-    """reference common/mixste.py:63-82 with comb=False; x is [S, L, C]."""
+def _self_attention(sd, pre: str, x: Tensor, heads: int, qk_scale: Optional[float] = None) -> Tensor:
+    """reference common/mixste.py:46-82 with comb=False; x is [S, L, C].  `qk_scale or head_dim ** -0.5` (:52);
+    qkv_bias=False leaves no bias key in the state dict (:54)."""
     S, L, C = x.shape
     d = C // heads
-    qkv = F.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = F.linear(x, sd[pre + "qkv.weight"], sd.get(pre + "qkv.bias"))
     qkv = qkv.reshape(S, L, 3, heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    w = ((q @ k.transpose(-2, -1)) * (d ** -0.5)).softmax(dim=-1)
+    w = ((q @ k.transpose(-2, -1)) * (qk_scale or d ** -0.5)).softmax(dim=-1)
     y = (w @ v).transpose(1, 2).reshape(S, L, C)
     return F.linear(y, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
 
 
-def transformer_block(sd, pre: str, x: Tensor, heads: int, eps: float = 1e-6, drop=None) -> Tensor:
+def transformer_block(sd, pre: str, x: Tensor, heads: int, eps: float = 1e-6, drop=None,
+                      qk_scale: Optional[float] = None) -> Tensor:
     """pre-norm block (reference common/mixste.py:113-116).  DropPath is the identity in eval; in training `drop` is
     the pair of per-sequence factors (mask / keep_prob, shape [S]) timm's DropPath multiplies the two branches by."""
-    a = _self_attention(sd, pre + "attn.", _layer_norm(sd, pre + "norm1", x, eps), heads)
+    a = _self_attention(sd, pre + "attn.", _layer_norm(sd, pre + "norm1", x, eps), heads, qk_scale)
     x = x + (a if drop is None or drop[0] is None else a * drop[0][:, None, None])
     h = F.linear(_layer_norm(sd, pre + "norm2", x, eps), sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
     m = F.linear(F.gelu(h), sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
@@ -184,7 +186,8 @@ def draw_drop_path(drop_path_rate: float, depth: int, B: int, Fr: int, J: int, l
 
 
 def mixste2_eval(sd: Dict[str, Tensor], pre: str, x_2d: Tensor, x_3d: Tensor, t: Tensor,
-                 depth: int = 8, heads: int = 8, taps: Optional[dict] = None, drop=None) -> Tensor:
+                 depth: int = 8, heads: int = 8, taps: Optional[dict] = None, drop=None,
+                 qk_scale: Optional[float] = None) -> Tensor:
     """MixSTE2.forward with is_train=False (reference common/mixste.py:278-298).
 
     x_2d [B,F,J,2], x_3d [B,P,F,J,3], t [B] int64 -> [B,P,F,J,3].  The token matrix is kept in one fixed
@@ -202,13 +205,15 @@ def mixste2_eval(sd: Dict[str, Tensor], pre: str, x_2d: Tensor, x_3d: Tensor, t:
         taps["embed"] = x.clone()
     for i in range(depth):
         # spatial block: sequences are the J joints of one (b,p,f)             mixste.py:239-244 / 264-270
-        x = transformer_block(sd, f"{pre}STEblocks.{i}.", x, heads, drop=None if drop is None else drop[2 * i])
+        x = transformer_block(sd, f"{pre}STEblocks.{i}.", x, heads, drop=None if drop is None else drop[2 * i],
+                              qk_scale=qk_scale)
         x = _layer_norm(sd, pre + "Spatial_norm", x, 1e-6)
         x = x.reshape(R, Fr, J, C).permute(0, 2, 1, 3).reshape(R * J, Fr, C)            # (b n) f c
         if i == 0:
             x = x + sd[pre + "Temporal_pos_embed"]                                      # mixste.py:250
         # temporal block: sequences are the F frames of one (b,p,j)             mixste.py:252-257 / 272-274
-        x = transformer_block(sd, f"{pre}TTEblocks.{i}.", x, heads, drop=None if drop is None else drop[2 * i + 1])
+        x = transformer_block(sd, f"{pre}TTEblocks.{i}.", x, heads, drop=None if drop is None else drop[2 * i + 1],
+                              qk_scale=qk_scale)
         x = _layer_norm(sd, pre + "Temporal_norm", x, 1e-6)
         x = x.reshape(R, J, Fr, C).permute(0, 2, 1, 3).reshape(R * Fr, J, C)            # back to (b f) n c
         if taps is not None:

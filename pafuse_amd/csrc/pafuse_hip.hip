@@ -361,6 +361,9 @@ int check_weights(const pafuse_mixste2_weights* w) {
     if (w->joints < 1 || w->joints > 144 || w->frames < 1 || w->frames > 144)
         return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..144", w->joints, w->frames);
     if (w->operand_bf16 < 0 || w->operand_bf16 > 2) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
+    if (w->mlp_hidden < 0 || (w->mlp_hidden > 0 && (w->mlp_hidden % 32 || w->mlp_hidden > 3 * w->channels)))
+        return fail(PAFUSE_E_SHAPE, "mlp hidden width %d must be a multiple of 32 and at most 3C = %d", w->mlp_hidden, 3 * w->channels);
+    if (!(w->qk_scale >= 0.f)) return fail(PAFUSE_E_ARG, "qk_scale must be positive (0 = head_dim^-0.5)");
     if (w->operand_bf16 == 2)
         for (int i = 0; i < w->depth; ++i)
             for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]})
@@ -390,7 +393,8 @@ struct BlockLaunch {
 
 BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
                        int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
-                       int bf16) {
+                       int bf16, int hidden = 0, float qk_scale = 0.f) {
+    if (hidden <= 0) hidden = 2 * C;  // mlp_ratio = 2, the PAFUSE configuration
     BlockLaunch b{};
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     GemmParams& g = b.qkv;
@@ -399,7 +403,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     AttnParams& a = b.attn;
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
     a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
-    a.scale = 1.0f / sqrtf((float)(C / heads));  // head_dim ** -0.5                    mixste.py:52
+    a.scale = qk_scale != 0.f ? qk_scale : 1.0f / sqrtf((float)(C / heads));  // qk_scale or head_dim ** -0.5  mixste.py:52
     // x = x + o Wproj^T + b ; xn = LN2(x)                                               mixste.py:80,114-115
     GemmParams& pj = b.proj;
     pj.A = pb.o, pj.W = bw.proj_w, pj.bias = bw.proj_b, pj.M = M, pj.N = C, pj.K = C;
@@ -408,11 +412,11 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     pj.bf16 = bf16, pj.Wsplit = (const uint8_t*)bw.proj_ws;
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
     GemmParams& f1 = b.fc1;
-    f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = 2 * C, f1.K = C, f1.act = 1;
+    f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = hidden, f1.K = C, f1.act = 1;
     f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
     GemmParams& f2 = b.fc2;
-    f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = 2 * C;
+    f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = hidden;
     f2.resid = pb.x, f2.out_x = tail.out_head ? nullptr : pb.x, f2.out_n = tail.out_head ? nullptr : pb.xn;
     f2.post_w = tail.post_w, f2.post_b = tail.post_b, f2.post_eps = tail.post_eps;
     f2.pos = tail.pos, f2.posJ = tail.posJ, f2.posF = tail.posF;
@@ -485,7 +489,8 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             t.post_w = w->snorm_w, t.post_b = w->snorm_b, t.post_eps = 1e-6f;
             if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
             t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
-            bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16);
+            bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16,
+                               w->mlp_hidden, w->qk_scale);
         }
         if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches))) return rc;
         for (int k = 0; k < n; ++k) {
@@ -502,7 +507,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
                 t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pbs[k].pred;
             }
             bl[k] = make_block(w->tte[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * J, F, J, (int64_t)F * J, 1, J, t,
-                               w->operand_bf16);
+                               w->operand_bf16, w->mlp_hidden, w->qk_scale);
         }
         if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches))) return rc;
     }
@@ -971,6 +976,8 @@ int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x
     int rc = check_weights(w);
     if (rc) return rc;
     if (!x2d || !x3d || !t || !out || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_forward: bad argument");
+    if ((w->mlp_hidden && w->mlp_hidden != 2 * w->channels) || w->qk_scale != 0.f)
+        return fail(PAFUSE_E_SHAPE, "training implements the PAFUSE configuration only (mlp_ratio = 2, qk_scale = None)");
     if (w->joints > 80 || w->frames > 80)  // attn_backward_kernel keeps one item in LDS (train_kernels.hpp)
         return fail(PAFUSE_E_SHAPE, "training: sequence lengths J=%d F=%d must be <= 80 (the single-model variant is inference only)",
                     w->joints, w->frames);

@@ -65,11 +65,23 @@ class MixSTE2(nn.Module):
                  num_heads=8, mlp_ratio=2., qkv_bias=True, qk_scale=None,
                  drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None, is_train=True):
         super().__init__()
-        if qk_scale is not None or not qkv_bias or mlp_ratio != 2.0 or drop_rate or attn_drop_rate:
-            raise NotImplementedError("the HIP path implements the PAFUSE configuration: qkv_bias=True, "
-                                      "qk_scale=None, mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
         norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
         C_ = embed_dim_ratio
+        # Constructor options PAFUSE never sets (it builds qkv_bias=True, qk_scale=None, mlp_ratio=2, no dropout,
+        # common/diffusionpose.py:144-147) are inference options here: the training kernels implement the PAFUSE
+        # configuration and refuse anything else in forward().
+        self.qk_scale = None if qk_scale is None else float(qk_scale)     # common/mixste.py:52: qk_scale or d ** -0.5
+        self.mlp_hidden = int(C_ * mlp_ratio)                             # common/mixste.py:101
+        self.qkv_bias = bool(qkv_bias)
+        self.drop_rate, self.attn_drop_rate = float(drop_rate), float(attn_drop_rate)   # nn.Dropout: identity in eval
+        if self.qk_scale is not None and not self.qk_scale > 0:
+            # `qk_scale or default` treats 0 as unset in the reference; a negative scale has no kernel here
+            self.qk_scale = None if self.qk_scale == 0 else self.qk_scale
+            if self.qk_scale is not None:
+                raise ValueError("qk_scale must be positive")
+        if self.mlp_hidden % 32 or not 0 < self.mlp_hidden <= 3 * C_:
+            raise NotImplementedError(f"mlp hidden width int({C_} * {mlp_ratio}) = {self.mlp_hidden}: the kernels need a "
+                                      f"multiple of 32, at most 3 * embed_dim_ratio")
         self.is_train = is_train
         self.num_frame, self.num_joints, self.in_chans = num_frame, num_joints, in_chans
         self.embed_dim, self.block_depth, self.num_heads = C_, depth, num_heads
@@ -86,6 +98,8 @@ class MixSTE2(nn.Module):
         self.Temporal_norm = norm_layer(C_)
         self.head = nn.Sequential(nn.LayerNorm(C_), nn.Linear(C_, 3))
         self.register_buffer("_freqs", sinusoid_frequencies(C_), persistent=False)
+        if not self.qkv_bias:        # nn.Linear(bias=False): no key in the state dict; the kernels add these zeros
+            self.register_buffer("_zero_qkv_bias", torch.zeros(3 * C_), persistent=False)
         self._wcache = None
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
@@ -100,7 +114,10 @@ class MixSTE2(nn.Module):
     def weights_struct(self):
         """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes)."""
         # attribute access, not named_parameters(): nn.DataParallel replicas keep their copies as plain attributes
-        get = lambda name: attrgetter(name)(self)
+        def get(name):
+            if name.endswith("attn.qkv.bias") and not self.qkv_bias:
+                return self._zero_qkv_bias
+            return attrgetter(name)(self)
         mode = int(self.operand_bf16)
         key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode)
         if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
@@ -111,6 +128,8 @@ class MixSTE2(nn.Module):
         fill_weights_struct(w, get, self._freqs, self.num_frame, self.num_joints, self.embed_dim,
                             self.block_depth, self.num_heads, self.in_chans, mode,
                             self._split_images(get) if mode == 2 else None)
+        w.mlp_hidden = self.mlp_hidden
+        w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
         self._wcache = (key, w)
         return w
 
@@ -141,6 +160,10 @@ class MixSTE2(nn.Module):
         if not x_3d.is_cuda:
             raise _lib.PafuseError("MixSTE2 runs on the HIP device only (no CPU fallback)")
         if self.is_train:
+            if (self.qk_scale is not None or not self.qkv_bias or self.mlp_hidden != 2 * self.embed_dim or self.drop_rate
+                    or self.attn_drop_rate):
+                raise NotImplementedError("training implements the PAFUSE configuration: qkv_bias=True, qk_scale=None, "
+                                          "mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
             if self.operand_bf16:
                 raise NotImplementedError("bf16 / split-precision products are inference options; training runs the "
                                           "fp32 matrix cores (set precision = 'f32')")

@@ -347,6 +347,28 @@ def g17_single_model():
          n_keys=np.asarray(len(sd)))
 
 
+# ------------------------------------------------------------------------------------------------- G18
+G18_KW = dict(num_frame=9, num_joints=17, in_chans=5, embed_dim_ratio=64, depth=2, num_heads=8, mlp_ratio=3.,
+              qkv_bias=False, qk_scale=0.3, drop_rate=0.1, attn_drop_rate=0.2, is_train=False)
+
+
+def g18_mixste_options():
+    """MixSTE2 constructor options PAFUSE never sets (common/mixste.py:141-144): mlp_ratio=3, qkv_bias=False,
+    qk_scale=0.3 and dropout rates (identity in eval) on a small eval-mode model."""
+    from common.mixste import MixSTE2
+    m = MixSTE2(**G18_KW).eval()
+    sd = gu.seeded_state_dict(m.state_dict(), seed=181)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(182)
+    x2d = torch.rand(2, 9, 17, 2, generator=g) * 2 - 1
+    x3d = torch.randn(2, 3, 9, 17, 3, generator=g).clamp(-1.1, 1.1)
+    t = torch.tensor([17, 803])
+    with torch.no_grad():
+        out = m(x2d, x3d, t)
+    save("g18_mixste_options.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8), x2d=x2d, x3d=x3d, t=t, out=out,
+         n_keys=np.asarray(len(sd)))
+
+
 # ------------------------------------------------------------------------------------------------- G12
 def _grad_stats(g):
     """compact pin of one gradient tensor: sum, L2 norm, first 8 entries"""
@@ -605,11 +627,11 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
                  g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train,
                  g14=g14_h3wb_loader, g15=g15_camera_to_world,
-                 g16=g16_chunked_generator, g17=g17_single_model)
+                 g16=g16_chunked_generator, g17=g17_single_model, g18=g18_mixste_options)
     for w in which:
         table[w]()

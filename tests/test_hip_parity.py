@@ -700,3 +700,23 @@ def test_bf16_precision_mode_end_to_end():
     got, want = _mpjpe_report(low.cpu(), target, x2d), _mpjpe_report(f32.cpu(), target, x2d)
     for k in want:
         assert (got[k] - want[k]).abs().max() <= BF16_MPJPE_TOL_MM, (k, (got[k] - want[k]).abs())
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_g18_mixste2_constructor_options_golden(mode):
+    """MixSTE2(mlp_ratio=3, qkv_bias=False, qk_scale=0.3, dropout rates) in eval against the reference's output (golden
+    G18), on the fp32 and the split-precision products; training such a model is refused."""
+    import pafuse_amd
+    from tests.test_oracle_golden import G18_KW
+    z = load_golden("g18_mixste_options.npz")
+    m = pafuse_amd.MixSTE2(**G18_KW)
+    sd = gu.seeded_state_dict(m.state_dict(), seed=181)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.operand_bf16 = mode
+    out = m(z["x2d"].to(DEV), z["x3d"].to(DEV), z["t"].to(DEV)).cpu()
+    assert (out - z["out"]).abs().max() <= 1e-5, (out - z["out"]).abs().max()
+    m.is_train, m.operand_bf16 = True, 0
+    with pytest.raises(NotImplementedError, match="PAFUSE configuration"):
+        m(z["x2d"].to(DEV), z["x3d"][:, 0].to(DEV), z["t"].to(DEV))

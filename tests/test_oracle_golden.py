@@ -3,6 +3,7 @@
 These pins are what allows the GPU parity tests to use the oracle as the checker at other sizes/seeds.
 """
 import numpy as np
+import pytest
 import torch
 
 from oracle import d3dp_oracle as orc
@@ -164,6 +165,26 @@ def test_g17_single_model_variant():
     assert torch.allclose(out, z["flip_out"], rtol=0, atol=2e-5), (out - z["flip_out"]).abs().max()
     o1 = orc.ddim_sample(sd, x2d, gu.synthetic_noises(B=1, P=1, n=1, seed=18), 1, part_joints=orc.SINGLE_MODEL)
     assert torch.allclose(o1, z["noflip_out"], rtol=0, atol=2e-5), (o1 - z["noflip_out"]).abs().max()
+
+
+G18_KW = dict(num_frame=9, num_joints=17, in_chans=5, embed_dim_ratio=64, depth=2, num_heads=8, mlp_ratio=3.,
+              qkv_bias=False, qk_scale=0.3, drop_rate=0.1, attn_drop_rate=0.2, is_train=False)
+
+
+def test_g18_mixste2_constructor_options():
+    """mlp_ratio=3, qkv_bias=False, qk_scale=0.3, dropout rates (common/mixste.py:141-144; identity in eval): the module
+    mirror has the reference's state-dict layout (no qkv bias keys, [3C] hidden) and the oracle reproduces the
+    reference's eval forward."""
+    import pafuse_amd
+    z = load_golden("g18_mixste_options.npz")
+    m = pafuse_amd.MixSTE2(**G18_KW)
+    sd = gu.seeded_state_dict(m.state_dict(), seed=181)
+    assert len(sd) == int(z["n_keys"]) and gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    assert not any(k.endswith("qkv.bias") for k in sd) and sd["STEblocks.0.mlp.fc1.weight"].shape == (192, 64)
+    out = orc.mixste2_eval(sd, "", z["x2d"], z["x3d"], z["t"], depth=2, heads=8, qk_scale=0.3)
+    assert torch.equal(out, z["out"]) or torch.allclose(out, z["out"], rtol=0, atol=2e-6), (out - z["out"]).abs().max()
+    with pytest.raises(NotImplementedError):            # hidden width 80 is no multiple of 32
+        pafuse_amd.MixSTE2(embed_dim_ratio=64, mlp_ratio=1.25)
 
 
 # ------------------------------------------------------------------------------------------------ training (n2)
