@@ -10,11 +10,17 @@
 using namespace pafuse;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int MODE = 0>
 void life(const char* tag, GemmParams p) {
     using T = GemmTile<WM, WN, NT>;
-    size_t lds = (size_t)NSTAGE * T::STAGE_FLOATS * 4;
-    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR>;
+    size_t lds = (size_t)NSTAGE * (MODE == 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * 4;
+    p.bf16 = MODE;
+    if (MODE == 2) {  // split-precision products: the pre-split image of W
+        uint8_t* ws; CK(hipMalloc(&ws, (size_t)p.N * p.K * 6));
+        hipLaunchKernelGGL(split_weights_kernel<32>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W, ws, p.N, p.K);
+        p.Wsplit = ws;
+    }
+    auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, MODE>;
     if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     size_t nw = tiles * (T::NTHR / 64);
@@ -36,7 +42,7 @@ void life(const char* tag, GemmParams p) {
         double a = (double)(h[w * 4] - t0) / (t1 - t0) * NB, b = (double)(h[w * 4 + 2] - t0) / (t1 - t0) * NB;
         for (int i = 0; i < NB; ++i) { double lo = std::max(a, (double)i), hi = std::min(b, (double)i + 1); if (hi > lo) alive[i] += hi - lo; }
     }
-    double mfma = (double)(p.K / 32) * 16 * NT * 64;
+    double mfma = MODE == 2 ? (double)(p.K / 16) * 6 * NT * 32 : (double)(p.K / 32) * 16 * NT * 64;
     printf("%s: tiles=%ld waves=%zu span=%.0f cyc | per wave: prologue+loop %.0f  epilogue %.0f  (own MFMA issue %.0f) | MFMA-pipe busy over span: %.1f%%\n  waves alive per CU over time:", tag, (long)tiles, nw,
            (double)(t1 - t0), loop / nw, epi / nw, mfma, mfma * nw / 1024.0 / (double)(t1 - t0) * 100);
     for (int i = 0; i < NB; ++i) printf(" %.1f", alive[i] / 256.0);
@@ -61,9 +67,12 @@ int main() {
     p.A = A, p.W = W, p.bias = bias, p.out = out;
     p.M = 25920, p.N = 1152, p.K = 384;
     life<4, 1, 2, EPI_BIAS, 1>("body qkv <4,1,2> s1", p);
+    life<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv SPLIT <4,1,4> s1", p);
+    life<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("body qkv SPLIT <4,1,2> s1", p);
     life<4, 1, 3, EPI_BIAS, 1, 1, 1>("body qkv <4,1,3> s1 TR", p);
     p.N = 768, p.act = 1;
     life<4, 1, 2, EPI_BIAS, 1>("body fc1+gelu <4,1,2> s1", p);
+    life<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body fc1+gelu SPLIT <4,1,4> s1", p);
     GemmParams q{};
     q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
     q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;

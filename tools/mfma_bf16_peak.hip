@@ -16,7 +16,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int NACC, int ORDER, int LDSR, int NWAVE>
-__global__ void __launch_bounds__(NWAVE * 64) kern(float* out, int iters, const uint32_t* rnd, unsigned long long* clk) {
+__global__ void __launch_bounds__(NWAVE * 64, 2) kern(float* out, int iters, const uint32_t* rnd, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x;
     for (int i = tid; i < 16384; i += NWAVE * 64) lds[i] = rnd[i];  // 64 KB of random bf16 pairs
