@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Determinism soak of the product path: N flip-TTA DDIM loops at the metric's configuration (P=20, T=10, B=1) on the
+same seeded inputs, every output compared bit for bit with the first.  The split-precision (bf16x3) default runs on one
+stream with grouped launches; this is the check that nothing in that schedule depends on timing.
+
+    python tools/soak_determinism.py [N=200] [precision=bf16x3]   ->  one JSON line
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import make_model  # noqa: E402
+from pafuse_amd import synthetic as gu  # noqa: E402
+from pafuse_amd._lib import kernel_source_digest  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    precision = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+    model, _ = make_model(20, 10, seed=77)
+    model.precision = precision
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=20, n=10, seed=3)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    x2d, x2f = x2d.cuda(), x2f.cuda()
+    ref = model(x2d, None, input_2d_flip=x2f)
+    bad, t0 = 0, time.time()
+    for _ in range(n):
+        bad += int(not torch.equal(model(x2d, None, input_2d_flip=x2f), ref))
+    print(json.dumps({"what": "repeated D3DP.forward, P=20 T=10 B=1, bitwise comparison with the first run", "runs": n,
+                      "precision": precision, "runs_that_differ": bad, "seconds": round(time.time() - t0, 1),
+                      "device": torch.cuda.get_device_name(0), "kernel_source_sha256": kernel_source_digest()}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
