@@ -155,6 +155,7 @@ int main() {
     p.N = 768, p.act = 1;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body fc1+gelu f32   <4,1,2> s1", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body fc1+gelu split <4,1,4> s1", p);
+    { GemmParams pn = p; pn.act = 0; time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body fc1 NOgelu split <4,1,4> s1", pn); }
     time_dma<8, 1, 4, EPI_BIAS, 2, 2>("body fc1+gelu dma <8,1,4> st2", p);
     time_dma<4, 1, 4, EPI_BIAS, 3, 1>("body fc1+gelu dma <4,1,4> st3", p);
     time_dma<8, 1, 2, EPI_BIAS, 3, 2>("body fc1+gelu dma <8,1,2> st3", p);

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Turns the raw outputs of tools/collect_profiles.sh (gpurun_out/prof/) into the committed summaries under profiles/.
+#   bash tools/summarise_profiles.sh [GITSHA of the collected tree, default HEAD]
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+O=$R/gpurun_out/prof
+GIT=${1:-$(git -C "$R" rev-parse HEAD)}
+SHA=$(python3 -c "import json;print(json.load(open('$O/fetch_bench_line.json'))['kernel_source_sha256'])")
+N=$(python3 -c "import json;print(json.load(open('$O/stats_bench_line.json'))['roofline']['launches'])")
+python3 "$R/tools/pmc_traffic.py" "$O/fetch_counter_collection.csv" "$O/write_counter_collection.csv" "$O/fetch_kernel_trace.csv" \
+    --sha256 "$SHA" --git "$GIT" --dtype bf16x3 > "$R/profiles/r02_pmc_traffic.json"
+cp "$O/stats_kernel_stats.csv" "$R/profiles/r02_kernel_stats_bench_P20_T10.csv"
+python3 "$R/tools/trace_by_grid.py" "$O/stats_kernel_trace.csv" "$N" > "$R/profiles/r02_kernel_trace_by_grid.csv"
+python3 "$R/tools/pmc_mfma_util.py" "$O/mfma_counter_collection.csv" "$N" > "$R/profiles/r02_pmc_mfma_util.json"
+cp "$O/train_kernel_stats.csv" "$R/profiles/r02_train_kernel_stats_B37.csv"
+cp "$O/bench_line.json" "$R/profiles/r02_bench_line.json"
+cp "$O/bench_line_f32.json" "$R/profiles/r02_bench_line_f32.json"
+cp "$O/stats_bench_line.json" "$R/profiles/r02_bench_line_under_rocprof.json"
+cp "$O/train_bench_line.json" "$R/profiles/r02_train_bench_line_under_rocprof.json"
+cp "$O/train_bench_line_unprofiled.json" "$R/profiles/r02_train_bench_line_unprofiled.json"
+cp "$O/soak_determinism.json" "$R/profiles/r02_soak_determinism.json"
+cp "$O/parity_report.json" "$R/profiles/r02_parity_report.json"
+echo "kernel sources $SHA (tree now: $(python3 -c "import sys; sys.path.insert(0,'$R'); from pafuse_amd._lib import kernel_source_digest as k; print(k())"))"
