@@ -250,7 +250,7 @@ def main():
     # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------------------
     if not args.no_cpu_baseline and rank == 0:
         from oracle import d3dp_oracle as orc
-        Pc, Tc = 4, 2
+        Pc, Tc = 20, 3        # the metric's P, three of its ten steps: 10 - 15 s of host CPU at the best thread count
         noises = gu.synthetic_noises(B=1, P=Pc, n=Tc, seed=9)
         xc, xcf = gu.synthetic_inputs_2d(B=1)
         n1 = gu.synthetic_noises(B=1, P=1, n=1, seed=9)
