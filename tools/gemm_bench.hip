@@ -127,6 +127,11 @@ int main() {
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body qkv  f32   <4,1,2> s1 minw5", p);
     time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv  split <4,1,4> s1 minw2", p);
     time_dma<8, 1, 4, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <8,1,4> st3", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 3, 0, 16>("body qkv  dma16 <4,1,4> st2 minw3 (3/CU)", p);
+    time_dma<4, 1, 4, EPI_BIAS, 2, 2, 0, 16>("body qkv  dma16 <4,1,4> st2 minw2", p);
+    time_dma<4, 1, 2, EPI_BIAS, 2, 4, 0, 16>("body qkv  dma16 <4,1,2> st2 minw4 (4/CU)", p);
+    time_dma<4, 1, 3, EPI_BIAS, 2, 3, 0, 16>("body qkv  dma16 <4,1,3> st2 minw3 (3/CU)", p);
+    time_dma<2, 2, 4, EPI_BIAS, 2, 3, 0, 16>("body qkv  dma16 <2,2,4> st2 minw3 (64x256)", p);
     time_dma<4, 1, 4, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <4,1,4> st3 (2/CU)", p);
     time_dma<4, 1, 2, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <4,1,2> st3 (3/CU)", p);
     time_dma<8, 1, 2, EPI_BIAS, 3, 2, 0, 16>("body qkv  dma16p <8,1,2> st3", p);
