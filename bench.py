@@ -201,6 +201,27 @@ def main():
         ms = e0.elapsed_time(e1)
         n = launches * reps
         achieved = flops.value / (ms * 1e-3) / 1e12
+        # the same for each layer kind alone (pafuse_d3dp_replay_layers): which kernels of the family are how far from peak
+        by_layer = {}
+        layer_kernel = ({1: "gemm_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
+                         8: "grouped_rowln_kernel"} if args.dtype == "bf16x3" else
+                        {1: "gemm_kernel", 2: "gemm_kernel<..EPI_ROWLN>", 4: "gemm_kernel", 8: "gemm_kernel<..EPI_ROWLN>"})
+        for bit, name in ((1, "qkv"), (2, "proj+LN"), (4, "fc1+GELU"), (8, "fc2+LN")):
+            fl = C.c_double(0.0)
+            nl = _lib.check(lib.pafuse_d3dp_replay_layers(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
+                                                          stream.cuda_stream, bit, C.byref(fl)))          # warm-up
+            fl = C.c_double(0.0)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(stream)
+            for _ in range(reps):
+                _lib.check(lib.pafuse_d3dp_replay_layers(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
+                                                         stream.cuda_stream, bit, C.byref(fl)))
+            a1.record(stream)
+            torch.cuda.synchronize(dev)
+            t = a0.elapsed_time(a1)
+            by_layer[name] = {"kernel": layer_kernel[bit], "launches": nl * reps, "avg_launch_us": round(t * 1e3 / (nl * reps), 2),
+                              "achieved": round(fl.value / (t * 1e-3) / 1e12, 2),
+                              "frac": round(fl.value / (t * 1e-3) / 1e12 / peak, 4)}
         # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
         # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
         traffic, traffic_info = None, {"traffic_source": None}
@@ -245,7 +266,10 @@ def main():
                             **traffic_info,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                             "flops_per_launch": round(flops.value / n / 1e9, 3),
-                            "flops_unit": "GFLOP (algorithmic 2*M*N*K)"}
+                            "flops_unit": "GFLOP (algorithmic 2*M*N*K)",
+                            "by_layer": by_layer,
+                            "by_layer_note": "each layer kind of the pass replayed alone (same tiles, HIP events); "
+                                             "achieved in TFLOP/s, frac against `peak`"}
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------------------
     if not args.no_cpu_baseline and rank == 0:

@@ -231,6 +231,10 @@ int pafuse_hypothesis_errors(const float *pred, const float *gt, const float *x2
  * *flops.  Uses (and overwrites) the workspace like pafuse_d3dp_sample does. */
 int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config *cfg, int32_t B, int32_t P, void *workspace,
                              size_t workspace_bytes, void *stream, double *flops);
+/* The same for a subset of the four linear layers of every block: layer_mask bits 1 = qkv, 2 = proj, 4 = fc1 (+GELU),
+ * 8 = fc2 (15 = pafuse_d3dp_replay_gemms).  bench.py times each layer kind alone for the per-kernel roofline lines. */
+int pafuse_d3dp_replay_layers(const pafuse_d3dp_config *cfg, int32_t B, int32_t P, void *workspace,
+                              size_t workspace_bytes, void *stream, int32_t layer_mask, double *flops);
 
 /* ---- Training: MixSTE2 in train mode and its backward -------------------------------------------
  * Replaces MixSTE2.forward with is_train=True (common/mixste.py:215-225,260-298: no hypothesis axis, DropPath on

@@ -84,6 +84,8 @@ SIGNATURES = {
     "pafuse_hypothesis_errors": (C.c_int, [C.c_void_p] * 7 + [C.c_int32] * 5 + [C.c_void_p] * 7),
     "pafuse_d3dp_replay_gemms": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.POINTER(C.c_double)]),
+    "pafuse_d3dp_replay_layers": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "pafuse_mixste2_train_bytes": (C.c_size_t, [C.POINTER(MixSTE2Weights), C.c_int32]),
     "pafuse_mixste2_train_forward": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,

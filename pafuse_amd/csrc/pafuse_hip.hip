@@ -430,7 +430,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
 // one block of n independent parts: the same layer of every part in one grid where the grouped kernels apply
 // (n == 1: the plain per-part launches)
 int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = false, double* flops = nullptr,
-               int* launches = nullptr) {
+               int* launches = nullptr, int layer_mask = 15) {
     int rc;
     GemmParams g[GROUP_MAX];
     auto count = [&](int layers) {
@@ -439,7 +439,8 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
         *launches += layers;
     };
     const bool grouped = grouping_enabled() && n >= 2;
-    auto layer = [&](GemmParams BlockLaunch::*which, bool rowln) -> int {
+    auto layer = [&](GemmParams BlockLaunch::*which, bool rowln, int bit) -> int {
+        if (!(layer_mask & bit)) return PAFUSE_OK;
         bool all = grouped;
         for (int i = 0; i < n; ++i) {
             g[i] = bl[i].*which;
@@ -454,13 +455,13 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
     // attention launches of a block pair get 21 us slower, more than the shared qkv grid saves (9 us; rocprofv3, r02)
     for (int i = 0; i < n; ++i) {
         g[i] = bl[i].qkv;
-        if ((rc = gemm_bias(g[i], s))) return rc;
+        if ((layer_mask & 1) && (rc = gemm_bias(g[i], s))) return rc;
         if (!gemms_only && (rc = attention(bl[i].attn, s))) return rc;
     }
-    count(n);
-    if ((rc = layer(&BlockLaunch::proj, true))) return rc;
-    if ((rc = layer(&BlockLaunch::fc1, false))) return rc;
-    return layer(&BlockLaunch::fc2, true);
+    if (layer_mask & 1) count(n);
+    if ((rc = layer(&BlockLaunch::proj, true, 2))) return rc;
+    if ((rc = layer(&BlockLaunch::fc1, false, 4))) return rc;
+    return layer(&BlockLaunch::fc2, true, 8);
 }
 
 int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
@@ -473,7 +474,8 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
 // the 2*depth blocks + head of n independent MixSTE2 denoisers of equal depth on rows already embedded in pb[i].x /
 // pb[i].xn; results in pb[i].pred [M_i,3].  Block k of every part is issued together (run_blocks).
 int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffers* pbs, const int64_t* Rs, int n,
-                        hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
+                        hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr,
+                        int layer_mask = 15) {
     if (n < 1 || n > GROUP_MAX) return fail(PAFUSE_E_ARG, "run_mixste_layers_n: %d parts", n);
     for (int i = 1; i < n; ++i)
         if (ws[i]->depth != ws[0]->depth) return fail(PAFUSE_E_ARG, "run_mixste_layers_n: parts of unequal depth");
@@ -492,7 +494,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16,
                                w->mlp_hidden, w->qk_scale);
         }
-        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches))) return rc;
+        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask))) return rc;
         for (int k = 0; k < n; ++k) {
             const pafuse_mixste2_weights* w = ws[k];
             const int F = w->frames, J = w->joints, C = w->channels;
@@ -509,14 +511,14 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             bl[k] = make_block(w->tte[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * J, F, J, (int64_t)F * J, 1, J, t,
                                w->operand_bf16, w->mlp_hidden, w->qk_scale);
         }
-        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches))) return rc;
+        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask))) return rc;
     }
     return PAFUSE_OK;
 }
 
 int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, int64_t R, hipStream_t s,
-                      bool gemms_only = false, double* flops = nullptr, int* launches = nullptr) {
-    return run_mixste_layers_n(&w, &pb, &R, 1, s, gemms_only, flops, launches);
+                      bool gemms_only = false, double* flops = nullptr, int* launches = nullptr, int layer_mask = 15) {
+    return run_mixste_layers_n(&w, &pb, &R, 1, s, gemms_only, flops, launches, layer_mask);
 }
 
 // parts of one configuration may share grids when they all run split-precision products and have the same depth
@@ -936,7 +938,13 @@ int pafuse_hypothesis_errors(const float* pred, const float* gt, const float* x2
 
 int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, void* workspace,
                              size_t workspace_bytes, void* stream, double* flops) {
+    return pafuse_d3dp_replay_layers(cfg, B, P, workspace, workspace_bytes, stream, 15, flops);
+}
+
+int pafuse_d3dp_replay_layers(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, void* workspace,
+                              size_t workspace_bytes, void* stream, int32_t layer_mask, double* flops) {
     StreamDevice on_stream_device(stream);
+    if (layer_mask < 1 || layer_mask > 15) return fail(PAFUSE_E_ARG, "replay_layers: layer_mask %d", layer_mask);
     int rc = d3dp_check(cfg, B, P);
     if (rc) return rc;
     if (!workspace || workspace_bytes < pafuse_d3dp_workspace_bytes(cfg, B, P))
@@ -954,10 +962,12 @@ int pafuse_d3dp_replay_gemms(const pafuse_d3dp_config* cfg, int32_t B, int32_t P
         ws[i] = &cfg->part[i], Rs[i] = R;
     }
     if (parts_groupable(cfg)) {  // the schedule pafuse_d3dp_sample runs: block k of every part in shared grids
-        if ((rc = run_mixste_layers_n(ws, pb, Rs, cfg->num_parts, (hipStream_t)stream, true, &fl, &launches))) return rc;
+        if ((rc = run_mixste_layers_n(ws, pb, Rs, cfg->num_parts, (hipStream_t)stream, true, &fl, &launches, layer_mask)))
+            return rc;
     } else {
         for (int i = 0; i < cfg->num_parts; ++i)
-            if ((rc = run_mixste_layers(&cfg->part[i], pb[i], R, (hipStream_t)stream, true, &fl, &launches))) return rc;
+            if ((rc = run_mixste_layers(&cfg->part[i], pb[i], R, (hipStream_t)stream, true, &fl, &launches, layer_mask)))
+                return rc;
     }
     if (flops) *flops += fl;
     return launches;
