@@ -17,6 +17,8 @@ Extra objects in the line:
                 algorithmic FLOPs of the GEMM launches of one flip-TTA denoiser pass (192 part by part; 128 when proj,
                 fc1 and fc2 are grouped) divided by their HIP-event time (launched back to back on the stream torch
                 uses), against 416.7 TFLOP/s (bf16 matrix peak / 6 products) or the 157.3 TFLOP/s f32 matrix peak.
+                `by_layer`: each of the four layer kinds replayed alone (pafuse_d3dp_replay_layers), so the line shows
+                which kernel of the family sits where (qkv / proj+LN / fc1+GELU / fc2+LN).
   roofline_loop the same fraction for the whole timed loop (2*T*69.38 GFLOP per hypothesis, everything included).
   cpu_baseline  the CPU oracle (a port of the reference's ATen path, oracle/) timed on the host cores of this box
                 on a bounded sample of the same workload.

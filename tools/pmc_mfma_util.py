@@ -3,7 +3,8 @@
 
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d out -o m -- \
         python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
-    python tools/pmc_mfma_util.py out/m_counter_collection.csv > profiles/r01_pmc_mfma_util.json
+    python tools/pmc_mfma_util.py out/m_counter_collection.csv [N [SKIP]] > profiles/r02_pmc_mfma_util.json
+(N launches of the roofline replay, before the last SKIP GEMM launches = the by_layer legs)
 
 SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (checked: = 64 cycles x the number of wave-level
 v_mfma_f32_32x32x2_f32 the launch issues), GRBM_GUI_ACTIVE over its 8 XCDs, so
@@ -16,12 +17,14 @@ import sys
 
 def main():
     last = int(sys.argv[2]) if len(sys.argv) > 2 else 576
+    skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # GEMM launches after the roofline replay (bench.py's by_layer legs)
     by = collections.defaultdict(dict)
     for r in csv.DictReader(open(sys.argv[1])):
         d = by[int(r["Dispatch_Id"])]
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["name"], d["grid"], d["wg"] = r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"])
-    gemm = [v for _, v in sorted(by.items()) if any(k in v["name"] for k in ("gemm_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "grouped_bias_kernel"))][-last:]
+    gemm = [v for _, v in sorted(by.items()) if any(k in v["name"] for k in ("gemm_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "grouped_bias_kernel"))]
+    gemm = gemm[-last - skip:-skip] if skip else gemm[-last:]
     groups = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for v in gemm:
         g = groups[(v["name"].split("(")[0].replace("void ", ""), v["grid"] // v["wg"])]
