@@ -220,9 +220,18 @@ struct GemmTile {
 // EPI_BIAS: out = act(acc + bias).  EPI_ROWLN / _TRAIN: the whole-row residual + LayerNorm chain of GemmParams; `smem` is
 // scratch for the cross-wave row sums (WN > 1; the caller guarantees every wave is done with its staging contents).
 // ----------------------------------------------------------------------------------------------------------------
-template <int WN, int NT, int BM, int EPI>
+// VEC > 0 (LDS-DMA tiles): the per-column vectors of the chain - bias, post_w, post_b, next_w, next_b, BN floats each - were
+// staged by the caller at smem + VEC (stage_epilogue_vectors) and are read from LDS; with VEC = 0 every lane loads its
+// 16-byte pieces of them from global memory between the dependent steps of the chain, ~120 small loads per lane that the
+// full register file cannot keep in flight (the epilogue was 52 000 cycles of a 64 x 384 tile's 122 000, tools/gemm_life.hip).
+template <int WN, int NT, int BM, int EPI, int VEC = 0>
 __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0,
                                                       const int wm, const int wn, const int r, const int h, float* smem) {
+    constexpr int BNV = WN * NT * 32;
+    auto vec4 = [&](const float* gptr, int slot, int n) -> f32x4 {
+        if constexpr (VEC > 0) return *reinterpret_cast<const f32x4*>(smem + VEC + slot * BNV + (n - n0));
+        else return *reinterpret_cast<const f32x4*>(gptr + n);
+    };
     // lane (r, h) owns row m = m0 + 32*wm + r; acc[nt][4q..4q+3] are columns 32*(wn*NT+nt) + 8q + 4h + {0,1,2,3}
     const int64_t m = m0 + wm * 32 + r;
     const bool live = m < p.M;
@@ -260,7 +269,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
             }
             return s;
         };
-        auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot) {
+        auto layer_norm = [&](const float* gw, const float* gb, float eps, int slot, int vslot) {
             float s = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -281,8 +290,8 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int n = nb + 32 * nt + 8 * q;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + n);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + n);
+                    const f32x4 g4 = vec4(gw, vslot, n);
+                    const f32x4 b4 = vec4(gb, vslot + 1, n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
@@ -300,7 +309,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = nb + 32 * nt + 8 * q;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const f32x4 b4 = vec4(p.bias, 0, n);
                 const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.resid + mo + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -318,7 +327,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                     }
                 }
             }
-        if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0);
+        if (p.post_w) layer_norm(p.post_w, p.post_b, p.post_eps, 0, 1);
         if (p.pos) {  // only the first spatial block of a pass
             const int f = (int)(((live ? m : p.M - 1) / p.posJ) % p.posF);
 #pragma unroll
@@ -342,7 +351,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                 }
         }
         if (p.next_w) {
-            layer_norm(p.next_w, p.next_b, p.next_eps, 2);
+            layer_norm(p.next_w, p.next_b, p.next_eps, 2, 3);
             if (p.out_n && live) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -714,6 +723,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM;
     if (m0 >= p.M) return;  // padded slot of a grouped launch (workgroup-uniform)
+    PAFUSE_STAMP(0);
     const int n0 = tile_n * BN;
     const int K = p.K, nk = K / BKC;
 
@@ -905,6 +915,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
             else
                 wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();  // chunk kc visible to every wave; every wave is done reading chunk kc - 1
+            if (kc == 0) { PAFUSE_STAMP(3); }
             // the refill of the stage chunk kc - 1 occupied (chunk kc + NSTAGE - 1) is issued piece by piece inside the MFMA
             // groups below: a DMA instruction costs its wave 60-180 cycles of issue, which a burst here would take from
             // the matrix pipe of every SIMD at once (all waves leave the barrier together)
@@ -1043,7 +1054,19 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
             __builtin_amdgcn_s_setprio(0);
         }
     }
+    PAFUSE_STAMP(1);
     __syncthreads();  // the staging LDS becomes the epilogue's scratch
+    constexpr int VEC = EPI == EPI_BIAS ? 0 : (7 * BM * WN + 3) / 4 * 4;  // behind the cross-wave reduction slots
+    if constexpr (VEC > 0) {
+        static_assert((size_t)(VEC + 5 * BN) * sizeof(float) <= (size_t)NSTAGE * T::STAGE_BYTES, "epilogue vectors must fit the ring");
+        const float* const src[5] = {p.bias, p.post_w, p.post_b, p.next_w, p.next_b};
+#pragma unroll
+        for (int v = 0; v < 5; ++v)
+            if (src[v])  // workgroup-uniform
+                for (int i = tid; i < BN / 4; i += T::NTHR)
+                    *reinterpret_cast<f32x4*>(smem + VEC + v * BN + 4 * i) = *reinterpret_cast<const f32x4*>(src[v] + n0 + 4 * i);
+        __syncthreads();
+    }
     if constexpr (ABL == 4) {
         float sacc = 0.f;
 #pragma unroll
@@ -1053,7 +1076,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
         if (sacc == 123.456f) p.out[0] = sacc;  // keeps the accumulators alive, stores nothing
         return;
     }
-    epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem);
+    epilogue_row_per_lane<WN, NT, BM, EPI, VEC>(acc, p, m0, n0, wm, wn, r, h, smem);
 }
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>

@@ -50,6 +50,38 @@ void life(const char* tag, GemmParams p) {
     CK(hipFree(st));
 }
 
+// the LDS-DMA tiles: stamps 0 = tile start, 3 = first chunk landed and visible, 1 = K loop done, 2 = epilogue done
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC>
+void life_dma(const char* tag, GemmParams p) {
+    using T = DmaTile<WM, WN, NT, BKC>;
+    const size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    p.bf16 = 2;
+    uint8_t* ws; CK(hipMalloc(&ws, (size_t)p.N * p.K * 6));
+    hipLaunchKernelGGL(split_weights_kernel<BKC>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W, ws, p.N, p.K);
+    p.Wsplit = ws;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, 0, BKC>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    const size_t nw = tiles * (T::NTHR / 64);
+    unsigned long long* st; CK(hipMalloc(&st, nw * 32)); CK(hipMemset(st, 0, nw * 32));
+    p.stamps = st;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(nw * 4);
+    CK(hipMemcpy(h.data(), st, nw * 32, hipMemcpyDeviceToHost));
+    double pro = 0, loop = 0, epi = 0; size_t n = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < nw; ++w) {
+        if (!h[w * 4] || !h[w * 4 + 2]) continue;
+        pro += h[w * 4 + 3] - h[w * 4]; loop += h[w * 4 + 1] - h[w * 4 + 3]; epi += h[w * 4 + 2] - h[w * 4 + 1]; ++n;
+        t0 = std::min(t0, h[w * 4]); t1 = std::max(t1, h[w * 4 + 2]);
+    }
+    const double mfma = (double)(p.K / 16) * 6 * NT * 32;
+    printf("%s: tiles=%ld waves=%zu span=%.0f cyc | per wave: prologue (first chunk) %.0f  K loop %.0f  epilogue %.0f  (own MFMA issue %.0f)\n", tag,
+           (long)tiles, n, (double)(t1 - t0), pro / n, loop / n, epi / n, mfma);
+    CK(hipFree(st)); CK(hipFree(ws));
+}
+
 int main() {
     const int64_t Mmax = 73440;
     float *A, *W, *bias, *out, *x, *xn, *vec;
@@ -77,10 +109,13 @@ int main() {
     q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
     q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
     q.M = 25920, q.N = 384, q.K = 768;
+    life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body fc2 rowln SPLIT dma16 <2,2,6> st2", q);
     life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2 rowln <1,4,3> s1 TR", q);
     q.K = 384;
+    life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2", q);
     life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln <1,4,3> s1 TR", q);
     q.M = 73440, q.N = 224, q.K = 448;
+    life_dma<4, 1, 7, EPI_ROWLN, 2, 2, 16>("face fc2 rowln SPLIT dma16 <4,1,7> st2", q);
     life<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2 rowln <1,7,1> s1 TR", q);
     return 0;
 }
