@@ -113,6 +113,10 @@ int main() {
     life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2 rowln <1,4,3> s1 TR", q);
     q.K = 384;
     life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2", q);
+    { GemmParams a = q; a.out_x = nullptr; a.out_n = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL no stores", a); }
+    { GemmParams a = q; a.post_w = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL no post LN", a); }
+    { GemmParams a = q; a.post_w = nullptr; a.next_w = nullptr; a.out_n = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL no LN at all", a); }
+    { GemmParams a = q; a.post_w = nullptr; a.next_w = nullptr; a.out_n = nullptr; a.out_x = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL resid only", a); }
     life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln <1,4,3> s1 TR", q);
     q.M = 73440, q.N = 224, q.K = 448;
     life_dma<4, 1, 7, EPI_ROWLN, 2, 2, 16>("face fc2 rowln SPLIT dma16 <4,1,7> st2", q);
