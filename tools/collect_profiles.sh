@@ -9,6 +9,10 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+# heartbeat: gpurun kills a call that writes nothing for 7 minutes (the CPU oracle of the parity report can take that long)
+( while sleep 60; do date >> "$O/heartbeat.log"; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 run() { echo "== $*" >&2; "$@"; }
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$O/stats_bench_line.json" 2> "$O/stats.err" || exit 1
 run rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/fetch_bench_line.json" 2> "$O/fetch.err" || exit 1
