@@ -55,6 +55,21 @@ def test_linear(M, N, K, act):
     assert torch.allclose(out.double(), ref, rtol=0, atol=2.5e-7 * K ** 0.5 + 1e-6), (out - ref).abs().max()
 
 
+def test_gelu_against_fp64():
+    """The epilogue's GELU (one branch-free erf form, kernels.hpp::gelu_erf) against an fp64 evaluation of
+    x * 0.5 * (1 + erf(x / sqrt(2))) (common/mixste.py:25,32), on x ~ N(0, 1.5) and a sweep of [-8, 8]: at least as close
+    as torch's own CPU fp32 GELU (what the reference and the oracle run)."""
+    from pafuse_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.randn(1 << 20, generator=g) * 1.5, torch.linspace(-8, 8, 1 << 16)]).reshape(-1, 64)
+    eye, zero = torch.eye(64), torch.zeros(64)                     # x @ I + 0 is exact: the output is GELU(x) itself
+    out = ops.linear(x.to(DEV), eye.to(DEV), zero.to(DEV), "gelu").cpu().double()
+    truth = x.double() * 0.5 * (1 + torch.special.erf(x.double() / 2 ** 0.5))
+    err, err_torch = (out - truth).abs(), (torch.nn.functional.gelu(x).double() - truth).abs()
+    assert err.max() <= 6e-7 and err.mean() <= 3e-8, (err.max(), err.mean())
+    assert err.max() <= err_torch.max() and err.mean() <= err_torch.mean(), (err.max(), err_torch.max(), err.mean(), err_torch.mean())
+
+
 def test_linear_exact_integers():
     """A = I-like and asymmetric integer W: catches any row/col or k-permutation slip exactly."""
     from pafuse_amd import ops
