@@ -21,7 +21,7 @@ DEV = "cuda"
 
 # |MPJPE_hip - MPJPE_oracle| bounds in mm per protocol, read off profiles/r02_parity_report.json (MI355X, P=5/T=5 and
 # P=20/T=10, every step).  north_star asks 1e-4 mm; NO protocol meets it at every step, and none can: measured
-# |dMPJPE| is 2e-6 .. 3.3e-4 mm for J-Best / P-Best / P-Agg alike, i.e. the size of the mean pointwise difference
+# |dMPJPE| is 2e-6 .. 3.7e-4 mm for J-Best / P-Best / P-Agg alike, i.e. the size of the mean pointwise difference
 # (2.5e-4 mm) - the differences do not average out over the 3 618 joints of a clip because part centring and
 # wb_pose_from_parts turn the rounding of ONE root / connection joint into a shift of a whole part, and because both
 # fp32 implementations (this one and the reference's ATen/MKL kernels) sit 2.1-2.6e-4 mm (mean) away from an exact
@@ -687,8 +687,8 @@ def test_linear_bf16_operands(M, N, K):
 
 
 # |MPJPE_bf16 - MPJPE_f32| bound (mm) for the opt-in bf16-operand mode at BASELINE configs[1] (P=5, T=5).  Measured on
-# MI355X (profiles/r02_parity_report.json, case "5,5,1,bf16", against the oracle): J-Best 3.7, P-Best 3.2, P-Agg 3.3,
-# J-Agg 3.1 mm (max over the five steps); pointwise mean 1.9e-3 m, max 1.2e-2 m.  Rounding every matrix operand to 8 significant bits costs that much on random weights - bf16 autocast
+# MI355X (profiles/r02_parity_report.json, case "5,5,1,bf16", against the oracle): J-Best 3.8, P-Best 3.5, P-Agg 3.4,
+# J-Agg 3.6 mm (max over the five steps); pointwise mean 1.9e-3 m, max 1.1e-2 m.  Rounding every matrix operand to 8 significant bits costs that much on random weights - bf16 autocast
 # of the reference itself sits at the same distance (hard part 1).
 BF16_MPJPE_TOL_MM = 6.0
 
