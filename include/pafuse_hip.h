@@ -118,6 +118,12 @@ typedef struct pafuse_ddim_step {
 const char *pafuse_version(void);
 const char *pafuse_last_error(void);
 
+/* Process-wide launch-schedule option (default 1): in the split-precision mode the same layer of the independent body-part
+ * denoisers runs in ONE grid (grouped_*_kernel); 0 launches every layer part by part.  A tile's arithmetic does not depend
+ * on the grid it runs in, so both schedules give the same bits (tests/test_hip_fullsize.py); the switch exists for that
+ * test and for A/B timing.  Returns the previous setting.  The library reads no environment variable. */
+int pafuse_set_grouped_launches(int32_t on);
+
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU; +2: bf16 operands (see operand_bf16).
  * K,N multiples of 32. */
 int pafuse_linear(const float *A, const float *W, const float *bias, float *out, int64_t M, int32_t N, int32_t K,

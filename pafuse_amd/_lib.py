@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PAFUSE_HIP_LIB", os.path.join(_HERE, "libpafuse_hip.so"))   # override: A/B diagnostics
+LIB_PATH = os.path.join(_HERE, "libpafuse_hip.so")   # the in-tree build; no environment variable selects another one
 
 MAX_DEPTH = 16
 MAX_PARTS = 4
@@ -54,6 +54,7 @@ class DDIMStep(C.Structure):
 SIGNATURES = {
     "pafuse_version": (C.c_char_p, []),
     "pafuse_last_error": (C.c_char_p, []),
+    "pafuse_set_grouped_launches": (C.c_int, [C.c_int32]),
     "pafuse_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "pafuse_split_weights_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
@@ -119,18 +120,23 @@ class PafuseError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library (once) and attach the prototypes.  Raises if it has not been built."""
+def load(path=None):
+    """Load the shared library (once) and attach the prototypes.  Raises if it has not been built.
+    `path` (development tools only, before anything else has loaded the library): another build of it, for A/B timing
+    of two builds inside one process image - an explicit argument, never the environment."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise PafuseError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        lib_path = path or LIB_PATH
+        if not os.path.exists(lib_path):
+            raise PafuseError(f"{lib_path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(lib_path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
         _lib = lib
+    elif path is not None and os.path.abspath(path) != os.path.abspath(getattr(_lib, "_name", "")):
+        raise PafuseError("the library is already loaded from " + str(getattr(_lib, "_name", "?")))
     return _lib
 
 

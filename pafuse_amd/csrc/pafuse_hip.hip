@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -80,11 +81,14 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     static_assert(stage_bytes <= 160 * 1024, "LDS budget");
     size_t lds = stage_bytes;
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, BF16>;
+#ifdef PAFUSE_DIAG
     static const int dbg_pad = [] { const char* e = getenv("PAFUSE_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
     if (dbg_pad && BF16 == 2 && EPI == EPI_BIAS) {  // diagnostic: keep other kernels off this workgroup's CU
         lds = std::max(lds, (size_t)dbg_pad);
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    } else if (lds > 64 * 1024) {
+    } else
+#endif
+    if (lds > 64 * 1024) {
         static DeviceOnce once;  // the attribute is per device (one-process multi-device callers: nn.DataParallel)
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
@@ -120,8 +124,10 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm_dma_kernel");
 }
 
-// diagnostic switch (environment PAFUSE_DEBUG_F32_MASK, read once): bit 0 = plain linear layers, bit 1 = whole-row
-// layers fall back to the fp32 matrix cores even in split-precision mode
+// diagnostic switch, compiled only into -DPAFUSE_DIAG builds (tools/): environment PAFUSE_DEBUG_F32_MASK, read once -
+// bit 0 = plain linear layers, bit 1 = whole-row layers fall back to the fp32 matrix cores even in split-precision mode.
+// The shipped library reads no environment variable: nothing outside its arguments changes which kernels it runs.
+#ifdef PAFUSE_DIAG
 int debug_f32_mask() {
     static const int mask = [] {
         const char* e = getenv("PAFUSE_DEBUG_F32_MASK");
@@ -129,6 +135,9 @@ int debug_f32_mask() {
     }();
     return mask;
 }
+#else
+constexpr int debug_f32_mask() { return 0; }
+#endif
 
 int gemm_bias(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
@@ -223,10 +232,10 @@ bool group_ok_rowln(const GemmParams& p) {
 bool group_ok_bias(const GemmParams& p) {
     return p.bf16 == 2 && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 && !(debug_f32_mask() & 29);
 }
-bool grouping_enabled() {
-    static const bool on = [] { const char* e = getenv("PAFUSE_NO_GROUPED"); return !(e && atoi(e)); }();
-    return on;
-}
+// process-wide schedule option (pafuse_set_grouped_launches): the same layer of the parts in shared grids (default) or
+// part by part - same tiles, same arithmetic, same bits either way
+std::atomic<int> g_grouped{1};
+bool grouping_enabled() { return g_grouped.load(std::memory_order_relaxed) != 0; }
 
 template <bool ROWLN>
 int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
@@ -554,6 +563,8 @@ extern "C" {
 
 const char* pafuse_version(void) { return "pafuse_hip 0.2 (gfx950, f32 MFMA + split-bf16x3 MFMA)"; }
 const char* pafuse_last_error(void) { return g_err; }
+
+int pafuse_set_grouped_launches(int32_t on) { return g_grouped.exchange(on ? 1 : 0); }
 
 int pafuse_linear(const float* A, const float* W, const float* bias, float* out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void* stream) {

@@ -277,35 +277,25 @@ def test_single_model_variant_training_is_refused_loudly():
         model(x2d.to(DEV), torch.zeros(1, 27, 134, 3, device=DEV))
 
 
-def test_grouped_launches_equal_part_by_part_launches(tmp_path):
-    """The default schedule puts proj / fc1 / fc2 of the three parts into shared grids (grouped_*_kernel).  A tile's
-    arithmetic must not depend on the grid it runs in: the same loop in a process started with PAFUSE_NO_GROUPED=1
-    (every layer launched part by part) gives the same bits."""
-    import os
-    import subprocess
-    import sys
+def test_grouped_launches_equal_part_by_part_launches():
+    """The default schedule puts the same layer of the three parts into shared grids (grouped_*_kernel).  A tile's
+    arithmetic must not depend on the grid it runs in: the same loop with every layer launched part by part
+    (pafuse_set_grouped_launches(0), the library's only process-wide option) gives the same bits."""
     from __graft_entry__ import make_model
-    from tests.conftest import ROOT
-    script = (
-        "import sys, torch\n"
-        "from __graft_entry__ import make_model\n"
-        "from pafuse_amd import synthetic as gu\n"
-        "model, _ = make_model(20, 2, seed=52)\n"
-        "x2d, x2f = gu.synthetic_inputs_2d(B=1)\n"
-        "noises = gu.synthetic_noises(B=1, P=20, n=2, seed=7)\n"
-        "model.noise_fn = lambda k, shape, device: noises[k]\n"
-        "torch.save(model(x2d.cuda(), None, input_2d_flip=x2f.cuda()).cpu(), sys.argv[1])\n")
-    out_file = str(tmp_path / "part_by_part.pt")
-    env = dict(os.environ, PAFUSE_NO_GROUPED="1", PYTHONPATH=ROOT)
-    res = subprocess.run([sys.executable, "-c", script, out_file], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
+    from pafuse_amd import _lib
+    lib = _lib.load()
     model, _ = make_model(20, 2, seed=52)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=20, n=2, seed=7)
     model.noise_fn = lambda k, shape, device: noises[k]
-    assert model.precision == "bf16x3" and "PAFUSE_NO_GROUPED" not in os.environ
+    assert model.precision == "bf16x3"
     grouped = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
-    assert torch.equal(grouped, torch.load(out_file))
+    assert lib.pafuse_set_grouped_launches(0) == 1
+    try:
+        part_by_part = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    finally:
+        assert lib.pafuse_set_grouped_launches(1) == 0
+    assert torch.equal(grouped, part_by_part)
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu():

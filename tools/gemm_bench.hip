@@ -102,6 +102,30 @@ float time_dma(const char* tag, GemmParams p, int reps = 20) {
     return us;
 }
 
+// ---- round 3: tall whole-row tiles, ONE 8-wave workgroup per CU, all parts in one grid (most expensive tiles first).
+// 384 -> 128 x 384 (4 x 2 waves), 256 -> 256 x 256, 224 -> 256 x 224 (8 x 1 waves): the W' stream per row is 2 - 4x
+// smaller than with the 64 / 128-row two-per-CU tiles of grouped_rowln_kernel.
+template <int EPI, int NST, int HANDS_BM>
+__global__ void __launch_bounds__(512, 2) grouped_tall_kernel(const GroupedGemmParams g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < GROUP_MAX; ++i)
+        if (i < g.n && b >= g.first[i]) s = i;
+    const GemmParams& p = g.p[s];
+    const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
+    switch (p.N) {
+        case 384: gemm_dma_tile<4, 2, 6, EPI, NST, 0, 16>(p, lb, nb, smem); break;
+        case 256:
+            if constexpr (HANDS_BM == 256) gemm_dma_tile<8, 1, 8, EPI, NST, 0, 16>(p, lb, nb, smem);
+            else gemm_dma_tile<4, 2, 4, EPI, NST, 0, 16>(p, lb, nb, smem);
+            break;
+        case 224: gemm_dma_tile<8, 1, 7, EPI, NST, 0, 16>(p, lb, nb, smem); break;
+        default: break;
+    }
+}
+
 int main() {
     const int64_t Mmax = 73440;
     float *A, *W, *bias, *out, *x, *xn, *vec, *xo;
@@ -239,6 +263,31 @@ int main() {
     time_dma<2, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <2,2,4> st3", q);
     time_dma<4, 2, 4, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <4,2,4> st3", q);
     time_dma<2, 4, 2, EPI_ROWLN, 3, 2, 0, 16>("hands proj rowln dma16 <2,4,2> st3", q);
+    // ---- round 3: what one tall tile costs (1 round: every CU runs at most one tile, the launch time IS a tile's time)
+    q.M = 25920, q.N = 384, q.K = 768;
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("tallabl body fc2 <4,2,6> st3 full", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 1, 16>("tallabl body fc2 <4,2,6> st3 ABL1 stream+epilogue", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 2, 16>("tallabl body fc2 <4,2,6> st3 ABL2 compute+epilogue", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 4, 16>("tallabl body fc2 <4,2,6> st3 ABL4 lds+mfma only", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("tallabl body fc2 <4,2,6> st2 full", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("tallabl body fc2 <2,2,6> st2 (2/CU) full", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 1, 16>("tallabl body fc2 <2,2,6> st2 (2/CU) ABL1 stream+epilogue", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 4, 16>("tallabl body fc2 <2,2,6> st2 (2/CU) ABL4 lds+mfma only", q);
+    q.K = 384;
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 0, 16>("tallabl body proj <4,2,6> st3 full", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 1, 16>("tallabl body proj <4,2,6> st3 ABL1 stream+epilogue", q);
+    time_dma<4, 2, 6, EPI_ROWLN, 3, 2, 4, 16>("tallabl body proj <4,2,6> st3 ABL4 lds+mfma only", q);
+    time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("tallabl body proj <2,2,6> st2 (2/CU) full", q);
+    q.M = 45360, q.N = 256, q.K = 512;
+    time_dma<8, 1, 8, EPI_ROWLN, 3, 2, 0, 16>("tallabl hands fc2 <8,1,8> st3 full", q);
+    time_dma<8, 1, 8, EPI_ROWLN, 3, 2, 1, 16>("tallabl hands fc2 <8,1,8> st3 ABL1 stream+epilogue", q);
+    time_dma<8, 1, 8, EPI_ROWLN, 3, 2, 4, 16>("tallabl hands fc2 <8,1,8> st3 ABL4 lds+mfma only", q);
+    time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("tallabl hands fc2 <2,2,4> st2 (2/CU) full", q);
+    q.M = 73440, q.N = 224, q.K = 448;
+    time_dma<8, 1, 7, EPI_ROWLN, 3, 2, 0, 16>("tallabl face fc2 <8,1,7> st3 full", q);
+    time_dma<8, 1, 7, EPI_ROWLN, 3, 2, 1, 16>("tallabl face fc2 <8,1,7> st3 ABL1 stream+epilogue", q);
+    time_dma<8, 1, 7, EPI_ROWLN, 3, 2, 4, 16>("tallabl face fc2 <8,1,7> st3 ABL4 lds+mfma only", q);
+    time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("tallabl face fc2 <4,1,7> st2 (2/CU) full", q);
     // ---- grouped whole-row launch (body + face + hands in one grid) against the per-part launches
     if (!getenv("GB_FILTER") || strstr("grouped", getenv("GB_FILTER"))) {
         struct Part { int64_t M; int N, K; uint8_t* ws; float *xo, *xn; };
@@ -308,6 +357,30 @@ int main() {
             timeit("three launches, round-2 production kernels", production);
             timeit("three launches, 4-wave st2 variants (2/CU)", separate);
             timeit("one grouped launch", grouped);
+            {   // tall tiles, one 8-wave workgroup per CU
+                auto tall = [&](auto kt, const char* tag, int hands_bm, size_t lds) {
+                    CK(hipFuncSetAttribute((const void*)kt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    const int u0 = (25920 + 127) / 128, u1 = (73440 + 255) / 256, u2 = (45360 + hands_bm - 1) / hands_bm;
+                    GroupedGemmParams gt{};
+                    // most expensive tiles first: body 128 x 384, hands, face
+                    gt.p[0] = gp[0], gt.p[1] = gp[2], gt.p[2] = gp[1], gt.n = 3;
+                    gt.first[0] = 0, gt.first[1] = pad8(u0), gt.first[2] = gt.first[1] + pad8(u2), gt.first[3] = gt.first[2] + pad8(u1);
+                    gt.first[4] = gt.first[3];
+                    for (int i = 0; i < 3; ++i) CK(hipMemset(pt[i].xn, 0, ref[i].size() * 4));
+                    hipLaunchKernelGGL(kt, dim3(gt.first[3]), dim3(512), lds, 0, gt); CK(hipDeviceSynchronize());
+                    for (int i = 0; i < 3; ++i) {
+                        got.resize(ref[i].size()); CK(hipMemcpy(got.data(), pt[i].xn, got.size() * 4, hipMemcpyDeviceToHost));
+                        double md = 0; for (size_t q = 0; q < got.size(); ++q) { double d = fabs((double)got[q] - ref[i][q]); if (d > md) md = d; }
+                        printf("tall %s part %d: max |d vs two-per-CU tiles| %.3e %s\n", tag, i, md, memcmp(got.data(), ref[i].data(), got.size() * 4) ? "" : "(bit-identical)");
+                    }
+                    timeit(tag, [&]() { hipLaunchKernelGGL(kt, dim3(gt.first[3]), dim3(512), lds, 0, gt); });
+                };
+                constexpr size_t st = DmaTile<4, 2, 6, 16>::STAGE_BYTES;
+                static_assert(st >= DmaTile<8, 1, 8, 16>::STAGE_BYTES && st >= DmaTile<8, 1, 7, 16>::STAGE_BYTES, "stage");
+                tall(grouped_tall_kernel<EPI_ROWLN, 3, 256>, "tall st3 (body 128, hands 256, face 256 rows)", 256, 3 * st);
+                tall(grouped_tall_kernel<EPI_ROWLN, 2, 256>, "tall st2 (body 128, hands 256, face 256 rows)", 256, 2 * st);
+                tall(grouped_tall_kernel<EPI_ROWLN, 3, 128>, "tall st3 (body 128, hands 128, face 256 rows)", 128, 3 * st);
+            }
             for (int i = 0; i < 3; ++i) { CK(hipFree(pt[i].ws)); CK(hipFree(pt[i].xo)); CK(hipFree(pt[i].xn)); }
         }
     }
