@@ -6,7 +6,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
-#include "../pafuse_amd/csrc/kernels.hpp"
+#include "kernels_r3_experiments.hpp"
 using namespace pafuse;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -126,6 +126,131 @@ __global__ void __launch_bounds__(512, 2) grouped_tall_kernel(const GroupedGemmP
     }
 }
 
+// both operands pre-split (round 3): A' made here from p.A (split_rows_kernel<16>, padded rows), W' 16-deep
+static uint8_t* g_aimg = nullptr;   // activation image, [768/16][Mpad][96]
+static uint8_t* g_oimg = nullptr;   // output image (timing of the split-store epilogue)
+template <int WM, int WN, int MT, int NT, int EPI, int NSTAGE, int MINW>
+float time_pre(const char* tag, GemmParams p, bool split_out = false, int reps = 20) {
+    using T = PreTile<WM, WN, MT, NT>;
+    if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
+    if (const char* r = getenv("GB_REPS")) reps = atoi(r);
+    const size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    const int64_t Mpad = (p.M + PRE_ROW_PAD - 1) / PRE_ROW_PAD * PRE_ROW_PAD;
+    p.bf16 = 2;
+    hipLaunchKernelGGL(split_weights_kernel<16>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
+                       (uint8_t*)p.Wsplit, p.N, p.K);
+    hipLaunchKernelGGL(split_rows_kernel<16>, dim3((unsigned)((p.M * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.A, g_aimg, p.M, p.K, Mpad);
+    p.Asplit = g_aimg, p.A_pad = Mpad;
+    if (split_out) { p.out_pad = Mpad; if (EPI == EPI_BIAS) p.out_s = g_oimg; else p.out_n_s = g_oimg; }
+    auto k = gemm_pre_kernel<WM, WN, MT, NT, EPI, NSTAGE, MINW>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    double maxd = -1.0, meand = 0.0;
+    const float* res = EPI == EPI_BIAS ? p.out : p.out_n;
+    if (res && g_ref && !split_out) {
+        const size_t n = (size_t)p.M * p.N;
+        CK(hipMemcpy(g_out_host, res, n * 4, hipMemcpyDeviceToHost));
+        maxd = 0.0;
+        for (size_t i = 0; i < n; ++i) { double d = fabs((double)g_out_host[i] - g_ref[i]); meand += d; if (d > maxd) maxd = d; }
+        meand /= n;
+    }
+    printf("%-40s M=%6ld N=%4d K=%3d tiles=%5ld lds=%6zu : %8.1f us  %6.1f TF/s (%.3f of 416.7)", tag, (long)p.M, p.N, p.K,
+           (long)tiles, lds, us, tf, tf / 416.7);
+    if (maxd >= 0) printf("  |d vs f32| max %.2e mean %.2e", maxd, meand);
+    printf("\n");
+    fflush(stdout);
+    return us;
+}
+
+// wave-specialised tile (round 3): 4 producer waves + WM x WN consumer waves, A fp32, W' 16-deep
+template <int WM, int WN, int NT, int EPI>
+float time_ws(const char* tag, GemmParams p, int reps = 20) {
+    using T = WsTile<WM, WN, NT>;
+    if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
+    if (const char* r = getenv("GB_REPS")) reps = atoi(r);
+    const size_t lds = (size_t)T::NSTAGE * T::STAGE_BYTES;
+    p.bf16 = 2;
+    hipLaunchKernelGGL(split_weights_kernel<16>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
+                       (uint8_t*)p.Wsplit, p.N, p.K);
+    auto k = gemm_ws_kernel<WM, WN, NT, EPI>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    double maxd = -1.0, meand = 0.0;
+    const float* res = EPI == EPI_BIAS ? p.out : p.out_n;
+    if (res && g_ref) {
+        const size_t n = (size_t)p.M * p.N;
+        CK(hipMemcpy(g_out_host, res, n * 4, hipMemcpyDeviceToHost));
+        maxd = 0.0;
+        for (size_t i = 0; i < n; ++i) { double d = fabs((double)g_out_host[i] - g_ref[i]); meand += d; if (d > maxd) maxd = d; }
+        meand /= n;
+    }
+    printf("%-44s M=%6ld N=%4d K=%3d tiles=%5ld lds=%6zu : %8.1f us  %6.1f TF/s (%.3f of 416.7)", tag, (long)p.M, p.N, p.K,
+           (long)tiles, lds, us, tf, tf / 416.7);
+    if (maxd >= 0) printf("  |d vs f32| max %.2e mean %.2e", maxd, meand);
+    printf("\n");
+    fflush(stdout);
+    return us;
+}
+
+// plain split layer on the 16x16x32 MFMA shape (round 3)
+template <int NB, int MINW>
+float time_16(const char* tag, GemmParams p, int reps = 20) {
+    using T = Tile16<NB>;
+    if (const char* f = getenv("GB_FILTER")) { if (!strstr(tag, f)) return 0.f; }
+    if (const char* r = getenv("GB_REPS")) reps = atoi(r);
+    const size_t lds = T::STAGE_BYTES;
+    p.bf16 = 2;
+    hipLaunchKernelGGL(split_weights_kernel<32>, dim3((unsigned)(((int64_t)p.N * (p.K / 8) + 255) / 256)), dim3(256), 0, 0, p.W,
+                       (uint8_t*)p.Wsplit, p.N, p.K);
+    auto k = gemm16_kernel<NB, MINW>;
+    if (lds > 64 * 1024) CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    double maxd = -1.0, meand = 0.0;
+    if (p.out && g_ref) {
+        const size_t n = (size_t)p.M * p.N;
+        CK(hipMemcpy(g_out_host, p.out, n * 4, hipMemcpyDeviceToHost));
+        maxd = 0.0;
+        for (size_t i = 0; i < n; ++i) { double d = fabs((double)g_out_host[i] - g_ref[i]); meand += d; if (d > maxd) maxd = d; }
+        meand /= n;
+    }
+    printf("%-44s M=%6ld N=%4d K=%3d tiles=%5ld lds=%6zu : %8.1f us  %6.1f TF/s (%.3f of 416.7)", tag, (long)p.M, p.N, p.K,
+           (long)tiles, lds, us, tf, tf / 416.7);
+    if (maxd >= 0) printf("  |d vs f32| max %.2e mean %.2e", maxd, meand);
+    printf("\n");
+    fflush(stdout);
+    return us;
+}
+
 int main() {
     const int64_t Mmax = 73440;
     float *A, *W, *bias, *out, *x, *xn, *vec, *xo;
@@ -135,6 +260,7 @@ int main() {
     CK(hipMalloc(&out, Mmax * 1152 * 4)); CK(hipMalloc(&x, Mmax * 384 * 4)); CK(hipMalloc(&xn, Mmax * 384 * 4));
     CK(hipMalloc(&vec, 1152 * 4));
     CK(hipMalloc(&xo, Mmax * 384 * 4));
+    CK(hipMalloc(&g_aimg, (size_t)(Mmax + 256) * 768 * 6)); CK(hipMalloc(&g_oimg, (size_t)(Mmax + 256) * 1152 * 6));
     std::vector<float> h(Mmax * 768);
     for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
     CK(hipMemcpy(A, h.data(), Mmax * 768 * 4, hipMemcpyHostToDevice));
@@ -146,6 +272,148 @@ int main() {
     p.A = A, p.W = W, p.bias = bias, p.out = out, p.Wsplit = Wsp;
     p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
     { const char* f = getenv("GB_FILTER"); if (!f) time_gemm<4, 1, 4, EPI_BIAS, 2>("(warm-up, ignore)", p, 200); }
+    // ---- round 3: plain layers on the 16x16x32 shape (tag "m16"); each shape's f32 line first (reference result)
+    for (int rep = 0; rep < 2; ++rep) {   // twice: the second pass shows the run-to-run spread inside one process
+    p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("m16-ref body qkv  f32   <4,1,2> s1 minw5", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("m16-ref body qkv  split <4,1,4> s1 minw2 (r2 production)", p);
+    time_16<8, 2>("m16 body qkv  128x128 minw2", p);
+    time_16<8, 3>("m16 body qkv  128x128 minw3", p);
+    time_16<4, 4>("m16 body qkv  128x64 minw4", p);
+    time_16<6, 3>("m16 body qkv  128x96 minw3", p);
+    p.N = 768, p.act = 1;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("m16-ref body fc1+gelu f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("m16-ref body fc1+gelu split <4,1,4> s1 (r2 production)", p);
+    time_16<8, 2>("m16 body fc1+gelu 128x128 minw2", p);
+    time_16<8, 3>("m16 body fc1+gelu 128x128 minw3", p);
+    time_16<4, 4>("m16 body fc1+gelu 128x64 minw4", p);
+    p.M = 73440, p.N = 672, p.K = 224, p.act = 0;
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>("m16-ref face qkv  f32   <4,1,3> s1 TR", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>("m16-ref face qkv  split <4,1,3> s1 TR (r2 production)", p);
+    time_16<6, 3>("m16 face qkv  128x96 minw3", p);
+    time_16<6, 4>("m16 face qkv  128x96 minw4", p);
+    time_16<14, 2>("m16 face qkv  128x224 minw2", p);
+    p.N = 448, p.act = 1;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("m16-ref face fc1+gelu f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("m16-ref face fc1+gelu split <4,1,2> s1 (r2 production)", p);
+    time_16<4, 4>("m16 face fc1+gelu 128x64 minw4", p);
+    time_16<14, 2>("m16 face fc1+gelu 128x224 minw2", p);
+    p.M = 45360, p.N = 768, p.K = 256, p.act = 0;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("m16-ref hands qkv f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("m16-ref hands qkv split <4,1,2> s1 (r2 production)", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("m16-ref hands qkv split <4,1,4> s1 minw2", p);
+    time_16<8, 2>("m16 hands qkv 128x128 minw2", p);
+    time_16<8, 3>("m16 hands qkv 128x128 minw3", p);
+    time_16<4, 4>("m16 hands qkv 128x64 minw4", p);
+    }
+    // ---- round 3: wave-specialised tiles (tag "ws"); each shape's f32 line first (reference result)
+    p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("ws-ref body qkv  f32   <4,1,2> s1 minw5", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("ws-ref body qkv  split <4,1,4> s1 minw2 (r2 production)", p);
+    time_ws<4, 2, 6, EPI_BIAS>("ws body qkv  <4,2,6> 128x384", p);
+    time_ws<4, 2, 4, EPI_BIAS>("ws body qkv  <4,2,4> 128x256 (N % 256 != 0: timing only)", p);
+    time_ws<8, 1, 4, EPI_BIAS>("ws body qkv  <8,1,4> 256x128", p);
+    p.N = 768, p.act = 1;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("ws-ref body fc1+gelu f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("ws-ref body fc1+gelu split <4,1,4> s1 (r2 production)", p);
+    time_ws<4, 2, 6, EPI_BIAS>("ws body fc1+gelu <4,2,6> 128x384", p);
+    time_ws<4, 2, 4, EPI_BIAS>("ws body fc1+gelu <4,2,4> 128x256", p);
+    p.M = 73440, p.N = 672, p.K = 224, p.act = 0;
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>("ws-ref face qkv  f32   <4,1,3> s1 TR", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>("ws-ref face qkv  split <4,1,3> s1 TR (r2 production)", p);
+    time_ws<8, 1, 7, EPI_BIAS>("ws face qkv  <8,1,7> 256x224", p);
+    time_ws<4, 2, 3, EPI_BIAS>("ws face qkv  <4,2,3> 128x192 (N % 192 != 0: timing only)", p);
+    p.N = 448, p.act = 1;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("ws-ref face fc1+gelu f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("ws-ref face fc1+gelu split <4,1,2> s1 (r2 production)", p);
+    time_ws<8, 1, 7, EPI_BIAS>("ws face fc1+gelu <8,1,7> 256x224", p);
+    p.M = 45360, p.N = 768, p.K = 256, p.act = 0;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("ws-ref hands qkv f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("ws-ref hands qkv split <4,1,2> s1 (r2 production)", p);
+    time_ws<4, 2, 4, EPI_BIAS>("ws hands qkv <4,2,4> 128x256", p);
+    time_ws<4, 2, 6, EPI_BIAS>("ws hands qkv <4,2,6> 128x384", p);
+    {
+        GemmParams q{};
+        q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = xo, q.out_n = xn, q.Wsplit = Wsp;
+        q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
+        q.M = 45360, q.N = 256, q.K = 512;
+        time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1>("ws-ref hands fc2 rowln f32   <2,2,4> minw2", q);
+        time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("ws-ref hands fc2 rowln dma16 <2,2,4> st2 (r2 production)", q);
+        time_ws<4, 2, 4, EPI_ROWLN>("ws hands fc2 rowln <4,2,4> 128x256", q);
+        q.K = 256;
+        time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1>("ws-ref hands proj rowln f32   <2,2,4> minw2", q);
+        time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("ws-ref hands proj rowln dma16 <2,2,4> st2 (r2 production)", q);
+        time_ws<4, 2, 4, EPI_ROWLN>("ws hands proj rowln <4,2,4> 128x256", q);
+        q.M = 73440, q.N = 224, q.K = 448;
+        time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("ws-ref face fc2  rowln f32   <1,7,1>", q);
+        time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("ws-ref face fc2 rowln dma16 <4,1,7> st2 (r2 production)", q);
+        time_ws<8, 1, 7, EPI_ROWLN>("ws face fc2 rowln <8,1,7> 256x224", q);
+        q.M = 25920, q.N = 384, q.K = 768;
+        time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("ws-ref body fc2  rowln f32   <1,4,3>", q);
+        time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("ws-ref body fc2 rowln dma16 <2,2,6> st2 (r2 production)", q);
+        time_ws<4, 2, 6, EPI_ROWLN>("ws body fc2 rowln <4,2,6> 128x384", q);
+        q.K = 384;
+        time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("ws-ref body proj rowln f32   <1,4,3>", q);
+        time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("ws-ref body proj rowln dma16 <2,2,6> st2 (r2 production)", q);
+        time_ws<4, 2, 6, EPI_ROWLN>("ws body proj rowln <4,2,6> 128x384", q);
+    }
+    // ---- round 3: both operands pre-split (tag "pre"); each shape's f32 line first (reference result)
+    p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("pre-ref body qkv  f32   <4,1,2> s1 minw5", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("pre-ref body qkv  split <4,1,4> s1 minw2 (r2 production)", p);
+    time_pre<4, 1, 2, 4, EPI_BIAS, 2, 2>("pre body qkv  <4,1,2,4> 256x128 st2", p);
+    time_pre<4, 1, 2, 4, EPI_BIAS, 3, 2>("pre body qkv  <4,1,2,4> 256x128 st3", p);
+    time_pre<2, 2, 2, 4, EPI_BIAS, 2, 2>("pre body qkv  <2,2,2,4> 128x256 st2 (N%256!=0: skip)", p);
+    time_pre<4, 1, 1, 4, EPI_BIAS, 2, 2>("pre body qkv  <4,1,1,4> 128x128 st2", p);
+    time_pre<4, 1, 1, 4, EPI_BIAS, 2, 3>("pre body qkv  <4,1,1,4> 128x128 st2 minw3", p);
+    time_pre<2, 1, 2, 4, EPI_BIAS, 2, 2>("pre body qkv  <2,1,2,4> 128x128 2 waves st2", p);
+    p.N = 768, p.act = 1;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("pre-ref body fc1+gelu f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("pre-ref body fc1+gelu split <4,1,4> s1 (r2 production)", p);
+    time_pre<4, 1, 2, 4, EPI_BIAS, 2, 2>("pre body fc1+gelu <4,1,2,4> 256x128 st2 f32 out", p);
+    time_pre<4, 1, 2, 4, EPI_BIAS, 2, 2>("pre body fc1+gelu <4,1,2,4> 256x128 st2 split out", p, true);
+    time_pre<2, 2, 2, 4, EPI_BIAS, 2, 2>("pre body fc1+gelu <2,2,2,4> 128x256 st2 split out", p, true);
+    time_pre<4, 1, 1, 4, EPI_BIAS, 2, 3>("pre body fc1+gelu <4,1,1,4> 128x128 st2 minw3 split out", p, true);
+    p.M = 73440, p.N = 672, p.K = 224, p.act = 0;
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1>("pre-ref face qkv  f32   <4,1,3> s1 TR", p);
+    time_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>("pre-ref face qkv  split <4,1,3> s1 TR (r2 production)", p);
+    time_pre<4, 1, 2, 3, EPI_BIAS, 2, 2>("pre face qkv  <4,1,2,3> 256x96 st2", p);
+    time_pre<4, 1, 1, 7, EPI_BIAS, 2, 2>("pre face qkv  <4,1,1,7> 128x224 st2", p);
+    time_pre<2, 1, 2, 7, EPI_BIAS, 2, 1>("pre face qkv  <2,1,2,7> 128x224 2 waves st2", p);
+    p.N = 448, p.act = 1;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("pre-ref face fc1+gelu f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("pre-ref face fc1+gelu split <4,1,2> s1 (r2 production)", p);
+    time_pre<4, 1, 2, 2, EPI_BIAS, 2, 2>("pre face fc1+gelu <4,1,2,2> 256x64 st2 split out", p, true);
+    time_pre<4, 1, 1, 7, EPI_BIAS, 2, 2>("pre face fc1+gelu <4,1,1,7> 128x224 st2 split out", p, true);
+    time_pre<4, 1, 1, 7, EPI_BIAS, 2, 2>("pre face fc1+gelu <4,1,1,7> 128x224 st2 f32 out", p);
+    p.M = 45360, p.N = 768, p.K = 256, p.act = 0;
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("pre-ref hands qkv f32   <4,1,2> s1", p);
+    time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("pre-ref hands qkv split <4,1,2> s1 (r2 production)", p);
+    time_pre<4, 1, 2, 4, EPI_BIAS, 2, 2>("pre hands qkv <4,1,2,4> 256x128 st2", p);
+    time_pre<2, 2, 2, 4, EPI_BIAS, 2, 2>("pre hands qkv <2,2,2,4> 128x256 st2", p);
+    {
+        GemmParams q{};
+        q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = xo, q.out_n = xn, q.Wsplit = Wsp;
+        q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
+        q.M = 45360, q.N = 256, q.K = 512;
+        time_gemm<2, 2, 4, EPI_ROWLN, 1, 2, 1>("pre-ref hands fc2 rowln f32   <2,2,4> minw2", q);
+        time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("pre-ref hands fc2 rowln dma16 <2,2,4> st2 (r2 production)", q);
+        time_pre<2, 2, 2, 4, EPI_ROWLN, 2, 2>("pre hands fc2 rowln <2,2,2,4> 128x256 st2", q);
+        time_pre<2, 2, 2, 4, EPI_ROWLN, 2, 2>("pre hands fc2 rowln <2,2,2,4> 128x256 st2 split out", q, true);
+        time_pre<2, 2, 1, 4, EPI_ROWLN, 2, 2>("pre hands fc2 rowln <2,2,1,4> 64x256 st2", q);
+        time_pre<2, 2, 1, 4, EPI_ROWLN, 2, 3>("pre hands fc2 rowln <2,2,1,4> 64x256 st2 minw3", q);
+        q.M = 73440, q.N = 224, q.K = 448;
+        time_gemm<1, 7, 1, EPI_ROWLN, 1, 1, 1>("pre-ref face fc2  rowln f32   <1,7,1>", q);
+        time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("pre-ref face fc2 rowln dma16 <4,1,7> st2 (r2 production)", q);
+        time_pre<4, 1, 1, 7, EPI_ROWLN, 2, 2>("pre face fc2 rowln <4,1,1,7> 128x224 st2", q);
+        time_pre<4, 1, 1, 7, EPI_ROWLN, 2, 2>("pre face fc2 rowln <4,1,1,7> 128x224 st2 split out", q, true);
+        time_pre<2, 1, 1, 7, EPI_ROWLN, 2, 2>("pre face fc2 rowln <2,1,1,7> 64x224 st2", q);
+        q.M = 25920, q.N = 384, q.K = 768;
+        time_gemm<1, 4, 3, EPI_ROWLN, 1, 1, 1>("pre-ref body fc2  rowln f32   <1,4,3>", q);
+        time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("pre-ref body fc2 rowln dma16 <2,2,6> st2 (r2 production)", q);
+        time_pre<4, 2, 1, 6, EPI_ROWLN, 3, 2>("pre body fc2 rowln <4,2,1,6> 128x384 8 waves st3", q);
+        time_pre<4, 2, 1, 6, EPI_ROWLN, 2, 2>("pre body fc2 rowln <4,2,1,6> 128x384 8 waves st2", q);
+    }
     // ---- f32 production tile (reference result) / best register-staged split tile / LDS-DMA pipelined split kernel
     p.M = 25920, p.N = 1152, p.K = 384, p.act = 0;
     time_gemm<4, 1, 2, EPI_BIAS, 1, 5>("body qkv  f32   <4,1,2> s1 minw5", p);
