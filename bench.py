@@ -227,19 +227,19 @@ def main():
         # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
         # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
         traffic, traffic_info = None, {"traffic_source": None}
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10):
             tj = json.load(open(tpath))
             if tj.get("dtype", "bf16x3") != args.dtype:
-                traffic_info = {"traffic_source": f"profiles/r02_pmc_traffic.json was collected in {tj.get('dtype', 'bf16x3')} mode: not quoted"}
+                traffic_info = {"traffic_source": f"profiles/r03_pmc_traffic.json was collected in {tj.get('dtype', 'bf16x3')} mode: not quoted"}
             elif tj.get("kernel_source_sha256") == _lib.kernel_source_digest():
                 traffic = round(tj["traffic_bytes_per_launch"])
-                traffic_info = {"traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                traffic_info = {"traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                                   "FETCH doubled per the gfx950 correction)",
                                 "hbm_GBps_dominant_kernel": round(traffic / (ms * 1e-3 / n) / 1e9, 1),
                                 "hbm_GBps_by_kernel_family": tj.get("hbm_GBps_by_kernel_family")}
             else:
-                traffic_info = {"traffic_source": "profiles/r02_pmc_traffic.json is from other kernel sources "
+                traffic_info = {"traffic_source": "profiles/r03_pmc_traffic.json is from other kernel sources "
                                                   "(kernel_source_sha256 differs): not quoted"}
         # algorithmic bytes per launch, two ways: (i) this design's launch boundaries (every GEMM reads A and W and
         # writes its outputs; whole-row kernels also read the residual and write x and xn); (ii) SURVEY 8(d)'s fused
@@ -256,10 +256,19 @@ def main():
                      "bf16x3": "dense bf16 matrix peak 2500 / 6 products; the same FLOPs against the f32-input matrix "
                                f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
+        products = 6 if args.dtype == "bf16x3" else 1          # matrix instructions executed per useful product
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: gemm_kernel, grouped_bias_kernel, grouped_rowln_kernel ({mfma})",
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(achieved / peak, 4), "peak_note": peak_note,
-                            "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                            "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                            # the same launches seen three ways: `frac` above prices the useful FLOPs against the
+                            # ceiling of the arithmetic scheme; these two price them / the executed matrix work against the
+                            # dense peak of the instruction that runs
+                            "frac_of_bf16_dense_peak": None if args.dtype == "f32" else round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+                            "mfma_pipe_frac": round(achieved * products / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
+                            "mfma_pipe_note": "executed matrix FLOPs (useful x 6 products in bf16x3) / dense peak of the instruction; "
+                                              "SQ_VALU_MFMA_BUSY_CYCLES of the same launches: profiles/r03_pmc_mfma_util.json",
+                            "traffic": traffic,
                             "traffic_unit": "HBM bytes per launch",
                             "algorithmic_bytes_per_launch": {"this_design_unfused_between_gemms": round(alg_unfused),
                                                              "survey_8d_fused_blocks": round(alg_fused)},

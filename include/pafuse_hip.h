@@ -152,10 +152,11 @@ int pafuse_layernorm(const float *x, const float *w, const float *b, float *out,
 int pafuse_attention(const float *qkv, float *o, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group,
                      int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void *stream);
 
-/* x[S*L,C] <- Block(x) in place for S contiguous sequences of L tokens (Block.forward, eps 1e-6). */
+/* x[S*L,C] <- Block(x) in place for S contiguous sequences of L tokens (Block.forward, eps 1e-6).  operand_bf16: the
+ * matrix-product mode of the four linear layers (as pafuse_mixste2_weights.operand_bf16; 2 needs the *_ws images). */
 size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C);
 int pafuse_block_forward(const pafuse_block_weights *w, float *x, int64_t S, int32_t L, int32_t C, int32_t heads,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         int32_t operand_bf16, void *workspace, size_t workspace_bytes, void *stream);
 
 /* temb[B,C] = time_mlp(t[B]);  hid_scratch: [B,2C] floats of device scratch */
 int pafuse_time_embed(const pafuse_mixste2_weights *w, const int64_t *t, int32_t B, float *temb, float *hid_scratch,

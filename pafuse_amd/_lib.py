@@ -67,7 +67,7 @@ SIGNATURES = {
                                    C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "pafuse_block_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "pafuse_block_forward": (C.c_int, [C.POINTER(BlockWeights), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
-                                       C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                       C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pafuse_time_embed": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "pafuse_mixste2_workspace_bytes": (C.c_size_t, [C.POINTER(MixSTE2Weights), C.c_int32, C.c_int32]),

@@ -561,7 +561,7 @@ __global__ void copy_kernel(const float* src, float* dst, int64_t n) {
 // ================================================================================================== C ABI
 extern "C" {
 
-const char* pafuse_version(void) { return "pafuse_hip 0.2 (gfx950, f32 MFMA + split-bf16x3 MFMA)"; }
+const char* pafuse_version(void) { return "pafuse_hip 0.3 (gfx950, f32 MFMA + split-bf16x3 MFMA)"; }
 const char* pafuse_last_error(void) { return g_err; }
 
 int pafuse_set_grouped_launches(int32_t on) { return g_grouped.exchange(on ? 1 : 0); }
@@ -626,9 +626,12 @@ int pafuse_attention(const float* qkv, float* o, int64_t nseq, int32_t L, int32_
 size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C) { return part_buffer_bytes(rows, C, 1); }
 
 int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int32_t L, int32_t C, int32_t heads,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         int32_t operand_bf16, void* workspace, size_t workspace_bytes, void* stream) {
     StreamDevice on_stream_device(stream);
     if (!w || !x || !workspace || S < 0) return fail(PAFUSE_E_ARG, "block_forward: bad argument");
+    if (operand_bf16 < 0 || operand_bf16 > 2) return fail(PAFUSE_E_ARG, "block_forward: matrix-product mode %d", operand_bf16);
+    if (operand_bf16 == 2 && (!w->qkv_ws || !w->proj_ws || !w->fc1_ws || !w->fc2_ws))
+        return fail(PAFUSE_E_ARG, "block_forward: split-precision mode needs the pre-split image of every linear weight");
     if (!width_supported(C)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", C);
     if (heads <= 0 || C % heads) return fail(PAFUSE_E_SHAPE, "block_forward: heads %d must divide C %d", heads, C);
     if (L <= 0) return fail(PAFUSE_E_SHAPE, "block_forward: sequence length %d", L);
@@ -642,7 +645,7 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
     int rc = pafuse_layernorm(x, w->norm1_w, w->norm1_b, pb.xn, M, C, 1e-6f, stream);
     if (rc) return rc;
     BlockTail t{};  // plain Block.forward: no post norm, nothing after
-    return run_block(*w, pb, M, C, heads, S, L, 1, L, 0, 1, t, s);
+    return run_block(*w, pb, M, C, heads, S, L, 1, L, 0, 1, t, s, false, nullptr, nullptr, operand_bf16);
 }
 
 int pafuse_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int32_t B, float* temb, float* hid_scratch,

@@ -273,8 +273,16 @@ class D3DP(nn.Module):
         if self.use_graph:
             # the C ABI neither allocates nor synchronises, so the whole T-step loop (~2 500 launches, fork/join
             # events included) is captured once per (shape, weights) and replayed on static buffers
-            key = (B, P, len(steps), bool(flip), dev, tuple(cfg.part[i].patch_w for i in range(cfg.num_parts)),
-                   tuple((cfg.part[i].operand_bf16, cfg.part[i].ste[0].qkv_ws) for i in range(cfg.num_parts)))
+            # a captured graph holds raw pointers to the parameters AND to every split image: key on the parameter
+            # storage and on the image generation of every denoiser (bumped whenever a weight version changes), and drop
+            # the graphs of dead generations - their images are freed and their static buffers would only pile up
+            shape_key = (B, P, len(steps), bool(flip), dev)
+            weights_key = (tuple(cfg.part[i].patch_w for i in range(cfg.num_parts)),
+                           tuple((cfg.part[i].operand_bf16, m.split_generation.get(dev.index, 0))
+                                 for i, m in enumerate(self.denoisers().values())))
+            key = shape_key + weights_key
+            for k in [k for k in self._graphs if k[:5] == shape_key and k != key]:
+                del self._graphs[k]
             g = self._graphs.get(key)
             if g is None:
                 st = {"x2d": x2d.clone(), "x2f": x2f.clone(), "noise": noise.clone(),

@@ -100,12 +100,12 @@ class MixSTE2(nn.Module):
         self.register_buffer("_freqs", sinusoid_frequencies(C_), persistent=False)
         if not self.qkv_bias:        # nn.Linear(bias=False): no key in the state dict; the kernels add these zeros
             self.register_buffer("_zero_qkv_bias", torch.zeros(3 * C_), persistent=False)
-        self._wcache = None
+        self._wcache_by_device = {}    # device index -> (key, struct, split images, event, stream): shared with DataParallel replicas
+        self.split_generation = {}     # device index -> how many times the split images were (re)made (graph caches key on it)
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
         self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA,
         #                                2 split precision "bf16x3" (fp32-equivalent, inference), 1 opt-in bf16 operands
-        self._split_cache = None       # (key, {weight name: uint8 image}) of the pre-split weights for mode 2
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -122,34 +122,38 @@ class MixSTE2(nn.Module):
         key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode)
         if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
-        if self._wcache is not None and self._wcache[0] == key:
-            return self._wcache[1]
+        dev = self._freqs.device
+        # per device, in a dict the replicas of nn.DataParallel share with their parent (replicate() copies attributes
+        # shallowly and makes fresh module objects on every forward: a per-object cache would never hit there, and every
+        # replica would re-split all its weights on every call)
+        hit = self._wcache_by_device.get(dev.index)
+        if hit is not None and hit[0] == key:
+            if mode == 2 and hit[3] is not None and torch.cuda.current_stream(dev) != hit[4]:
+                torch.cuda.current_stream(dev).wait_event(hit[3])     # images were made on another stream
+            return hit[1]
         w = _lib.MixSTE2Weights()
+        images, event, stream = None, None, None
+        if mode == 2:
+            images = self._split_images(get)
+            stream = torch.cuda.current_stream(dev)
+            event = torch.cuda.Event()
+            event.record(stream)
+            self.split_generation[dev.index] = self.split_generation.get(dev.index, 0) + 1
         fill_weights_struct(w, get, self._freqs, self.num_frame, self.num_joints, self.embed_dim,
-                            self.block_depth, self.num_heads, self.in_chans, mode,
-                            self._split_images(get) if mode == 2 else None)
+                            self.block_depth, self.num_heads, self.in_chans, mode, images)
         w.mlp_hidden = self.mlp_hidden
         w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
-        self._wcache = (key, w)
+        self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
         return w
 
     def _split_images(self, get):
         """Pre-split (bf16x3) images of every linear weight, made on the device by pafuse_split_weights: one uint8
         tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct)."""
-        lib = _lib.load()
         images = {}
         for name in self._param_names:
             if not name.endswith(SPLIT_SUFFIXES):
                 continue
-            wt = get(name)
-            N, K = wt.shape
-            img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=wt.device)
-            with torch.cuda.device(wt.device):
-                whole_row = int(name.endswith(("attn.proj.weight", "mlp.fc2.weight")))
-                _lib.check(lib.pafuse_split_weights(_ptr(wt.detach(), name), N, K, whole_row, img.data_ptr(),
-                                                    torch.cuda.current_stream(wt.device).cuda_stream))
-            images[name] = img
-        self._split_cache = images          # keeps the storage alive as long as the struct that points into it
+            images[name] = split_image(get(name), name.endswith(("attn.proj.weight", "mlp.fc2.weight")))
         return images
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -319,6 +323,18 @@ def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, i
                 setattr(dst[i], field, _ptr(get(f"{prefix}.{i}.{key}"), f"{prefix}.{i}.{key}"))
             for field, key in BLOCK_SPLIT:
                 setattr(dst[i], field, split[f"{prefix}.{i}.{key}"].data_ptr() if split is not None else None)
+
+
+def split_image(weight, whole_row):
+    """The pre-split (bf16x3) image of one linear weight [N,K] on its device (pafuse_split_weights): a uint8 tensor of
+    6 bytes per element; `whole_row` picks the chunk depth the whole-row layers (attn.proj, mlp.fc2) read."""
+    lib = _lib.load()
+    N, K = weight.shape
+    img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    with torch.cuda.device(weight.device):
+        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(whole_row), img.data_ptr(),
+                                            torch.cuda.current_stream(weight.device).cuda_stream))
+    return img
 
 
 def fill_block_struct(dst, blk):

@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .mixste2 import _ptr, fill_block_struct
+from .mixste2 import _ptr, fill_block_struct, split_image
 
 
 def _stream(t):
@@ -64,18 +64,31 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
     return o
 
 
-def block_forward(block_params, x, heads=8):
-    """Block.forward (common/mixste.py:113-116) on [S,L,C]; ``block_params`` is a pafuse_amd.mixste2._BlockParams."""
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+
+
+def block_forward(block_params, x, heads=8, precision="f32"):
+    """Block.forward (common/mixste.py:113-116) on [S,L,C]; ``block_params`` is a pafuse_amd.mixste2._BlockParams;
+    ``precision`` the matrix-product mode of its four linear layers ('bf16x3' makes the split images here)."""
     lib = _lib.load()
     S, L, Cc = x.shape
     _need(block_params.norm1.weight.numel() == Cc and Cc % heads == 0, f"block: parameters are not for width {Cc}")
+    _need(precision in PRECISIONS, f"precision must be one of {sorted(PRECISIONS)}")
     y = x.contiguous().clone()
     w = _lib.BlockWeights()
     fill_block_struct(w, block_params)
+    images = []
+    if precision == "bf16x3":
+        for field, lin, whole_row in (("qkv_ws", block_params.attn.qkv, False), ("proj_ws", block_params.attn.proj, True),
+                                      ("fc1_ws", block_params.mlp.fc1, False), ("fc2_ws", block_params.mlp.fc2, True)):
+            images.append(split_image(lin.weight, whole_row))
+            setattr(w, field, images[-1].data_ptr())
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.pafuse_block_forward(C.byref(w), y.data_ptr(), S, L, Cc, heads, ws.data_ptr(), nbytes, _stream(x)))
+        _lib.check(lib.pafuse_block_forward(C.byref(w), y.data_ptr(), S, L, Cc, heads, PRECISIONS[precision], ws.data_ptr(),
+                                            nbytes, _stream(x)))
+    del images      # (stream-ordered: the caching allocator reuses the blocks only for later work on this stream)
     return y
 
 

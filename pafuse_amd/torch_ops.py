@@ -6,9 +6,12 @@ there is no fallback), with fake-tensor shape functions so the ops trace under `
   pafuse::linear(x, weight, bias, gelu)                    nn.Linear (+ exact GELU)       common/mixste.py:30-43,54,57
   pafuse::layer_norm(x, weight, bias, eps)                 nn.LayerNorm                   common/mixste.py:96,101
   pafuse::attention(qkv, heads, seq_len, joints)           softmax(q k^T d^-1/2) v        common/mixste.py:65-79
-  pafuse::block(x, weights[12], heads)                     Block.forward on [S,L,C]       common/mixste.py:113-116
-  pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads)  MixSTE2.forward, eval          common/mixste.py:278-298
-  pafuse::ddim_loop(...)                                   D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
+  pafuse::block(x, weights[12], heads, precision)          Block.forward on [S,L,C]       common/mixste.py:113-116
+  pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads, precision)  MixSTE2.forward, eval  common/mixste.py:278-298
+  pafuse::ddim_loop(..., precision)                        D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
+
+``precision`` ('bf16x3' default = the modules' inference default, 'f32', 'bf16') is the matrix-product mode of the linear
+layers; in 'bf16x3' the ops build and cache the pre-split weight images themselves (cached_split_image).
 
 ``weights`` lists are in ``named_parameters()`` order of the corresponding module (= the reference's state-dict
 order), so ``list(model.parameters())`` is the argument.  The modules in pafuse_amd call the C ABI directly; these ops
@@ -21,7 +24,7 @@ from typing import List
 import torch
 
 from . import _lib
-from .mixste2 import MixSTE2, _ptr, fill_weights_struct, sinusoid_frequencies
+from .mixste2 import MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, sinusoid_frequencies, split_image
 
 BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
@@ -64,8 +67,32 @@ def _freqs(channels, device):
     return _freq_cache[key]
 
 
-def mixste_struct(weights, frames, joints, depth, heads):
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+_image_cache = {}        # (data_ptr, _version, device, whole_row) of a linear weight -> its split image (bf16x3 mode)
+_IMAGE_CACHE_MAX = 2048  # ~ three models' worth of linear weights; the oldest entries go first
+
+
+def cached_split_image(weight, whole_row):
+    """The pre-split image of a linear weight, made once per (storage, version): the schema'd ops take plain parameter
+    tensors, so they build and cache the images the split-precision kernels read (the modules keep theirs per module)."""
+    key = (weight.data_ptr(), weight._version, weight.device, bool(whole_row), tuple(weight.shape))
+    img = _image_cache.get(key)
+    if img is None:
+        while len(_image_cache) >= _IMAGE_CACHE_MAX:
+            _image_cache.pop(next(iter(_image_cache)))
+        img = _image_cache[key] = split_image(weight, whole_row)
+    return img
+
+
+def _mode(precision):
+    if precision not in PRECISIONS:
+        raise _lib.PafuseError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+    return PRECISIONS[precision]
+
+
+def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
     """pafuse_mixste2_weights from a flat parameter list; returns (struct, keep-alive)."""
+    mode = _mode(precision)
     channels = weights[0].shape[-1]                           # Spatial_pos_embed [1,J,C] comes first
     names = mixste_param_names(frames, joints, channels, depth, heads)
     if len(weights) != len(names):
@@ -76,8 +103,12 @@ def mixste_struct(weights, frames, joints, depth, heads):
         _ptr(t, n)
     fr = _freqs(channels, weights[0].device)
     w = _lib.MixSTE2Weights()
-    fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5)
-    return w, (table, fr)
+    images = None
+    if mode == 2:
+        images = {n: cached_split_image(t, n.endswith(("attn.proj.weight", "mlp.fc2.weight")))
+                  for n, t in table.items() if n.endswith(SPLIT_SUFFIXES)}
+    fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
+    return w, (table, fr, images)
 
 
 # ------------------------------------------------------------------------------------------------ unit ops
@@ -141,9 +172,11 @@ def _(qkv, heads, seq_len, joints=0):
 
 
 @torch.library.custom_op("pafuse::block", mutates_args=(), device_types="cuda")
-def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int) -> torch.Tensor:
-    """Block.forward on [S,L,C]: S sequences of L tokens (spatial: L = J; temporal: the caller passes [.., F, C])."""
+def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int, precision: str = "bf16x3") -> torch.Tensor:
+    """Block.forward on [S,L,C]: S sequences of L tokens (spatial: L = J; temporal: the caller passes [.., F, C]).
+    precision: matrix-product mode of the linear layers, as pafuse_amd.D3DP.precision (default: the inference default)."""
     lib = _lib.load()
+    mode = _mode(precision)
     if len(weights) != len(BLOCK_KEYS):
         raise _lib.PafuseError(f"block: expected {len(BLOCK_KEYS)} tensors in order {BLOCK_KEYS}")
     S, L, Cc = x.shape
@@ -155,26 +188,31 @@ def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int) -> torch.Ten
     w = _lib.BlockWeights()
     for field, t, name in zip(_lib.BLOCK_FIELDS, weights, BLOCK_KEYS):
         setattr(w, field, _ptr(t, name))
+    images = []
+    if mode == 2:
+        for field, idx, whole_row in (("qkv_ws", 2, False), ("proj_ws", 4, True), ("fc1_ws", 8, False), ("fc2_ws", 10, True)):
+            images.append(cached_split_image(weights[idx], whole_row))
+            setattr(w, field, images[-1].data_ptr())
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    _lib.check(lib.pafuse_block_forward(C.byref(w), _ptr(y, "x"), S, L, Cc, heads, ws.data_ptr(), nbytes, _stream(x)))
+    _lib.check(lib.pafuse_block_forward(C.byref(w), _ptr(y, "x"), S, L, Cc, heads, mode, ws.data_ptr(), nbytes, _stream(x)))
     return y
 
 
 @block.register_fake
-def _(x, weights, heads):
+def _(x, weights, heads, precision="bf16x3"):
     return torch.empty_like(x)
 
 
 # ------------------------------------------------------------------------------------------- model-level ops
 @torch.library.custom_op("pafuse::mixste_eval", mutates_args=(), device_types="cuda")
 def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: List[torch.Tensor], depth: int,
-                heads: int) -> torch.Tensor:
+                heads: int, precision: str = "bf16x3") -> torch.Tensor:
     lib = _lib.load()
     _need(x3d.dim() == 5 and x3d.shape[-1] == 3, "mixste_eval: x3d must be [B,P,F,J,3]")
     B, P, F, J, _ = x3d.shape
     _need(tuple(x2d.shape) == (B, F, J, 2) and tuple(t.shape) == (B,), "mixste_eval: x2d must be [B,F,J,2], t [B]")
-    w, keep = mixste_struct(weights, F, J, depth, heads)
+    w, keep = mixste_struct(weights, F, J, depth, heads, precision)
     x2d, x3d, t = x2d.contiguous().float(), x3d.contiguous().float(), t.contiguous().long()
     out = torch.empty(B, P, F, J, 3, device=x3d.device, dtype=torch.float32)
     nbytes = lib.pafuse_mixste2_workspace_bytes(C.byref(w), B, P)
@@ -185,19 +223,21 @@ def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: 
 
 
 @mixste_eval.register_fake
-def _(x2d, x3d, t, weights, depth, heads):
+def _(x2d, x3d, t, weights, depth, heads, precision="bf16x3"):
     return torch.empty_like(x3d)
 
 
 @torch.library.custom_op("pafuse::ddim_loop", mutates_args=(), device_types="cuda")
 def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, weights: List[torch.Tensor],
               part_joints: List[torch.Tensor], flip_perm: torch.Tensor, depth: int, heads: int, times: List[int],
-              sched: List[float], flip: bool, scale: float) -> torch.Tensor:
+              sched: List[float], flip: bool, scale: float, precision: str = "bf16x3") -> torch.Tensor:
     """The whole sampler.  noise [n_draws,B,P,F,J,3] in the reference's draw order; weights = the per-part
     parameter lists concatenated in part order; part_joints[i] int32 joint indices of part i; flip_perm int32 [J];
     times[k] the k-th timestep (the last one is the step whose time_next < 0); sched 5 doubles per step:
-    sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t], sqrt(alpha_next), c, sigma.  -> [B,T,P,F,J,3]"""
+    sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t], sqrt(alpha_next), c, sigma.  precision: the
+    matrix-product mode of every part's linear layers (default = the modules' inference default).  -> [B,T,P,F,J,3]"""
     lib = _lib.load()
+    _mode(precision)
     _need(noise.dim() == 6 and noise.shape[-1] == 3, "ddim_loop: noise must be [n_draws,B,P,F,J,3]")
     n_draws, B, P, F, J, _ = noise.shape
     _need(tuple(x2d.shape) == (B, F, J, 2) and (not flip or tuple(x2d_flip.shape) == (B, F, J, 2)),
@@ -216,7 +256,7 @@ def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, we
     for i, idx in enumerate(part_joints):
         Jp = idx.numel()
         n = len(mixste_param_names(F, Jp, weights[at].shape[-1], depth, heads))
-        w, k = mixste_struct(weights[at:at + n], F, Jp, depth, heads)
+        w, k = mixste_struct(weights[at:at + n], F, Jp, depth, heads, precision)
         at += n
         idx32 = idx.to(device=dev, dtype=torch.int32).contiguous()
         cfg.part[i], cfg.part_joints[i] = w, idx32.data_ptr()
@@ -249,7 +289,7 @@ def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, we
 
 
 @ddim_loop.register_fake
-def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale):
+def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale, precision="bf16x3"):
     n_draws, B, P, F, J, _ = noise.shape
     return noise.new_empty(B, len(times), P, F, J, 3)
 

@@ -37,3 +37,15 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def pytest_terminal_summary(terminalreporter):
+    """the parity cases' measured |dMPJPE| against their bounds and against north_star's 1e-4 mm (tests/test_hip_parity.py)"""
+    try:
+        from tests.test_hip_parity import PARITY_LINES
+    except Exception:
+        return
+    if PARITY_LINES:
+        terminalreporter.write_sep("-", "MPJPE parity (HIP path vs CPU oracle)")
+        for line in PARITY_LINES:
+            terminalreporter.write_line(line)

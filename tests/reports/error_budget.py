@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where the |HIP - oracle| difference comes from: both fp32 implementations against an fp64 evaluation of the
-same function (same fp32 weights/inputs, arithmetic in double).  Run on the GPU box; prints JSON lines."""
+same function (same fp32 weights/inputs, arithmetic in double).  Run on the GPU box; prints JSON lines and, with
+`--out FILE`, writes them as one document carrying the kernel-source digest (profiles/r03_error_budget.json: the numbers
+behind "both fp32 implementations sit 2.1-2.6e-4 mm from exact arithmetic" in DESIGN.md section 4)."""
 import json
 import os
 import sys
@@ -14,6 +16,8 @@ from oracle import d3dp_oracle as orc  # noqa: E402
 from tests.golden import golden_util as gu  # noqa: E402
 from pafuse_amd import ops  # noqa: E402
 
+out_path = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "--out" else None
+rows = []
 model, sd = make_model(2, 2, seed=77)
 sd64 = {k: v.double() for k, v in sd.items()}
 x2d, _ = gu.synthetic_inputs_2d(B=1)
@@ -31,7 +35,7 @@ for tval in (999, 499, 99):
         o32 = orc.mixste2_eval(sd, pre, x2d[..., idx, :], x3d[..., idx, :], t)
         oh = model.pose_estimator[part](x2d[..., idx, :].cuda(), x3d[..., idx, :].cuda(), t.cuda()).cpu()
         e32, eh = (o32.double() - o64), (oh.double() - o64)
-        print(json.dumps({
+        rows.append({
             "t": tval, "part": part,
             "temb_err_oracle32": (te32.double() - te64).abs().max().item(),
             "temb_err_hip": (teh.double() - te64).abs().max().item(),
@@ -39,4 +43,16 @@ for tval in (999, 499, 99):
             "oracle32_vs_fp64": {"max": e32.abs().max().item(), "mean_abs": e32.abs().mean().item(), "mean": e32.mean().item()},
             "hip_vs_fp64": {"max": eh.abs().max().item(), "mean_abs": eh.abs().mean().item(), "mean": eh.mean().item()},
             "hip_vs_oracle32": {"max": (oh - o32).abs().max().item(), "mean_abs": (oh - o32).abs().mean().item()},
-        }))
+        })
+        print(json.dumps(rows[-1]), flush=True)
+if out_path:
+    from pafuse_amd._lib import kernel_source_digest
+    mean = lambda key: sum(r[key]["mean_abs"] for r in rows) / len(rows)
+    doc = {"what": "one denoiser pass (P=2, seeded weights 77) per part and timestep: the fp32 CPU oracle and the HIP path (precision "
+                   f"{model.precision}) against an fp64 evaluation of the same function; metres",
+           "device": torch.cuda.get_device_name(0), "kernel_source_sha256": kernel_source_digest(),
+           "summary_mm": {"oracle32_vs_fp64_mean_abs": mean("oracle32_vs_fp64") * 1e3, "hip_vs_fp64_mean_abs": mean("hip_vs_fp64") * 1e3,
+                          "hip_vs_oracle32_mean_abs": mean("hip_vs_oracle32") * 1e3},
+           "rows": rows}
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1)

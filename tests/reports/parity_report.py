@@ -3,11 +3,12 @@
 of the four protocols (J-Best / P-Best / P-Agg / J-Agg, main_h3wb.py:327-348) at every DDIM step.
 
 Run on the GPU box:
-    python tests/reports/parity_report.py [--out FILE.json] CASE [CASE ...]      CASE = P,T[,B[,precision]]
-e.g. `5,5 20,10 5,5,1,f32 5,5,1,bf16` (precision defaults to the inference default, bf16x3).  One JSON object per case is printed; with --out they are also written as one JSON file
-(`profiles/r02_parity_report.json` is this script's output, and the per-protocol bounds asserted in
-tests/test_hip_parity.py::MPJPE_TOL_MM are read off it).  The oracle runs ALL P hypotheses here (the aggregation
-protocols reduce over P): P=20, T=10 is about two minutes of host CPU.
+    python tests/reports/parity_report.py --out profiles/r03_parity_report.json [--no-fullsize] [extra P,T,B,precision ...]
+It runs exactly the case functions the GPU tests run (tests/test_hip_parity.py::loop_case for LOOP_CASES x {f32, bf16x3},
+tests/test_hip_fullsize.py::fullsize_case) plus the metric's own P=20, T=10 loop in both fp32-grade modes and the opt-in
+bf16 mode at P=5, T=5; every case is recorded under its name together with the SHA-256 of the oracle's output.  The tests
+assert 1.25 x these measurements per case and protocol (tests/test_hip_parity.py::parity_bounds) - valid for the oracle
+arithmetic recorded here, which the hash identifies.
 """
 import json
 import os
@@ -19,35 +20,20 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from __graft_entry__ import make_model  # noqa: E402
 from oracle import d3dp_oracle as orc  # noqa: E402
 from pafuse_amd import synthetic as gu  # noqa: E402
-from tests.test_hip_parity import _j_agg_compare, _mpjpe_report  # noqa: E402
+from tests.test_hip_parity import LOOP_CASES, _j_agg_compare, _mpjpe_report, loop_case, tensor_sha256  # noqa: E402
 
 
-_ORACLE = {}        # (P, T, B) -> (oracle output, seconds): the oracle does not depend on the HIP path's product mode
-
-
-def run_case(P, T, B=1, precision="bf16x3"):
-    model, sd = make_model(P, T, seed=77)
-    model.precision = precision
-    x2d, x2f = gu.synthetic_inputs_2d(B=B)
-    noises = gu.synthetic_noises(B=B, P=P, n=T, seed=3)
-    model.noise_fn = lambda k, shape, device: noises[k]
-    out = model(x2d.cuda(), None, input_2d_flip=x2f.cuda()).cpu()
-    if (P, T, B) not in _ORACLE:
-        t0 = time.time()
-        ref = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
-        _ORACLE[(P, T, B)] = (ref, time.time() - t0)
-    ref, cpu_s = _ORACLE[(P, T, B)]
-    target = orc.center_pose_parts(gu.synthetic_target_3d(B))
+def measure(name, out, ref, target, x2d, precision, cpu_s=None):
     got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
     d = (out - ref).abs()
+    T = out.shape[1]
     jagg_same, jagg_flip_frac, jagg_flip_margin = _j_agg_compare(out, ref, target, x2d)
-    # J-Agg picks, per (frame, joint), the hypothesis with the smallest 2-D reprojection error: count the joints whose
-    # pick differs between the two runs (a near-tie decided the other way swaps in another hypothesis' 3-D error)
+    pairs = [(got[k] - want[k]).abs() for k in ("J-Best", "P-Best", "P-Agg")]
     return {
-        "B": B, "P": P, "T": T, "precision": model.precision, "oracle_cpu_s": round(cpu_s, 2),
+        "name": name, "B": out.shape[0], "P": out.shape[2], "T": T, "precision": precision,
+        "oracle_sha256": tensor_sha256(ref), "oracle_cpu_s": None if cpu_s is None else round(cpu_s, 2),
         "pointwise_max_abs_m": d.max().item(), "pointwise_mean_abs_m": d.mean().item(),
         "per_step_pointwise_max_abs_m": [d[:, k].max().item() for k in range(T)],
         "clamped_frac": (ref.abs() >= 1.1).float().mean().item(),
@@ -57,32 +43,58 @@ def run_case(P, T, B=1, precision="bf16x3"):
         "j_agg_same_picks_mm_abs_diff_max": jagg_same, "j_agg_fraction_of_joints_with_different_pick": jagg_flip_frac,
         "j_agg_largest_2d_margin_m_among_different_picks": jagg_flip_margin,
         "north_star_1e-4mm_met": {k: bool((got[k] - want[k]).abs().max().item() <= 1e-4) for k in want},
+        "north_star_1e-4mm_met_fraction_of_step_protocol_pairs": sum(int((v <= 1e-4).sum()) for v in pairs) / sum(v.numel() for v in pairs),
     }
 
 
 def main(argv):
-    out_path = None
+    out_path, fullsize = None, True
     if argv and argv[0] == "--out":
         out_path, argv = argv[1], argv[2:]
-    cases = []
-    for spec in argv or ["5,5"]:
+    if argv and argv[0] == "--no-fullsize":
+        fullsize, argv = False, argv[1:]
+    extra = [(1, 20, 10, "bf16x3"), (1, 20, 10, "f32"), (1, 5, 5, "bf16")]
+    for spec in argv:
         f = spec.split(",")
-        cases.append((int(f[0]), int(f[1]), int(f[2]) if len(f) > 2 else 1, f[3] if len(f) > 3 else "bf16x3"))
+        extra.append((int(f[2]) if len(f) > 2 else 1, int(f[0]), int(f[1]), f[3] if len(f) > 3 else "bf16x3"))
     try:
         sha = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
         sha = os.environ.get("PAFUSE_GIT_SHA", "unknown (gpurun snapshot has no .git)")
     results = []
-    for c in cases:
-        r = run_case(*c)
+
+    def emit(r):
         print(json.dumps(r), flush=True)
         results.append(r)
+
+    done = set()
+    for (B, P, T) in LOOP_CASES:
+        for prec in ("f32", "bf16x3"):
+            t0 = time.time()
+            name, out, ref, target, x2d = loop_case(B, P, T, prec)
+            emit(measure(name, out, ref, target, x2d, prec, time.time() - t0))
+            done.add((B, P, T, prec))
+    for (B, P, T, prec) in extra:
+        if (B, P, T, prec) in done:
+            continue
+        t0 = time.time()
+        name, out, ref, target, x2d = loop_case(B, P, T, prec)
+        emit(measure(name, out, ref, target, x2d, prec, time.time() - t0))
+    if fullsize:
+        from tests.test_hip_fullsize import CHECKED, FULLSIZE_SELECTIONS, fullsize_case
+        t0 = time.time()
+        fs = fullsize_case()
+        out, ref = fs["out"][:, :, list(CHECKED)].cpu(), fs["ref"]
+        target = orc.center_pose_parts(gu.synthetic_target_3d(1))
+        for name, sel in FULLSIZE_SELECTIONS.items():
+            emit(measure(name, out[:, :, sel], ref[:, :, sel].contiguous(), target, fs["x2d"], "bf16x3", time.time() - t0))
     if out_path:
         from pafuse_amd._lib import kernel_source_digest
-        doc = {"what": "HIP path vs CPU oracle (oracle/d3dp_oracle.py, pinned to the reference by tests/golden), seeded "
-                       "synthetic weights seed 77, inputs seed 1234, noise seed 3; MPJPE in mm with fp64 metric arithmetic",
+        doc = {"what": "HIP path vs CPU oracle (oracle/d3dp_oracle.py, pinned to the reference by tests/golden) on the GPU tests' own "
+                       "seeded cases; MPJPE in mm with fp64 metric arithmetic; the tests assert 1.25 x mpjpe_mm_abs_diff_max per case",
                "device": torch.cuda.get_device_name(0), "git_sha": sha, "kernel_source_sha256": kernel_source_digest(),
-               "cases": results}
+               "cpu": next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?"),
+               "torch": torch.__version__, "cases": results}
         with open(out_path, "w") as f:
             json.dump(doc, f, indent=1)
 

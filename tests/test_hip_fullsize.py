@@ -5,9 +5,9 @@ Full-size checks use what the domain offers: a hypothesis' DDIM t
 own noise draws, so (a) any sharding of the hypothesis axis must reproduce the unsharded run bit for bit, and (b) the
 CPU oracle, run on a few hypotheses only, is an exact check of those hypotheses inside the big run.
 
-MPJPE tolerances come from the committed report profiles/r02_parity_report.json (tests/reports/parity_report.py run
-on MI355X); what is asserted per protocol, and why north_star's 1e-4 mm is out of reach for two fp32 implementations,
-is stated next to tests/test_hip_parity.py::MPJPE_TOL_MM.
+MPJPE bounds are per case and per protocol, 1.25 x the measurements committed in profiles/r03_parity_report.json
+(tests/reports/parity_report.py runs this module's case function on MI355X); what is asserted, and why north_star's
+1e-4 mm is out of reach for two fp32 implementations, is stated in tests/test_hip_parity.py next to parity_bounds.
 """
 import ctypes as C
 
@@ -22,12 +22,13 @@ from tests.test_hip_parity import _assert_mpjpe_parity
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 T_FULL = 10
-CHECKED = (0, 7, 19, 83, 159)       # hypotheses the oracle re-computes (the first three lie inside the P=20 run)
+CHECKED = tuple(range(20)) + (83, 159)   # hypotheses the oracle re-computes: ALL of the P=20 run (the metric's own
+#                                          configuration, every protocol reduces over them) and two from the far shards
 
 
-@pytest.fixture(scope="module")
-def full160():
-    """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on five of its hypotheses."""
+def fullsize_case():
+    """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on 22 of its hypotheses, all ten
+    steps (about five minutes of host CPU).  Shared by the tests below and tests/reports/parity_report.py."""
     from __graft_entry__ import make_model
     model, sd = make_model(160, T_FULL, seed=51)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
@@ -37,6 +38,14 @@ def full160():
     sub = [n[:, list(CHECKED)] for n in noises]
     ref = orc.ddim_sample(sd, x2d, sub, T_FULL, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
     return dict(model=model, sd=sd, x2d=x2d, x2f=x2f, noises=noises, out=out, ref=ref)
+
+
+FULLSIZE_SELECTIONS = {"fullsize_P20_T10_bf16x3": slice(0, 20), "fullsize_P20plus2of160_T10_bf16x3": slice(0, 22)}
+
+
+@pytest.fixture(scope="module")
+def full160():
+    return fullsize_case()
 
 
 def test_p160_single_run_shape_and_finite(full160):
@@ -83,16 +92,17 @@ def test_p20_t10_equals_its_halves_and_the_p160_prefix(full160):
 
 
 def test_full_size_trajectories_vs_oracle(full160):
-    """the oracle on hypotheses {0, 7, 19} (inside the P=20 run) and {83, 159} of the P=160 run, all ten steps:
-    pointwise 1e-5, and the four MPJPE protocols over the checked hypotheses within the per-protocol bounds."""
+    """the oracle on ALL 20 hypotheses of the P=20 run (the metric's configuration: the aggregation protocols reduce over
+    exactly these) and on {83, 159} of the P=160 run, all ten steps: pointwise 1e-5, and the four MPJPE protocols within
+    the per-case bounds."""
     out = full160["out"][:, :, list(CHECKED)].cpu()
     ref = full160["ref"]
     assert out.shape == ref.shape == (1, T_FULL, len(CHECKED), 27, 134, 3)
     d = (out - ref).abs()
     assert float(d.max()) <= 1e-5, [float(d[:, k].max()) for k in range(T_FULL)]
     target = orc.center_pose_parts(gu.synthetic_target_3d(1))
-    for sel in (slice(0, 3), slice(0, 5)):             # the P=20 members alone, then all five
-        _assert_mpjpe_parity(out[:, :, sel], ref[:, :, sel], target, full160["x2d"])
+    for case, sel in FULLSIZE_SELECTIONS.items():      # the P=20 run alone, then with the two far hypotheses
+        _assert_mpjpe_parity(out[:, :, sel], ref[:, :, sel].contiguous(), target, full160["x2d"], case)
 
 
 # ------------------------------------------------------------------------------ index stages, bit for bit (golden G6)

@@ -19,21 +19,51 @@ from tests.golden import golden_util as gu
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-# |MPJPE_hip - MPJPE_oracle| bounds in mm per protocol, read off profiles/r02_parity_report.json (MI355X, P=5/T=5 and
-# P=20/T=10, every step).  north_star asks 1e-4 mm; NO protocol meets it at every step, and none can: measured
-# |dMPJPE| is 2e-6 .. 3.7e-4 mm for J-Best / P-Best / P-Agg alike, i.e. the size of the mean pointwise difference
-# (2.5e-4 mm) - the differences do not average out over the 3 618 joints of a clip because part centring and
-# wb_pose_from_parts turn the rounding of ONE root / connection joint into a shift of a whole part, and because both
-# fp32 implementations (this one and the reference's ATen/MKL kernels) sit 2.1-2.6e-4 mm (mean) away from an exact
-# evaluation of the same function (tests/reports/error_budget.py; test_accuracy_equivalent_to_reference_fp32 asserts
-# the HIP path is not further from exact arithmetic than the reference is).  Asserted: 5e-4 mm, the tightest round
-# bound above every measurement.
+# |MPJPE_hip - MPJPE_oracle| in mm, per protocol AND per test case.  north_star asks 1e-4 mm; no protocol meets it at every
+# step, and none can: measured |dMPJPE| is 2e-6 .. 3.7e-4 mm for J-Best / P-Best / P-Agg alike, i.e. the size of the mean
+# pointwise difference (2.5e-4 mm) - the differences do not average out over the 3 618 joints of a clip because part
+# centring and wb_pose_from_parts turn the rounding of ONE root / connection joint into a shift of a whole part, and both
+# fp32 implementations (this one and the reference's ATen/MKL kernels) sit 2.1-2.6e-4 mm (mean) from an exact evaluation
+# of the same function (profiles/r03_error_budget.json; test_accuracy_equivalent_to_reference_fp32 asserts the HIP path
+# is not further from exact arithmetic than the reference is).
+# What is asserted: for every named case below, each protocol's max-over-steps |dMPJPE| <= 1.25 x the value measured for
+# that case and protocol on MI355X and committed in profiles/r03_parity_report.json (tests/reports/parity_report.py runs
+# exactly the case functions of this module), never more than the old blanket 5e-4 mm.  The per-case numbers are a
+# property of both roundings; when the CPU oracle's arithmetic on this box is not the recorded one (its output hash
+# differs: another BLAS code path), only the blanket bound is meaningful and only it is asserted.
 # J-Agg additionally picks, per (frame, joint), the hypothesis with the smallest 2-D reprojection error: where two
 # hypotheses tie to within rounding the two runs may pick differently, and one different pick moves the clip mean by
-# (difference of the two hypotheses' 3-D errors) / 3618 - measured once in 20 steps x 3 618 joints: 1.1e-2 mm.  The
-# tests therefore compare J-Agg on the joints where both runs make the same pick (5e-4 mm) and bound the picks that
-# differ: few, and each a genuine near-tie (_j_agg_compare).
-MPJPE_TOL_MM = {"J-Best": 5e-4, "P-Best": 5e-4, "P-Agg": 5e-4, "J-Agg": 5e-4}
+# (difference of the two hypotheses' 3-D errors) / 3618 (measured once in 20 steps x 3 618 joints: 1.1e-2 mm).  J-Agg is
+# therefore compared on the joints where both runs make the same pick, and the picks that differ are bounded: few, and
+# each a genuine near-tie (_j_agg_compare).
+BLANKET_TOL_MM = 5e-4
+BOUND_FACTOR = 1.25
+BOUND_FLOOR_MM = 2e-5          # below this a measured value says nothing about the next weight seed's rounding
+PARITY_REPORT = "profiles/r03_parity_report.json"
+PROTOCOLS = ("J-Best", "P-Best", "P-Agg", "J-Agg")
+PARITY_LINES = []              # one line per asserted case, printed in the terminal summary (tests/conftest.py)
+
+
+def tensor_sha256(t):
+    import hashlib
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def parity_bounds(case, ref):
+    """{protocol: bound in mm} for a named case (J-Agg: the same-pick comparison), and whether they are the per-case ones."""
+    import json
+    import os
+    from tests.conftest import ROOT
+    path = os.path.join(ROOT, PARITY_REPORT)
+    entries = {c["name"]: c for c in json.load(open(path))["cases"]} if os.path.exists(path) else {}
+    e = entries.get(case)
+    if e is None:
+        pytest.fail(f"{PARITY_REPORT} has no case '{case}': regenerate it with tests/reports/parity_report.py on the GPU box")
+    if e["oracle_sha256"] != tensor_sha256(ref):
+        return {k: BLANKET_TOL_MM for k in PROTOCOLS}, False
+    m = dict(e["mpjpe_mm_abs_diff_max"])
+    m["J-Agg"] = e["j_agg_same_picks_mm_abs_diff_max"]
+    return {k: min(BLANKET_TOL_MM, max(BOUND_FACTOR * m[k], BOUND_FLOOR_MM)) for k in PROTOCOLS}, True
 
 
 def _seeded(shape, seed, scale=1.0):
@@ -177,7 +207,10 @@ def test_g3_time_embed_golden():
         assert torch.allclose(out, z[f"{part}.out"], rtol=0, atol=5e-6), (part, (out - z[f"{part}.out"]).abs().max())
 
 
-def test_g4_blocks_golden():
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_g4_blocks_golden(precision):
+    """golden G4 (one real-width block per part, spatial and temporal, outputs of the reference) through pafuse_block_forward in
+    both fp32-grade product modes.  (G3, the timestep MLP, has no product mode: time_embed_kernel is fp32 VALU arithmetic.)"""
     from functools import partial
     from pafuse_amd import ops
     from pafuse_amd.mixste2 import _BlockParams
@@ -189,7 +222,7 @@ def test_g4_blocks_golden():
         blk.load_state_dict(sd)
         blk = blk.to(DEV)
         for tag in ("s", "t"):
-            y = ops.block_forward(blk, z[f"{part}.x{tag}"].to(DEV)).cpu()
+            y = ops.block_forward(blk, z[f"{part}.x{tag}"].to(DEV), precision=precision).cpu()
             ref = z[f"{part}.y{tag}"]
             assert torch.allclose(y, ref, rtol=0, atol=1e-5), (part, tag, (y - ref).abs().max())
 
@@ -305,21 +338,27 @@ def _j_agg_compare(out, ref, target, x2d):
     return d, flipped.double().mean().item(), worst
 
 
-def _assert_mpjpe_parity(out, ref, target, x2d):
+def _assert_mpjpe_parity(out, ref, target, x2d, case):
     got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
-    for k in ("J-Best", "P-Best", "P-Agg"):
-        assert (got[k] - want[k]).abs().max() <= MPJPE_TOL_MM[k], (k, (got[k] - want[k]).abs().max())
+    bounds, per_case = parity_bounds(case, ref)
+    diffs = {k: (got[k] - want[k]).abs() for k in ("J-Best", "P-Best", "P-Agg")}
     d, frac, worst = _j_agg_compare(out, ref, target, x2d)
-    # same picks: the common bound; different picks: rare, and only where the two best hypotheses tie to within the
+    met = sum(int((v <= 1e-4).sum()) for v in diffs.values())
+    total = sum(v.numel() for v in diffs.values())
+    PARITY_LINES.append(f"{case}: |dMPJPE| max mm " + ", ".join(f"{k} {float(v.max()):.2e} (<= {bounds[k]:.2e})" for k, v in diffs.items()) +
+                        f", J-Agg same picks {d:.2e} (<= {bounds['J-Agg']:.2e}), different picks {frac:.1e} of joints; north_star "
+                        f"1e-4 mm met at {met} of {total} (step, protocol) pairs; bounds: "
+                        + ("1.25 x committed measurement" if per_case else "blanket (oracle arithmetic differs from the recorded one)"))
+    for k, v in diffs.items():
+        assert v.max() <= bounds[k], (case, k, float(v.max()), bounds[k])
+    # same picks: the case's bound; different picks: rare, and only where the two best hypotheses tie to within the
     # pointwise tolerance of the poses (a 1e-5 m pose difference moves a 2-D reprojection error by < 1e-4)
-    assert d <= MPJPE_TOL_MM["J-Agg"] and frac <= 2e-3 and worst <= 1e-4, (d, frac, worst)
+    assert d <= bounds["J-Agg"] and frac <= 2e-3 and worst <= 1e-4, (case, d, bounds["J-Agg"], frac, worst)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
-@pytest.mark.parametrize("B,P,T", [(1, 5, 5), (2, 3, 2)])
-def test_loop_vs_oracle_mpjpe(B, P, T, precision):
-    """BASELINE configs[1] shape (P=5, T=5) and a B>1 case: pointwise and MPJPE parity, for the fp32 matrix cores and
-    for the split-precision (bf16x3) products alike - the same bounds."""
+def loop_case(B, P, T, precision):
+    """(name, out, ref, target, x2d) of a seeded flip-TTA loop: the HIP path and the oracle on the same inputs.  Shared by
+    test_loop_vs_oracle_mpjpe and tests/reports/parity_report.py (the committed bounds are measured on these very runs)."""
     from __graft_entry__ import make_model
     model, sd = make_model(P, T, seed=77)
     model.precision = precision
@@ -328,8 +367,20 @@ def test_loop_vs_oracle_mpjpe(B, P, T, precision):
     model.noise_fn = lambda k, shape, device: noises[k]
     out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     ref = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    return f"loop_B{B}_P{P}_T{T}_{precision}", out, ref, orc.center_pose_parts(gu.synthetic_target_3d(B)), x2d
+
+
+LOOP_CASES = [(1, 5, 5), (2, 3, 2)]
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("B,P,T", LOOP_CASES)
+def test_loop_vs_oracle_mpjpe(B, P, T, precision):
+    """BASELINE configs[1] shape (P=5, T=5) and a B>1 case: pointwise and MPJPE parity, for the fp32 matrix cores and
+    for the split-precision (bf16x3) products alike, each against its own committed measurement."""
+    case, out, ref, target, x2d = loop_case(B, P, T, precision)
     assert torch.allclose(out, ref, rtol=0, atol=1e-5), (out - ref).abs().max()
-    _assert_mpjpe_parity(out, ref, orc.center_pose_parts(gu.synthetic_target_3d(B)), x2d)
+    _assert_mpjpe_parity(out, ref, target, x2d, case)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
@@ -561,28 +612,37 @@ def test_torch_custom_ops_equal_the_modules():
     g, be = _seeded((256,), 4).to(DEV), _seeded((256,), 5).to(DEV)
     assert torch.equal(ops.layer_norm(x, g, be, 1e-6), wrap.layer_norm(x, g, be, 1e-6))
     model, _ = make_model(3, 2, seed=91)
-    model.precision = "f32"                     # the schema'd ops take the fp32 parameters only: the fp32 matrix cores
     body = model.pose_estimator["body"]
     x2d = _seeded((2, 27, 24, 2), 6).to(DEV)
     x3d = _seeded((2, 3, 27, 24, 3), 7).to(DEV)
     t = torch.tensor([999, 499], device=DEV)
-    assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads),
-                       body(x2d, x3d, t))
     blk = body.STEblocks[0]
     xs = _seeded((4, 24, 384), 8).to(DEV)
-    from pafuse_amd.ops import block_forward
-    assert torch.equal(ops.block(xs, list(blk.parameters()), 8), block_forward(blk, xs))
-    qkv = _seeded((2 * 27 * 24, 3 * 384), 9).to(DEV)
-    from pafuse_amd.ops import attention
-    assert torch.equal(ops.attention(qkv, 8, 24, 0), attention(qkv, 8, 2 * 27, 24))
-    assert torch.equal(ops.attention(qkv, 8, 27, 24),
-                       attention(qkv, 8, 2 * 24, 27, group=24, group_stride=27 * 24, seq_stride=1, tok_stride=24))
+    from pafuse_amd.ops import attention, block_forward
     i2d, i2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=3, n=2, seed=12)
     model.noise_fn = lambda k, shape, device: noises[k]
-    want = model(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV))
-    got = ops.ddim_loop(i2d.to(DEV), i2f.to(DEV), torch.stack(noises).to(DEV), *to.ddim_loop_args(model))
-    assert torch.equal(got, want)
+    assert model.precision == "bf16x3"          # the ops' default precision is the modules' inference default
+    assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads), body(x2d, x3d, t))
+    for precision in ("bf16x3", "f32"):         # the default split-precision path and the fp32 matrix cores
+        model.precision = precision
+        assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads, precision),
+                           body(x2d, x3d, t)), precision
+        assert torch.equal(ops.block(xs, list(blk.parameters()), 8, precision), block_forward(blk, xs, precision=precision)), precision
+        want = model(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV))
+        got = ops.ddim_loop(i2d.to(DEV), i2f.to(DEV), torch.stack(noises).to(DEV), *to.ddim_loop_args(model), precision)
+        assert torch.equal(got, want), precision
+    # an in-place weight update must remake the ops' cached images (keyed by storage and version)
+    model.precision = "bf16x3"
+    before = ops.block(xs, list(blk.parameters()), 8)
+    with torch.no_grad():
+        blk.attn.qkv.weight.mul_(1.5)
+    after = ops.block(xs, list(blk.parameters()), 8)
+    assert not torch.equal(before, after) and torch.equal(after, block_forward(blk, xs, precision="bf16x3"))
+    qkv = _seeded((2 * 27 * 24, 3 * 384), 9).to(DEV)
+    assert torch.equal(ops.attention(qkv, 8, 24, 0), attention(qkv, 8, 2 * 27, 24))
+    assert torch.equal(ops.attention(qkv, 8, 27, 24),
+                       attention(qkv, 8, 2 * 24, 27, group=24, group_stride=27 * 24, seq_stride=1, tok_stride=24))
 
 
 def test_replicas_share_nothing_device_bound():

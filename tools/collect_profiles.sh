@@ -14,6 +14,9 @@ cd /tmp && export TMPDIR=/tmp
 HB=$!
 trap "kill $HB 2>/dev/null" EXIT
 run() { echo "== $*" >&2; "$@"; }
+# build BEFORE anything runs under the profiler: a stale or missing library would otherwise be compiled (hipcc and its
+# children exec'd) inside a profiled, GPU-initialised process, and pollute the first pass
+run python3 -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as ge; ge.build()" || exit 1
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$O/stats_bench_line.json" 2> "$O/stats.err" || exit 1
 run rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/fetch_bench_line.json" 2> "$O/fetch.err" || exit 1
 run rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O" -o write -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$O/write_bench_line.json" 2> "$O/write.err" || exit 1
@@ -23,5 +26,6 @@ run python3 "$R/bench.py" > "$O/bench_line.json" 2> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --dtype f32 --no-cpu-baseline > "$O/bench_line_f32.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --train --no-cpu-baseline > "$O/train_bench_line_unprofiled.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/tools/soak_determinism.py" 200 > "$O/soak_determinism.json" 2>> "$O/bench.err" || exit 1
-run python3 "$R/tests/reports/parity_report.py" --out "$O/parity_report.json" 5,5,1,bf16x3 5,5,1,f32 5,5,1,bf16 20,10,1,bf16x3 20,10,1,f32 > "$O/parity_report.log" 2>&1 || exit 1
+run python3 "$R/tests/reports/error_budget.py" --out "$O/error_budget.json" > "$O/error_budget.log" 2>&1 || exit 1
+run python3 "$R/tests/reports/parity_report.py" --out "$O/parity_report.json" > "$O/parity_report.log" 2>&1 || exit 1
 ls -la "$O" | head -40
