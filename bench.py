@@ -61,6 +61,9 @@ def main():
                          "rehearsing the N > 1 code path on a box with fewer GPUs than ranks (with --single-device)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (never a performance number; needs --backend gloo)")
+    ap.add_argument("--dump-output", default=None, metavar="FILE",
+                    help="rank 0 saves the last step's gathered predictions [B,T,P,F,J,3] (torch.save): the rehearsal tests "
+                         "compare them with a single-process run of the same seed")
     ap.add_argument("--train", action="store_true",
                     help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
                          "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
@@ -136,7 +139,9 @@ def main():
     census = rank_census(hi - lo)
     if census["ranks_seen"] != world or sum(census["P_local"]) != P_total:
         raise SystemExit(f"rank census {census} does not match --gpus {world} x {P_local} hypotheses")
-    gather_ms = None
+    gather_ms = copy_ms = None
+    if args.dump_output and rank == 0:
+        torch.save(out.cpu(), args.dump_output)
     if world > 1:
         local = out[:, :, lo:hi].contiguous()
         gather_hypotheses(local, P_total)                      # warm-up
@@ -148,6 +153,14 @@ def main():
         gt = torch.tensor([(time.perf_counter() - t0) / 5], dtype=torch.float64, device=cdev)
         dist.all_reduce(gt, op=dist.ReduceOp.MAX)
         gather_ms = round(float(gt.item()) * 1e3, 3)
+        # of which the one pass that moves the rank axis next to the hypothesis axis (no communication)
+        stage = torch.empty((world,) + tuple(local.shape), device=local.device if args.backend == "nccl" else "cpu")
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            stage.permute(1, 2, 0, 3, 4, 5, 6).reshape(out.shape)
+        fence()
+        copy_ms = round((time.perf_counter() - t0) / 5 * 1e3, 3)
     value = B * P_total / sec_per_step
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
@@ -173,7 +186,7 @@ def main():
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
-        "allgather_ms": gather_ms,
+        "allgather_ms": gather_ms, "allgather_ms_note": "collective + the one layout pass, max over ranks", "gather_copy_ms": copy_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
                           "unit": "TFLOP/s", "frac": round(loop_tflops / peak, 4),
                           "frac_of_f32_peak": round(loop_tflops / PEAK_F32_MFMA_TFLOPS, 4),

@@ -615,6 +615,38 @@ def g16_chunked_generator():
 
 
 # -------------------------------------------------------------------------------------------------- G8
+# ------------------------------------------------------------------------------------------------- G19
+G19_SUB = (0, 7, 19)     # hypotheses whose whole trajectory is stored
+
+
+def g19_metric_config_p20_t10():
+    """The metric's own configuration run by the REFERENCE: D3DP.forward, flip-TTA, B=1, P=20, T=10 at the real dims
+    (BASELINE configs[2]; about three minutes of CPU), on the seeded weights / inputs / noise of the full-size GPU tests
+    (tests/test_hip_fullsize.py: weights seed 51, noise seed 160, the first 20 hypotheses of the P=160 draw).  Stored: the
+    trajectories of three hypotheses (pointwise check) and, over ALL 20 hypotheses, what the four MPJPE protocols reduce
+    to per DDIM step - J-Best / P-Best / P-Agg / J-Agg in mm (fp64 metric arithmetic of the oracle's metric functions,
+    themselves pinned by G7 / G9) plus the J-Agg pick, picked 3-D error and 2-D margin of every (step, frame, joint), so
+    that a run can be compared with the reference on the joints where both pick the same hypothesis."""
+    from oracle import d3dp_oracle as orc
+    from tests.test_hip_parity import PROTOCOLS, _j_agg_parts, _mpjpe_report
+    m = build_reference_d3dp(20, 10, flip=True)
+    sd = gu.seeded_state_dict(m.state_dict(), seed=51)
+    m.load_state_dict(sd)
+    x2d, x2d_flip = gu.synthetic_inputs_2d(B=1)
+    noises = [n[:, :20].contiguous() for n in gu.synthetic_noises(B=1, P=160, n=10, seed=160)]
+    with NoiseTape(noises) as tape, torch.no_grad():
+        out = m(x2d, None, input_2d_flip=x2d_flip)
+        assert tape.k == 10
+    assert out.shape == (1, 10, 20, 27, 134, 3)
+    target = orc.center_pose_parts(gu.synthetic_target_3d(1))
+    rep = _mpjpe_report(out, target, x2d)
+    pick, e3, margin = _j_agg_parts(out, target, x2d)
+    save("g19_metric_config.npz", sha=np.frombuffer(gu.sha256_of(sd), dtype=np.uint8),
+         out_sub=out[:, :, list(G19_SUB)], sub=np.asarray(G19_SUB),
+         mpjpe_mm=torch.stack([rep[k] for k in PROTOCOLS]),            # [4, T] fp64
+         jagg_pick=pick.to(torch.int8), jagg_e3=e3, jagg_margin=margin)
+
+
 def g8_default_init():
     """SHA-256 of the reference's default-initialised MixSTE2 under a fixed seed (pins parameter creation order)."""
     from common.mixste import MixSTE2
@@ -627,11 +659,11 @@ def g8_default_init():
 if __name__ == "__main__":
     install_shims()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g19"]
     table = dict(g1=g1_tiny_mixste, g2=g2_schedule, g3=g3_time_mlp, g4=g4_blocks, g5=g5_d3dp_loops,
                  g6=g6_index_ops, g7=g7_metrics, g8=g8_default_init, g9=g9_evaluate_accumulators,
                  g10=g10_clip_cutting, g11=g11_scale, g12=g12_train_tiny, g13=g13_d3dp_train,
                  g14=g14_h3wb_loader, g15=g15_camera_to_world,
-                 g16=g16_chunked_generator, g17=g17_single_model, g18=g18_mixste_options)
+                 g16=g16_chunked_generator, g17=g17_single_model, g18=g18_mixste_options, g19=g19_metric_config_p20_t10)
     for w in which:
         table[w]()

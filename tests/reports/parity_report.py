@@ -81,13 +81,36 @@ def main(argv):
         name, out, ref, target, x2d = loop_case(B, P, T, prec)
         emit(measure(name, out, ref, target, x2d, prec, time.time() - t0))
     if fullsize:
-        from tests.test_hip_fullsize import CHECKED, FULLSIZE_SELECTIONS, fullsize_case
+        from __graft_entry__ import make_model
+        from tests.conftest import load_golden
+        from tests.test_hip_fullsize import CHECKED, FULLSIZE_SELECTIONS, T_FULL, fullsize_case, g19_compare
         t0 = time.time()
         fs = fullsize_case()
         out, ref = fs["out"][:, :, list(CHECKED)].cpu(), fs["ref"]
         target = orc.center_pose_parts(gu.synthetic_target_3d(1))
         for name, sel in FULLSIZE_SELECTIONS.items():
-            emit(measure(name, out[:, :, sel], ref[:, :, sel].contiguous(), target, fs["x2d"], "bf16x3", time.time() - t0))
+            emit(measure(name, out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, fs["x2d"], "bf16x3", time.time() - t0))
+        # the metric's own configuration against the REFERENCE's run of it (golden G19): all 20 hypotheses, every step
+        z = load_golden("g19_metric_config.npz")
+        for prec in ("bf16x3", "f32"):
+            if prec == "bf16x3":
+                out20 = fs["out"][:, :, :20].cpu()
+            else:
+                model, _ = make_model(20, T_FULL, seed=51)
+                model.precision = prec
+                noises = [n[:, :20].contiguous() for n in fs["noises"]]
+                model.noise_fn = lambda k, shape, device: noises[k]
+                out20 = model(fs["x2d"].cuda(), None, input_2d_flip=fs["x2f"].cuda()).cpu()
+            pt, diffs, d, frac, worst = g19_compare(out20, z, fs["x2d"])
+            emit({"name": f"g19_P20_T10_{prec}", "B": 1, "P": 20, "T": T_FULL, "precision": prec,
+                  "against": "tests/golden/g19_metric_config.npz (the reference's own run of BASELINE configs[2])",
+                  "oracle_sha256": None, "pointwise_max_abs_m_on_stored_trajectories": pt,
+                  "mpjpe_mm_abs_diff_per_step": {k: v.tolist() for k, v in diffs.items()},
+                  "mpjpe_mm_abs_diff_max": {**{k: float(v.max()) for k, v in diffs.items()}, "J-Agg": d},
+                  "j_agg_same_picks_mm_abs_diff_max": d, "j_agg_fraction_of_joints_with_different_pick": frac,
+                  "j_agg_largest_2d_margin_m_among_different_picks": worst,
+                  "north_star_1e-4mm_met_fraction_of_step_protocol_pairs":
+                      sum(int((v <= 1e-4).sum()) for v in diffs.values()) / sum(v.numel() for v in diffs.values())})
     if out_path:
         from pafuse_amd._lib import kernel_source_digest
         doc = {"what": "HIP path vs CPU oracle (oracle/d3dp_oracle.py, pinned to the reference by tests/golden) on the GPU tests' own "

@@ -22,13 +22,14 @@ from tests.test_hip_parity import _assert_mpjpe_parity
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 T_FULL = 10
-CHECKED = tuple(range(20)) + (83, 159)   # hypotheses the oracle re-computes: ALL of the P=20 run (the metric's own
-#                                          configuration, every protocol reduces over them) and two from the far shards
+CHECKED = (0, 7, 19, 83, 159)       # hypotheses the oracle re-computes live (the first three lie inside the P=20 run);
+#                                     ALL 20 hypotheses of the P=20 run are checked against the reference's own output
+#                                     (golden G19, test_g19_metric_config_vs_reference)
 
 
 def fullsize_case():
-    """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on 22 of its hypotheses, all ten
-    steps (about five minutes of host CPU).  Shared by the tests below and tests/reports/parity_report.py."""
+    """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on five of its hypotheses, all ten
+    steps (about a minute of host CPU).  Shared by the tests below and tests/reports/parity_report.py."""
     from __graft_entry__ import make_model
     model, sd = make_model(160, T_FULL, seed=51)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
@@ -40,7 +41,7 @@ def fullsize_case():
     return dict(model=model, sd=sd, x2d=x2d, x2f=x2f, noises=noises, out=out, ref=ref)
 
 
-FULLSIZE_SELECTIONS = {"fullsize_P20_T10_bf16x3": slice(0, 20), "fullsize_P20plus2of160_T10_bf16x3": slice(0, 22)}
+FULLSIZE_SELECTIONS = {"fullsize_3of20_T10_bf16x3": slice(0, 3), "fullsize_5of160_T10_bf16x3": slice(0, 5)}
 
 
 @pytest.fixture(scope="module")
@@ -92,17 +93,70 @@ def test_p20_t10_equals_its_halves_and_the_p160_prefix(full160):
 
 
 def test_full_size_trajectories_vs_oracle(full160):
-    """the oracle on ALL 20 hypotheses of the P=20 run (the metric's configuration: the aggregation protocols reduce over
-    exactly these) and on {83, 159} of the P=160 run, all ten steps: pointwise 1e-5, and the four MPJPE protocols within
-    the per-case bounds."""
+    """the oracle on hypotheses {0, 7, 19} (inside the P=20 run) and {83, 159} of the P=160 run, all ten steps:
+    pointwise 1e-5, and the four MPJPE protocols over the checked hypotheses within the per-case bounds."""
     out = full160["out"][:, :, list(CHECKED)].cpu()
     ref = full160["ref"]
     assert out.shape == ref.shape == (1, T_FULL, len(CHECKED), 27, 134, 3)
     d = (out - ref).abs()
     assert float(d.max()) <= 1e-5, [float(d[:, k].max()) for k in range(T_FULL)]
     target = orc.center_pose_parts(gu.synthetic_target_3d(1))
-    for case, sel in FULLSIZE_SELECTIONS.items():      # the P=20 run alone, then with the two far hypotheses
-        _assert_mpjpe_parity(out[:, :, sel], ref[:, :, sel].contiguous(), target, full160["x2d"], case)
+    for case, sel in FULLSIZE_SELECTIONS.items():      # the P=20 members alone, then all five
+        _assert_mpjpe_parity(out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, full160["x2d"], case)
+
+
+def g19_compare(out20, z, x2d):
+    """HIP predictions [1,10,20,27,134,3] of the metric's configuration against golden G19 (the REFERENCE's own run of it):
+    (pointwise max |d| on the stored trajectories, {protocol: |dMPJPE| per step in mm} for J-Best / P-Best / P-Agg,
+    J-Agg |d| on the joints where both pick the same hypothesis, fraction of different picks, largest 2-D margin there)."""
+    from tests.test_hip_parity import _j_agg_parts, _mpjpe_report
+    target = orc.center_pose_parts(gu.synthetic_target_3d(1))
+    sub = [int(i) for i in z["sub"]]
+    pt = float((out20[:, :, sub] - z["out_sub"]).abs().max())
+    got = _mpjpe_report(out20, target, x2d)
+    diffs = {k: (got[k] - z["mpjpe_mm"][i]).abs() for i, k in enumerate(("J-Best", "P-Best", "P-Agg"))}
+    pick, e3, margin = _j_agg_parts(out20, target, x2d)
+    same = pick == z["jagg_pick"].long()
+    n = same.sum(dim=(0, 2, 3)).clamp(min=1)
+    d = float((((e3 - z["jagg_e3"]) * same).sum(dim=(0, 2, 3)) / n).abs().max()) * 1000
+    flipped = ~same
+    worst = float(torch.maximum(margin, z["jagg_margin"])[flipped].max()) if bool(flipped.any()) else 0.0
+    return pt, diffs, d, float(flipped.double().mean()), worst
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_g19_metric_config_vs_reference(full160, precision):
+    """BASELINE configs[2] - the configuration the metric is quoted on (B=1, P=20, T=10, flip-TTA) - against the output
+    of the REFERENCE itself on the same weights, inputs and noise (golden G19, made by tests/golden/make_golden.py from
+    /root/reference): three whole trajectories pointwise, and all four MPJPE protocols over ALL 20 hypotheses at every
+    step, within 1.25 x the committed measurement of this very comparison.  The golden was computed on the build
+    container's CPU; the reference's fp32 arithmetic itself differs between that host and the GPU box's (up to 1.6e-3 mm at
+    two timesteps, profiles/r03_host_variation.json), which is what these bounds contain - the oracle run on THIS box
+    agrees with the HIP path to 3.7e-4 mm (test_full_size_trajectories_vs_oracle, test_loop_vs_oracle_mpjpe)."""
+    from tests.test_hip_parity import PARITY_LINES, parity_bounds
+    z = load_golden("g19_metric_config.npz")
+    assert gu.sha256_of(full160["sd"]) == z["sha"].numpy().tobytes()
+    if precision == "bf16x3":
+        out20 = full160["out"][:, :, :20].cpu()        # (bit-equal to a P=20 run: test_p20_t10_equals_its_halves...)
+    else:
+        from __graft_entry__ import make_model
+        model, _ = make_model(20, T_FULL, seed=51)
+        model.precision = precision
+        noises = [n[:, :20].contiguous() for n in full160["noises"]]
+        model.noise_fn = lambda k, shape, device: noises[k]
+        out20 = model(full160["x2d"].to(DEV), None, input_2d_flip=full160["x2f"].to(DEV)).cpu()
+    pt, diffs, d, frac, worst = g19_compare(out20, z, full160["x2d"])
+    assert pt <= 2e-5, pt       # (measured 8.5e-6: 4/5 of it is the two hosts' difference)
+    case = f"g19_P20_T10_{precision}"
+    bounds, _ = parity_bounds(case, None)              # a golden comparison: nothing about this box' CPU enters
+    met = sum(int((v <= 1e-4).sum()) for v in diffs.values())
+    PARITY_LINES.append(f"{case} (vs the reference's own run): |dMPJPE| max mm " +
+                        ", ".join(f"{k} {float(v.max()):.2e} (<= {bounds[k]:.2e})" for k, v in diffs.items()) +
+                        f", J-Agg same picks {d:.2e} (<= {bounds['J-Agg']:.2e}), different picks {frac:.1e} of joints; "
+                        f"north_star 1e-4 mm met at {met} of {sum(v.numel() for v in diffs.values())} (step, protocol) pairs")
+    for k, v in diffs.items():
+        assert v.max() <= bounds[k], (k, float(v.max()), bounds[k])
+    assert d <= bounds["J-Agg"] and frac <= 2e-3 and worst <= 1e-4, (d, bounds["J-Agg"], frac, worst)
 
 
 # ------------------------------------------------------------------------------ index stages, bit for bit (golden G6)
@@ -308,23 +362,27 @@ def test_grouped_launches_equal_part_by_part_launches():
     assert torch.equal(grouped, part_by_part)
 
 
-def test_bench_two_rank_rehearsal_on_one_gpu():
+def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     """bench.py's N > 1 code path (rank census, hypothesis sharding, the all-gather and its timing, max-over-ranks
     clock) run as two real ranks under torch.distributed.run - sharing this box's single GPU over gloo, which is a
-    rehearsal of the code path, never a performance number (the line says so)."""
+    rehearsal of the code path, never a performance number (the line says so).  The gathered predictions of the last
+    step must EQUAL, bit for bit, what ONE process computes for all P hypotheses from the same seed: every rank draws
+    the full-P noise and keeps its slice, the gather puts the slices back in hypothesis order."""
     import json
     import os
     import socket
     import subprocess
     import sys
+    from __graft_entry__ import make_model
     from tests.conftest import ROOT
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    dump = str(tmp_path / "gathered.pt")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
            "--single-device", "--steps", "1", "--warmup", "1", "--proposals", "2", "--timesteps", "2",
-           "--no-cpu-baseline", "--no-roofline"]
+           "--no-cpu-baseline", "--no-roofline", "--dump-output", dump]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -332,4 +390,14 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["P_local_per_rank"] == [2, 2]
     assert line["config"]["P_total"] == 4 and line["allgather_ms"] is not None and line["allgather_ms"] > 0
+    assert line["gather_copy_ms"] is not None and line["gather_copy_ms"] <= line["allgather_ms"] * 1.5 + 1.0
     assert line["scaling"] == "weak" and line["value"] > 0 and line["config"]["single_device_rehearsal"] is True
+    # the same job in ONE process: same weights (seed 51), same generator seed, the second forward (warm-up + 1 step)
+    model, _ = make_model(4, 2, seed=51)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    torch.manual_seed(1234)
+    for _ in range(2):
+        single = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    gathered = torch.load(dump)
+    assert gathered.shape == single.shape == (1, 2, 4, 27, 134, 3)
+    assert torch.equal(gathered, single.cpu())

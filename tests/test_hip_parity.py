@@ -59,11 +59,16 @@ def parity_bounds(case, ref):
     e = entries.get(case)
     if e is None:
         pytest.fail(f"{PARITY_REPORT} has no case '{case}': regenerate it with tests/reports/parity_report.py on the GPU box")
-    if e["oracle_sha256"] != tensor_sha256(ref):
+    if ref is not None and e["oracle_sha256"] != tensor_sha256(ref):
         return {k: BLANKET_TOL_MM for k in PROTOCOLS}, False
     m = dict(e["mpjpe_mm_abs_diff_max"])
     m["J-Agg"] = e["j_agg_same_picks_mm_abs_diff_max"]
-    return {k: min(BLANKET_TOL_MM, max(BOUND_FACTOR * m[k], BOUND_FLOOR_MM)) for k in PROTOCOLS}, True
+    # ref None: the case compares with a committed golden made on ANOTHER host (G19: the reference on the build container's
+    # Xeon).  The reference's own fp32 result moves between x86 hosts by more than the HIP path differs from the oracle on
+    # one host (profiles/r03_host_variation.json: up to 1.6e-3 mm at the steps t = 799 and t = 599), so the blanket bound
+    # does not apply there - only 1.25 x the committed measurement of that very comparison
+    cap = BLANKET_TOL_MM if ref is not None else float("inf")
+    return {k: min(cap, max(BOUND_FACTOR * m[k], BOUND_FLOOR_MM)) for k in PROTOCOLS}, True
 
 
 def _seeded(shape, seed, scale=1.0):
@@ -366,11 +371,14 @@ def loop_case(B, P, T, precision):
     noises = gu.synthetic_noises(B=B, P=P, n=T, seed=3)
     model.noise_fn = lambda k, shape, device: noises[k]
     out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
-    ref = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    if (B, P, T) not in _LOOP_ORACLE:       # the oracle does not depend on the HIP path's product mode
+        _LOOP_ORACLE[(B, P, T)] = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    ref = _LOOP_ORACLE[(B, P, T)]
     return f"loop_B{B}_P{P}_T{T}_{precision}", out, ref, orc.center_pose_parts(gu.synthetic_target_3d(B)), x2d
 
 
 LOOP_CASES = [(1, 5, 5), (2, 3, 2)]
+_LOOP_ORACLE = {}
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])

@@ -251,3 +251,19 @@ def test_g13_d3dp_train_forward_loss_and_gradient_statistics():
         scale = float(ref[1]) + 1e-12                     # the gradient's L2 norm
         assert abs(float(got[1] - ref[1])) <= 1e-4 * scale, (k, got[1], ref[1])
         assert torch.allclose(got[2:], ref[2:], rtol=1e-3, atol=1e-5 * scale), k
+
+
+def test_g19_oracle_equals_the_reference_on_the_metric_configuration():
+    """golden G19 = the reference's own run of BASELINE configs[2] (P=20, T=10, flip-TTA): the oracle re-computes the three
+    stored hypotheses through all ten steps (a hypothesis' trajectory depends on nothing but its own noise draws) and
+    must reproduce them (bit for bit here; atol slack for another host BLAS)."""
+    from tests.golden.state_template import d3dp_template
+    z = load_golden("g19_metric_config.npz")
+    sd = gu.seeded_state_dict(d3dp_template(), seed=51)
+    assert gu.sha256_of(sd) == z["sha"].numpy().tobytes()
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    sub = [int(i) for i in z["sub"]]
+    noises = [n[:, sub].contiguous() for n in gu.synthetic_noises(B=1, P=160, n=10, seed=160)]
+    out = orc.ddim_sample(sd, x2d, noises, 10, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    assert out.shape == z["out_sub"].shape == (1, 10, 3, 27, 134, 3)
+    assert torch.allclose(out, z["out_sub"], rtol=0, atol=2e-6), (out - z["out_sub"]).abs().max()

@@ -1,4 +1,5 @@
-"""world_size-2 gloo test (CPU) of the N>1 path: shard ranges, the single all-gather, ragged shards."""
+"""gloo tests (CPU) of the N>1 path at world sizes 2 and 8: shard ranges, the single all-gather, ragged shards - the
+gathered tensor must EQUAL the unsharded one, element for element (values, not shapes)."""
 import os
 import socket
 
@@ -50,6 +51,20 @@ def test_all_gather_world2(P):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, P, q)) for r in range(2)]
     [p.start() for p in procs]
     res = [q.get(timeout=120) for _ in range(6)]
+    [p.join(timeout=60) for p in procs]
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (2, 3, P, 4, 5, 3) for _, _, shape in res)
+
+
+@pytest.mark.parametrize("P", [16, 21])
+def test_all_gather_world8(P):
+    """the node's own world size (8 ranks): even (P=16: 2 per rank) and ragged (P=21: five ranks carry 3) shards"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, P, q)) for r in range(8)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=300) for _ in range(24)]
     [p.join(timeout=60) for p in procs]
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (2, 3, P, 4, 5, 3) for _, _, shape in res)

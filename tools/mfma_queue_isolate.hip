@@ -108,25 +108,28 @@ struct Bufs {
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 300;
-    const int64_t M = 25920;
+    // victim rows: 25920 fills every CU with victim workgroups (partners only overlap at its edges); 5184 (the P = 8
+    // denoiser of tests/cabi/queue_concurrency.c: 369 workgroups) leaves room for the partner's waves on the SAME CUs
+    const int64_t M = argc > 2 ? atoll(argv[2]) : 25920;
+    const int64_t MP = 25920;   // partner kernels keep their size
     const int N = 1152, K = 384;
     Bufs b{};
-    CK(hipMalloc(&b.A, M * K * 4)); CK(hipMalloc(&b.A2, M * K * 4)); CK(hipMalloc(&b.W, (size_t)N * K * 4));
-    CK(hipMalloc(&b.bias, N * 4)); CK(hipMalloc(&b.out, M * N * 4)); CK(hipMalloc(&b.ref, M * N * 4)); CK(hipMalloc(&b.out2, M * N * 4));
+    CK(hipMalloc(&b.A, MP * K * 4)); CK(hipMalloc(&b.A2, MP * K * 4)); CK(hipMalloc(&b.W, (size_t)N * K * 4));
+    CK(hipMalloc(&b.bias, N * 4)); CK(hipMalloc(&b.out, MP * N * 4)); CK(hipMalloc(&b.ref, MP * N * 4)); CK(hipMalloc(&b.out2, MP * N * 4));
     CK(hipMalloc(&b.Ws, (size_t)N * K * 6)); CK(hipMalloc(&b.Ws2, (size_t)N * K * 6));
-    CK(hipMalloc(&b.qkv, M * N * 4)); CK(hipMalloc(&b.o, M * K * 4));
+    CK(hipMalloc(&b.qkv, MP * N * 4)); CK(hipMalloc(&b.o, MP * K * 4));
     CK(hipMalloc(&b.scratch, 1 << 22)); CK(hipMalloc(&b.copy_src, 64 << 20)); CK(hipMalloc(&b.copy_dst, 64 << 20));
     CK(hipMalloc(&b.loop_out, 1 << 22)); CK(hipMalloc(&b.loop_ref, 1 << 22)); CK(hipMalloc(&b.pl_out, 1 << 22));
     CK(hipMalloc(&b.rnd, 16384 * 4)); CK(hipMalloc(&b.cnt, 4));
     {
-        std::vector<float> h((size_t)M * N);
+        std::vector<float> h((size_t)MP * N);
         srand(1);
         for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
-        CK(hipMemcpy(b.A, h.data(), M * K * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(b.A2, h.data() + 12345, M * K * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.A, h.data(), MP * K * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.A2, h.data() + 12345, MP * K * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(b.W, h.data() + 777, (size_t)N * K * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(b.bias, h.data() + 99, N * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(b.qkv, h.data(), M * N * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.qkv, h.data(), MP * N * 4, hipMemcpyHostToDevice));
         std::vector<uint32_t> r(16384);
         auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u >> 16; };
         for (auto& v : r) v = bf((float)rand() / RAND_MAX * 2.f - 1.f) | (bf((float)rand() / RAND_MAX * 2.f - 1.f) << 16);
@@ -135,20 +138,21 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(split_weights_kernel<32>, dim3((unsigned)(((int64_t)N * (K / 8) + 255) / 256)), dim3(256), 0, 0, b.W, b.Ws, N, K);
     hipLaunchKernelGGL(split_weights_kernel<32>, dim3((unsigned)(((int64_t)N * (K / 8) + 255) / 256)), dim3(256), 0, 0, b.W, b.Ws2, N, K);
     CK(hipDeviceSynchronize());
-    hipStream_t sA, sB;
+    hipStream_t sA, sB, sC;
     CK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&sC, hipStreamNonBlocking));
 
     GemmParams g{};
     g.A = b.A, g.W = b.W, g.bias = b.bias, g.out = b.out, g.M = M, g.N = N, g.K = K, g.Wsplit = b.Ws;
     GemmParams g2 = g;
-    g2.A = b.A2, g2.out = b.out2, g2.Wsplit = b.Ws2;
+    g2.A = b.A2, g2.out = b.out2, g2.Wsplit = b.Ws2, g2.M = MP;
     AttnParams at{};  // body spatial attention on its own qkv buffer
-    at.qkv = b.qkv, at.o = b.o, at.nseq = M / 24, at.L = 24, at.C = 384, at.heads = 8, at.d = 48;
+    at.qkv = b.qkv, at.o = b.o, at.nseq = MP / 24, at.L = 24, at.C = 384, at.heads = 8, at.d = 48;
     at.group = 1, at.group_stride = 24, at.seq_stride = 0, at.tok_stride = 1, at.scale = 0.144f;
 
     using T44 = GemmTile<4, 1, 4>;
     using T42 = GemmTile<4, 1, 2>;
-    const int LOOP_BLOCKS = 2048;
+    const int LOOP_BLOCKS = M >= 25920 ? 2048 : 384;
     struct Victim { const char* name; int id; };
     const Victim victims[] = {{"V0 split GEMM gemm_kernel<4,1,4,BF16=2>", 0}, {"V1 rounded-bf16 GEMM gemm_kernel<4,1,2,BF16=1>", 1},
                               {"V2 bare 32x32x16 bf16 loop", 2}, {"V3 bare 16x16x32 bf16 loop", 3}, {"V4 fp32 GEMM gemm_kernel<4,1,2>", 4}};
@@ -166,7 +170,10 @@ int main(int argc, char** argv) {
     struct Partner { const char* name; int id; };
     const Partner partners[] = {{"none", 0}, {"attention attn_kernel<32,48,4> (f32 16x16x4 MFMA)", 1}, {"VALU spin", 2}, {"LDS spin", 3},
                                 {"streaming copy", 4}, {"bare f32 32x32x2 MFMA loop", 5}, {"bare f32 16x16x4 MFMA loop", 6},
-                                {"bare bf16 32x32x16 MFMA loop", 7}, {"second split GEMM (own buffers)", 8}};
+                                {"bare bf16 32x32x16 MFMA loop", 7}, {"second split GEMM (own buffers)", 8},
+                                // three hardware queues, the mix of one denoiser chain: attention on B, another kernel on C
+                                {"3 queues: attention + second split GEMM", 9}, {"3 queues: attention + VALU spin", 10},
+                                {"3 queues: attention + streaming copy", 11}};
     auto launch_partner = [&](int id, hipStream_t s) {
         switch (id) {
             case 1: {
@@ -181,10 +188,11 @@ int main(int argc, char** argv) {
             case 5: hipLaunchKernelGGL(mfma_loop<2>, dim3(LOOP_BLOCKS), dim3(256), 0, s, b.pl_out, b.rnd, 1500); break;
             case 6: hipLaunchKernelGGL(mfma_loop<3>, dim3(LOOP_BLOCKS), dim3(256), 0, s, b.pl_out, b.rnd, 1500); break;
             case 7: hipLaunchKernelGGL(mfma_loop<0>, dim3(LOOP_BLOCKS), dim3(256), 0, s, b.pl_out, b.rnd, 6000); break;
-            case 8: { GemmParams p = g2; p.bf16 = 2; hipLaunchKernelGGL((gemm_kernel<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>), dim3((unsigned)((M + 127) / 128 * (N / 128))), dim3(256), T44::STAGE_FLOATS_SPLIT * 4, s, p); break; }
+            case 8: { GemmParams p = g2; p.bf16 = 2; hipLaunchKernelGGL((gemm_kernel<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>), dim3((unsigned)((MP + 127) / 128 * (N / 128))), dim3(256), T44::STAGE_FLOATS_SPLIT * 4, s, p); break; }
             default: break;
         }
     };
+    printf("victim rows M = %ld; ", (long)M);
     printf("rounds per cell: %d   (a cell = launches of the victim whose output differs from its solo result / words that differ)\n", rounds);
     for (const Victim& v : victims) {
         launch_victim(v.id, sA, true);
@@ -200,10 +208,14 @@ int main(int argc, char** argv) {
                 CK(hipMemsetAsync(b.cnt, 0, 4, sA));
                 CK(hipStreamSynchronize(sA));
                 // partner first (two launches keep queue B busy across the victim's lifetime), victim in the middle
-                launch_partner(pt.id, sB);
+                const int idB = pt.id >= 9 ? 1 : pt.id, idC = pt.id == 9 ? 8 : (pt.id == 10 ? 2 : (pt.id == 11 ? 4 : 0));
+                launch_partner(idB, sB);
+                launch_partner(idC, sC);
                 launch_victim(v.id, sA, false);
-                launch_partner(pt.id, sB);
-                CK(hipStreamSynchronize(sA)); CK(hipStreamSynchronize(sB));
+                launch_partner(idB, sB);
+                launch_partner(idC, sC);
+                launch_partner(idB, sB);
+                CK(hipStreamSynchronize(sA)); CK(hipStreamSynchronize(sB)); CK(hipStreamSynchronize(sC));
                 hipLaunchKernelGGL(diff_count, dim3(1024), dim3(256), 0, sA, out, ref, words, b.cnt);
                 unsigned c = 0;
                 CK(hipMemcpyAsync(&c, b.cnt, 4, hipMemcpyDeviceToHost, sA));
