@@ -12,11 +12,14 @@ sharded (weak scaling: P = 20*N, 20 per rank) and every step ends with the singl
 per-rank predictions.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family (the linear-layer GEMMs: `gemm_kernel`, and in the default split-precision
-                mode the grids that hold the same layer of all three parts, `grouped_bias_kernel` / `grouped_rowln_kernel`):
-                algorithmic FLOPs of the GEMM launches of one flip-TTA denoiser pass (192 part by part; 128 when proj,
-                fc1 and fc2 are grouped) divided by their HIP-event time (launched back to back on the stream torch
-                uses), against 416.7 TFLOP/s (bf16 matrix peak / 6 products) or the 157.3 TFLOP/s f32 matrix peak.
+  roofline      the dominant kernel family, the linear-layer GEMMs (`gemm_kernel` / `gemm_dma_kernel`; with --streams 0
+                the single-stream schedule's shared grids `grouped_bias_kernel` / `grouped_rowln_kernel`): algorithmic
+                FLOPs of the GEMM launches of one flip-TTA denoiser pass (192 part by part; 128 when proj, fc1 and fc2
+                are grouped) divided by their HIP-event time, launched back to back on the stream torch uses, against
+                416.7 TFLOP/s (bf16 matrix peak / 6 products) or the 157.3 TFLOP/s f32 matrix peak.  The timed loop runs
+                the three parts on three streams (queues), where a kernel's own duration is not observable (kernels
+                of different queues share the CUs); the replay runs the SAME kernels of the SAME launches one after
+                the other, which is the kernel-quality number, and `roofline_loop` is what the overlap makes of it.
                 `by_layer`: each of the four layer kinds replayed alone (pafuse_d3dp_replay_layers), so the line shows
                 which kernel of the family sits where (qkv / proj+LN / fc1+GELU / fc2+LN).
   roofline_loop the same fraction for the whole timed loop (2*T*69.38 GFLOP per hypothesis, everything included).
@@ -162,6 +165,8 @@ def main():
         fence()
         copy_ms = round((time.perf_counter() - t0) / 5 * 1e3, 3)
     value = B * P_total / sec_per_step
+    # HIP streams (hardware queues) the library spread one rank's loop over
+    lanes = _lib.check(_lib.load().pafuse_d3dp_lanes(C.byref(model.config_struct(True)), B, P_local, args.streams))
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
     dtype_label = {"f32": "f32",
@@ -185,6 +190,7 @@ def main():
                    "single_device_rehearsal": bool(args.single_device),
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
+        "streams": lanes,
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
         "allgather_ms": gather_ms, "allgather_ms_note": "collective + the one layout pass, max over ranks", "gather_copy_ms": copy_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
@@ -201,6 +207,10 @@ def main():
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         stream = torch.cuda.current_stream(dev)
         reps = 3
+        # the replay launches what the timed loop launched: part by part when the loop ran on side streams, the shared
+        # grids of the single-stream schedule otherwise (pafuse_set_grouped_launches: the library's process-wide option)
+        per_part = lanes > 1 or args.dtype != "bf16x3"
+        was_grouped = lib.pafuse_set_grouped_launches(0 if per_part else 1)
         flops = C.c_double(0.0)
         launches = _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
                                                            stream.cuda_stream, C.byref(flops)))       # warm-up
@@ -219,7 +229,10 @@ def main():
         # the same for each layer kind alone (pafuse_d3dp_replay_layers): which kernels of the family are how far from peak
         by_layer = {}
         layer_kernel = ({1: "gemm_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
-                         8: "grouped_rowln_kernel"} if args.dtype == "bf16x3" else
+                         8: "grouped_rowln_kernel"} if not per_part else
+                        {1: "gemm_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
+                         4: "gemm_kernel (one launch per part)", 8: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)"}
+                        if args.dtype == "bf16x3" else
                         {1: "gemm_kernel", 2: "gemm_kernel<..EPI_ROWLN>", 4: "gemm_kernel", 8: "gemm_kernel<..EPI_ROWLN>"})
         for bit, name in ((1, "qkv"), (2, "proj+LN"), (4, "fc1+GELU"), (8, "fc2+LN")):
             fl = C.c_double(0.0)
@@ -237,6 +250,7 @@ def main():
             by_layer[name] = {"kernel": layer_kernel[bit], "launches": nl * reps, "avg_launch_us": round(t * 1e3 / (nl * reps), 2),
                               "achieved": round(fl.value / (t * 1e-3) / 1e12, 2),
                               "frac": round(fl.value / (t * 1e-3) / 1e12 / peak, 4)}
+        lib.pafuse_set_grouped_launches(was_grouped)
         # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
         # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
         traffic, traffic_info = None, {"traffic_source": None}
@@ -270,7 +284,11 @@ def main():
                                f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
         products = 6 if args.dtype == "bf16x3" else 1          # matrix instructions executed per useful product
-        line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: gemm_kernel, grouped_bias_kernel, grouped_rowln_kernel ({mfma})",
+        family = "gemm_kernel, gemm_dma_kernel" if per_part else "gemm_kernel, grouped_bias_kernel, grouped_rowln_kernel"
+        line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {family} ({mfma})",
+                            "schedule": (f"timed loop: {lanes} streams, one body-part denoiser per stream; this object: the same "
+                                         "launches replayed one after the other on one stream" if lanes > 1 else
+                                         "timed loop and this replay: one stream"),
                             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                             "frac": round(achieved / peak, 4), "peak_note": peak_note,
                             "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),

@@ -175,10 +175,11 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights *w, const float *x2d, co
  * `aux_streams` (may be NULL / n_aux 0): extra HIP streams; a step's work is cut into (part, hypothesis-group) lanes,
  * one stream each, groups = (n_aux + 1) / parts (>= 1): 2 aux streams = the three parts side by side (fastest
  * measured; more lanes cost more in small launches than they gain in overlap).  Events are created and destroyed
- * inside the call only when aux streams are given.  Aux streams are IGNORED when any part runs a bf16-MFMA mode
- * (operand_bf16 != 0): those kernels must not share the GPU with kernels of other hardware queues (erratum-like
- * behaviour of v_mfma_f32_32x32x16_bf16 under multi-queue concurrency, profiles/r02_bf16_mfma_concurrency.md);
- * pafuse_d3dp_lanes then returns 1. */
+ * inside the call only when aux streams are given.  The library must be built without packed-fp32 VALU instructions
+ * for this (as __graft_entry__.build() does, -DPAFUSE_NO_PACKED_F32): beside v_mfma_f32_32x32x16_bf16 waves of another
+ * queue a v_pk_*_f32 with a high-register src1 select returns wrong lanes on MI355X
+ * (profiles/r03_bf16_mfma_concurrency.md).  A build without that flag ignores the aux streams when any part runs a
+ * bf16-MFMA mode (operand_bf16 != 0) and pafuse_d3dp_lanes returns 1. */
 size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config *cfg, int32_t B, int32_t P);
 int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *steps, int32_t nsteps,
                        const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,

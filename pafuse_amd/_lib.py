@@ -104,11 +104,13 @@ KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/train_kernels.
 
 
 def kernel_source_digest():
-    """SHA-256 over the native sources the library is built from.  Measurements kept under profiles/ carry it, and
-    bench.py only quotes a committed counter profile whose digest equals the running tree's (the GPU box has no .git)."""
+    """SHA-256 over the native sources the library is built from and the compiler flags.  Measurements kept under
+    profiles/ carry it, and bench.py only quotes a committed counter profile whose digest equals the running tree's (the
+    GPU box has no .git)."""
     import hashlib
+    from .build_flags import HIPCC_FLAGS
     root = os.path.dirname(_HERE)
-    h = hashlib.sha256()
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
     for rel in KERNEL_SOURCES:
         h.update(rel.encode())
         with open(os.path.join(root, rel), "rb") as f:

@@ -208,6 +208,35 @@ struct GemmParams {
     unsigned long long* stamps;  // diagnostic builds (-DPAFUSE_STAMPS) only: per wave {start, loop end, end}
 };
 
+// Diagnostic builds only (-DPAFUSE_XQ_FENCE=1 acquire, 2 release, 3 both, 4 acquire + wait + barrier, 6 = 4 + release; tests/cabi/queue_concurrency.c): every wave of
+// every kernel of the denoiser chain opens with an agent-scope acquire and / or closes with an agent-scope release of its
+// own, on top of what the command processor does at kernel boundaries - the experiment that tells a cache-maintenance
+// problem between dependent kernels under multi-queue concurrency from a problem inside the kernels.  (Round 3: the
+// fences moved the failure rate - release 10x down, acquire up - but did not remove it; the cause was inside a kernel,
+// the packed-fp32 VALU forms of profiles/r03_bf16_mfma_concurrency.md.)
+#ifdef PAFUSE_XQ_FENCE
+struct XqFence {
+    __device__ __forceinline__ XqFence() {
+        if (PAFUSE_XQ_FENCE & 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (PAFUSE_XQ_FENCE & 4) {   // the consumer recipe of cdna_hip_programming.md G16: acquire, wait for it, workgroup barrier
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    __device__ __forceinline__ ~XqFence() {
+        if (PAFUSE_XQ_FENCE & 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+};
+#define PAFUSE_XQ_GUARD() XqFence xq_fence_guard
+#else
+#define PAFUSE_XQ_GUARD()
+#endif
+
 #ifdef PAFUSE_STAMPS
 __device__ __forceinline__ unsigned long long pafuse_stamp() {
     unsigned long long t;
@@ -654,6 +683,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParams p) {
+    PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_tile<WM, WN, NT, EPI, NSTAGE, TR, BF16>(p, blockIdx.x, gridDim.x, smem);
 }
@@ -1100,6 +1130,7 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
+    PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_dma_tile<WM, WN, NT, EPI, NSTAGE, ABL, BKC>(p, blockIdx.x, gridDim.x, smem);
 }
@@ -1107,9 +1138,8 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmP
 // ----------------------------------------------------------------------------------------------------------------
 // Grouped whole-row launch: the same layer (proj, or fc2) of up to GROUP_MAX independent body-part denoisers in ONE
 // grid.  Alone, each part's launch fills the 256 CUs badly - a part's 405 / 574 / 709 tiles on 512 workgroup slots run as
-// 0.79 / 1.12 / 1.38 rounds - and the bf16-MFMA kernels may not overlap on several queues
-// (profiles/r02_bf16_mfma_concurrency.md); inside one grid the hardware dispatcher hands the next tile of whichever part
-// to each CU as it frees.  Slot s owns workgroups first[s] .. first[s+1]-1 (multiples of 8, so b & 7 is still the XCD
+// 0.79 / 1.12 / 1.38 rounds; inside one grid the hardware dispatcher hands the next tile of whichever part to each CU
+// as it frees (the single-stream schedule; with side streams the parts overlap as kernels of three queues instead).  Slot s owns workgroups first[s] .. first[s+1]-1 (multiples of 8, so b & 7 is still the XCD
 // and each slot keeps its XCD-contiguous tile order; surplus workgroups return at once), most expensive tiles first.
 // Every variant is a 4-wave LDS-DMA tile on the 16-deep image with a two-stage ring, two workgroups per CU (the LN
 // epilogue of one overlaps the K loop of the other): 384 -> 64 x 384, 256 -> 64 x 256, 224 -> 128 x 224 (7 column blocks
@@ -1125,6 +1155,7 @@ struct GroupedGemmParams {
 
 template <int EPI>
 __global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemmParams g) {
+    PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     int s = 0;
@@ -1145,6 +1176,7 @@ __global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemm
 // 128 x 128 where N allows, else 128 x 64, else 128 x 96 (row-per-lane epilogue); three workgroups per CU.
 template <int EPI>
 __global__ void __launch_bounds__(256, 3) grouped_bias_kernel(const GroupedGemmParams g) {
+    PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     int s = 0;
@@ -1195,6 +1227,7 @@ __device__ __forceinline__ void attn_item(int64_t i, int64_t nseq, int heads, in
 
 template <int LP, int DP, int NW>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
+    PAFUSE_XQ_GUARD();
     constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16, ITEMS = NW / QT, LDV = DP + 4;
     constexpr int NTHR = NW * 64, C4 = DP / 4;
     static_assert(NW % QT == 0, "waves must be a multiple of the query tiles");
@@ -1382,6 +1415,7 @@ struct TimeEmbedParams {
 // workgroup, one output row per wave (coalesced weight-row reads + wave reduction).
 template <int PHASE>
 __global__ void __launch_bounds__(512) time_embed_kernel(const TimeEmbedParams p) {
+    PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.y, C = p.C;
     const int K = PHASE == 0 ? C : 2 * C, NOUT = PHASE == 0 ? 2 * C : C;
@@ -1438,6 +1472,7 @@ constexpr int EMBED_ROWS_PER_BLOCK = 8;
 constexpr int EMBED_NV = 3;  // C <= 384
 
 __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
+    PAFUSE_XQ_GUARD();
     const int lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
     const int64_t local = (int64_t)blockIdx.x * EMBED_ROWS_PER_BLOCK + (threadIdx.x >> 6) * 2 + hh;
     const bool live = local < p.nrows;  // uniform per half-wave; dead halves still take part in the shuffles
@@ -1538,6 +1573,7 @@ struct FinalizeParams {
 };
 
 __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
+    PAFUSE_XQ_GUARD();
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)p.B * p.P * p.F * p.J;
     if (e >= total) return;

@@ -436,6 +436,30 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     return b;
 }
 
+// ---- PAFUSE_DIAG builds only: a hash of every intermediate tensor of a denoiser pass, written by a tiny kernel queued right
+// behind its producer (tests/cabi/queue_concurrency.c compares the hashes of a concurrent run with the single-stream ones:
+// the FIRST slot that differs names the kernel that went wrong on right inputs)
+#ifdef PAFUSE_DIAG
+thread_local unsigned long long* g_trace = nullptr;   // device array of slots, zeroed by the caller
+thread_local int g_trace_n = 0, g_trace_i = 0;
+thread_local float* g_snap = nullptr;                 // device buffer [M*C (+ B*C)]: copy of x right behind embed_kernel,
+//                                                       then of temb taken between time_embed_kernel and embed_kernel
+__global__ void trace_hash_kernel(const uint32_t* data, int64_t words, unsigned long long* slot) {
+    unsigned long long h = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (int64_t)gridDim.x * 256)
+        h += (unsigned long long)data[i] * (2 * (unsigned long long)i + 1);      // order-independent sum
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(slot, h);
+}
+void trace(const void* buf, size_t bytes, hipStream_t s) {
+    if (!g_trace || g_trace_i >= g_trace_n) return;
+    hipLaunchKernelGGL(trace_hash_kernel, dim3(64), dim3(256), 0, s, (const uint32_t*)buf, (int64_t)(bytes / 4), g_trace + g_trace_i++);
+}
+#define PAFUSE_TRACE(buf, bytes, s) trace(buf, bytes, s)
+#else
+#define PAFUSE_TRACE(buf, bytes, s)
+#endif
+
 // one block of n independent parts: the same layer of every part in one grid where the grouped kernels apply
 // (n == 1: the plain per-part launches)
 int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = false, double* flops = nullptr,
@@ -457,6 +481,14 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
         }
         const int r = rowln ? gemm_group<true>(g, n, s) : gemm_group<false>(g, n, s);
         count(all ? 1 : n);
+        for (int i = 0; i < n; ++i) {
+            if (rowln) {
+                if (g[i].out_x) PAFUSE_TRACE(g[i].out_x, (size_t)g[i].M * g[i].N * 4, s);
+                if (g[i].out_n) PAFUSE_TRACE(g[i].out_n, (size_t)g[i].M * g[i].N * 4, s);
+            } else {
+                PAFUSE_TRACE(g[i].out, (size_t)g[i].M * g[i].N * 4, s);
+            }
+        }
         return r;
     };
     // qkv -> attention stays part by part: a part's qkv rows (119 - 197 MB at P = 20) are read back by its attention
@@ -465,7 +497,9 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
     for (int i = 0; i < n; ++i) {
         g[i] = bl[i].qkv;
         if ((layer_mask & 1) && (rc = gemm_bias(g[i], s))) return rc;
+        PAFUSE_TRACE(g[i].out, (size_t)g[i].M * g[i].N * 4, s);
         if (!gemms_only && (rc = attention(bl[i].attn, s))) return rc;
+        PAFUSE_TRACE(bl[i].attn.o, (size_t)g[i].M * bl[i].attn.C * 4, s);
     }
     if (layer_mask & 1) count(n);
     if ((rc = layer(&BlockLaunch::proj, true, 2))) return rc;
@@ -550,6 +584,7 @@ int launch_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int64_t
 }
 
 __global__ void copy_kernel(const float* src, float* dst, int64_t n) {
+    PAFUSE_XQ_GUARD();
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
@@ -561,10 +596,27 @@ __global__ void copy_kernel(const float* src, float* dst, int64_t n) {
 // ================================================================================================== C ABI
 extern "C" {
 
-const char* pafuse_version(void) { return "pafuse_hip 0.3 (gfx950, f32 MFMA + split-bf16x3 MFMA)"; }
+const char* pafuse_version(void) {
+#ifdef PAFUSE_NO_PACKED_F32
+    return "pafuse_hip 0.3 (gfx950, f32 MFMA + split-bf16x3 MFMA, no packed-fp32 VALU)";
+#else
+    return "pafuse_hip 0.3 (gfx950, f32 MFMA + split-bf16x3 MFMA, packed-fp32 VALU: bf16 modes on one stream)";
+#endif
+}
 const char* pafuse_last_error(void) { return g_err; }
 
 int pafuse_set_grouped_launches(int32_t on) { return g_grouped.exchange(on ? 1 : 0); }
+
+#ifdef PAFUSE_DIAG
+/* diagnostic builds only (not declared in include/pafuse_hip.h): hash every intermediate of the following passes of this
+ * thread into slots[0 .. n) (device memory, zeroed by the caller); returns how many slots the previous passes used */
+int pafuse_diag_trace(unsigned long long* slots, int32_t n) {
+    const int used = g_trace_i;
+    g_trace = slots, g_trace_n = n, g_trace_i = 0;
+    return used;
+}
+void pafuse_diag_snapshot(float* x_copy) { g_snap = x_copy; }
+#endif
 
 int pafuse_linear(const float* A, const float* W, const float* bias, float* out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void* stream) {
@@ -675,6 +727,9 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     PartBuffers pb;
     carve_part((char*)workspace, M, w->channels, B, pb);
     if ((rc = launch_time_embed(w, t, 0, B, pb.temb, pb.wide, s))) return rc;
+#ifdef PAFUSE_DIAG
+    if (g_snap) (void)hipMemcpyAsync(g_snap + M * w->channels, pb.temb, (size_t)B * w->channels * 4, hipMemcpyDeviceToDevice, s);
+#endif
     EmbedParams e{};
     e.x3d = x3d, e.x2d = x2d, e.x2d_flip = nullptr, e.joints = nullptr, e.perm = nullptr;
     e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb.temb;
@@ -684,6 +739,12 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
     if ((rc = check_launch("embed_kernel"))) return rc;
+    PAFUSE_TRACE(pb.temb, (size_t)B * w->channels * 4, s);
+    PAFUSE_TRACE(pb.x, (size_t)M * w->channels * 4, s);
+    PAFUSE_TRACE(pb.xn, (size_t)M * w->channels * 4, s);
+#ifdef PAFUSE_DIAG
+    if (g_snap) (void)hipMemcpyAsync(g_snap, pb.x, (size_t)M * w->channels * 4, hipMemcpyDeviceToDevice, s);
+#endif
     if ((rc = run_mixste_layers(w, pb, R, s, (debug_f32_mask() & 32) != 0))) return rc;
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((M * 3 + 255) / 256)), dim3(256), 0, s, pb.pred, out, M * 3);
     return check_launch("copy_kernel");
@@ -700,11 +761,22 @@ size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config* cfg, int32_t B, int
     return total;
 }
 
-// side streams only for the fp32 matrix cores (see pafuse_d3dp_sample)
+// Side streams beside the split-precision kernels need a library WITHOUT packed-fp32 VALU instructions: on MI355X a
+// v_pk_{add,mul,fma}_f32 whose src1 takes the high register of its pair for the low result (op_sel:[0,1,..]) returns wrong
+// lanes while a wave of another kernel on the same SIMD issues v_mfma_f32_32x32x16_bf16 (two-kernel reproducer:
+// tools/mfma_queue_isolate.hip V9.3 / V9.9 / V9.10 / V9.12; profiles/r03_bf16_mfma_concurrency.md).  hipcc's SLP vectoriser
+// emits that form in the VALU-only kernels of this file (embed, LayerNorm, epilogues); __graft_entry__.build() therefore
+// compiles the device code with the packed-fp32-ops target feature off and says so with -DPAFUSE_NO_PACKED_F32.  A build
+// without that promise keeps the bf16-MFMA modes on the caller's stream.
 static bool lanes_allowed(const pafuse_d3dp_config* cfg) {
+#if defined(PAFUSE_NO_PACKED_F32) || defined(PAFUSE_ALLOW_BF16_LANES)
+    (void)cfg;
+    return true;
+#else
     for (int i = 0; i < cfg->num_parts; ++i)
         if (cfg->part[i].operand_bf16 != 0) return false;
     return true;
+#endif
 }
 
 static int d3dp_check(const pafuse_d3dp_config* cfg, int B, int P) {
@@ -751,10 +823,8 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     // Parts are independent inside a step, and so are hypotheses: with aux streams the work of a step is cut into
     // (part, hypothesis-group) lanes, each a chain of small launches on its own stream, so that the ramp-up and
     // tail of one lane's kernels are filled by the other lanes (groups = (n_aux + 1) / parts, at least 1).
-    // NOT in the bf16-MFMA modes (operand_bf16 != 0): kernels built on v_mfma_f32_32x32x16_bf16 return sporadically
-    // wrong tiles on MI355X when kernels of OTHER hardware queues run beside them (profiles/r02_bf16_mfma_concurrency.md:
-    // reproduced on every box, with the workgroup alone on its CU, with padded MFMAs; never with one queue, never with
-    // the fp32-input MFMAs, never with the legacy 8-deep v_mfma_f32_32x32x8_bf16_1k) - those modes run on `stream` only.
+    // Without aux streams (or in a build that may hold packed-fp32 instructions, see lanes_allowed) everything runs on
+    // `stream`, block k of every part in shared grids.
     n_aux = lanes_allowed(cfg) ? n_aux : 0;
     const int n_lanes_max = 1 + (n_aux > 0 ? n_aux : 0);
     int groups = n_lanes_max / NP;

@@ -113,9 +113,8 @@ class D3DP(nn.Module):
         self.train_draw_fn = None      # callable(sample) -> (t [1] int64, noise [F,J,3]) (tests, training path)
         self.proposal_shard = None     # (lo, hi): this rank's slice of the hypothesis axis (pafuse_amd.parallel)
         self.aux_streams = None        # explicit list of torch.cuda.Stream the parts are spread over; None = two
-        self.n_aux_streams = 2         # streams per device made on first use (0: everything on the current stream);
-        #                                used by precision 'f32' only - the bf16-MFMA modes run on one stream (the
-        #                                library ignores side streams there, include/pafuse_hip.h)
+        self.n_aux_streams = 2         # streams per device made on first use (0: everything on the current stream,
+        #                                the parts' layers in grouped launches); 2 = the three parts side by side
         self._aux_by_device = {}       # shared by DataParallel replicas, keyed by device index
         self.use_graph = False         # replay the whole loop as one hipGraph (captured per input shape)
         self.max_rows_per_launch = 640  # nflip*B*P hypothesis passes per library call: larger batches are cut along

@@ -6,6 +6,8 @@
  *       -L/opt/rocm/lib -lamdhip64 -lm -o tools/bin/queue_concurrency
  *   LD_LIBRARY_PATH=pafuse_amd ./tools/bin/queue_concurrency <mode 0|1|2> [depth] [rounds] [streams]
  * Prints "<bad> of <n> concurrent outputs differ".  Exit code 0 always (a measurement, not a test). */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <stdint.h>
@@ -98,7 +100,16 @@ int main(int argc, char** argv) {
         x2d[i] = dev_rand((size_t)B * F * J * 2, 1.0f, 0.0f), x3d[i] = dev_rand(n_out, 1.0f, 0.0f);
         CK(hipMalloc((void**)&out[i], n_out * 4)); CK(hipMalloc((void**)&ref[i], n_out * 4));
         nbytes = pafuse_mixste2_workspace_bytes(&w[i], B, P);
-        CK(hipMalloc(&ws[i], nbytes));
+    }
+    /* the three workspaces in ONE arena, each between two guard zones of a known pattern: a kernel that writes outside its
+     * own workspace either lands in a neighbour's buffers (wrong results only while that neighbour is in flight, i.e. only
+     * under concurrency) or in a guard, which is checked at the end */
+    const size_t GUARD = (size_t)8 << 20, slot = (nbytes + 255) / 256 * 256;
+    char* arena;
+    CK(hipMalloc((void**)&arena, 4 * GUARD + 3 * slot));
+    CK(hipMemset(arena, 0xAB, 4 * GUARD + 3 * slot));
+    for (int i = 0; i < 3; ++i) {
+        ws[i] = arena + GUARD + i * (slot + GUARD);
         CK(hipMemset(ws[i], 0xff, nbytes));     /* NaN-poisoned workspace */
     }
     CK(hipDeviceSynchronize());
@@ -117,8 +128,99 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < n_out; ++k) finite &= isfinite(h0[k]) != 0;
         if (!finite) printf("copy %d: non-finite reference output\n", i);
     }
+    /* with a -DPAFUSE_DIAG build of the library on LD_LIBRARY_PATH: hash every intermediate tensor of every pass and report,
+     * for each wrong output, the first kernel output that differs from the single-stream pass (its inputs were still right) */
+    typedef int (*trace_fn)(unsigned long long*, int32_t);
+    trace_fn diag_trace = (trace_fn)dlsym(RTLD_DEFAULT, "pafuse_diag_trace");
+    typedef void (*snap_fn)(float*);
+    snap_fn diag_snap = (snap_fn)dlsym(RTLD_DEFAULT, "pafuse_diag_snapshot");
+    const size_t n_x = (size_t)B * P * F * J * C + (size_t)B * C;   /* x, then temb as embed_kernel found it */
+    float *snap_dev[3] = {0}, *snap_ref[3] = {0}, *snap_now = NULL;
+    int reported = 0;
+    enum { SLOTS = 512 };
+    unsigned long long *tr_dev[3] = {0}, *tr_ref[3] = {0}, *tr_now = NULL;
+    int n_slots = 0;
+    static int first_bad_hist[SLOTS];
+    if (diag_trace) {
+        tr_now = malloc(SLOTS * 8);
+        for (int i = 0; i < 3; ++i) {
+            CK(hipMalloc((void**)&tr_dev[i], SLOTS * 8));
+            CK(hipMemset(tr_dev[i], 0, SLOTS * 8));
+            tr_ref[i] = malloc(SLOTS * 8);
+            if (diag_snap) {
+                CK(hipMalloc((void**)&snap_dev[i], n_x * 4));
+                snap_ref[i] = malloc(n_x * 4), snap_now = snap_now ? snap_now : malloc(n_x * 4);
+                diag_snap(snap_dev[i]);
+            }
+            diag_trace(tr_dev[i], SLOTS);
+            PK(pafuse_mixste2_forward(&w[i], x2d[i], x3d[i], t, B, P, out[i], ws[i], nbytes, s[0]));
+            CK(hipStreamSynchronize(s[0]));
+            n_slots = diag_trace(NULL, 0);
+            CK(hipMemcpy(tr_ref[i], tr_dev[i], SLOTS * 8, hipMemcpyDeviceToHost));
+            if (diag_snap) CK(hipMemcpy(snap_ref[i], snap_dev[i], n_x * 4, hipMemcpyDeviceToHost));
+        }
+        printf("diagnostic library: %d traced tensors per pass (temb, x, xn, then per block: qkv, o, x, xn, hidden, x, xn)\n", n_slots);
+    }
     int bad = 0, total = 0;
     for (int r = 0; r < rounds; ++r) {
+        if (diag_trace) {
+            for (int i = 0; i < 3; ++i) CK(hipMemset(tr_dev[i], 0, SLOTS * 8));
+            CK(hipDeviceSynchronize());
+            for (int i = 0; i < 3; ++i) {
+                if (diag_snap) diag_snap(snap_dev[i]);
+                diag_trace(tr_dev[i], SLOTS);
+                PK(pafuse_mixste2_forward(&w[i], x2d[i], x3d[i], t, B, P, out[i], ws[i], nbytes, s[i % ns]));
+            }
+            diag_trace(NULL, 0);
+            CK(hipDeviceSynchronize());
+            for (int i = 0; i < 3 && diag_snap && reported < 6; ++i) {   /* what a wrong embedding looks like */
+                CK(hipMemcpy(snap_now, snap_dev[i], n_x * 4, hipMemcpyDeviceToHost));
+                if (!memcmp(snap_now, snap_ref[i], n_x * 4)) continue;
+                size_t nd = 0, first = 0, last = 0;
+                long rows_bad = 0;
+                {
+                    const size_t t0 = (size_t)B * P * F * J * C;
+                    int tb = 0;
+                    for (int c = 0; c < C; ++c) tb += memcmp(&snap_now[t0 + c], &snap_ref[i][t0 + c], 4) != 0;
+                    printf("round %d copy %d: temb as read between time_embed and embed: %d of %d elements differ", r, i, tb, C);
+                    if (tb) {
+                        printf(" (channels:");
+                        for (int c = 0; c < C; ++c) if (memcmp(&snap_now[t0 + c], &snap_ref[i][t0 + c], 4)) printf(" %d", c);
+                        printf(")");
+                    }
+                    printf("\n");
+                }
+                for (size_t m = 0; m < (size_t)B * P * F * J; ++m) {
+                    int rb = 0;
+                    for (int c = 0; c < C; ++c)
+                        if (memcmp(&snap_now[m * C + c], &snap_ref[i][m * C + c], 4)) { if (!nd) first = m * C + c; last = m * C + c; ++nd, rb = 1; }
+                    rows_bad += rb;
+                }
+                printf("round %d copy %d: x behind embed_kernel differs in %zu of %zu elements, %ld of %zu rows; first (row %zu, ch %zu) "
+                       "last (row %zu, ch %zu); first: got %.9g want %.9g", r, i, nd, n_x, rows_bad, (size_t)B * P * F * J, first / C, first % C, last / C,
+                       last % C, snap_now[first], snap_ref[i][first]);
+                /* is the wrong row another row's right value? (a wrong temb / pos / input index) */
+                {
+                    const size_t m = first / C;
+                    double dsum = 0;
+                    for (int c = 0; c < C; ++c) dsum += fabs((double)snap_now[m * C + c] - snap_ref[i][m * C + c]);
+                    printf("; mean |d| over that row %.3g; wrong channels of that row:", dsum / C);
+                    for (int c = 0; c < C; ++c) if (memcmp(&snap_now[m * C + c], &snap_ref[i][m * C + c], 4)) printf(" %d", c);
+                    printf("\n");
+                }
+                ++reported;
+            }
+            for (int i = 0; i < 3; ++i) {
+                CK(hipMemcpy(tr_now, tr_dev[i], SLOTS * 8, hipMemcpyDeviceToHost));
+                for (int k = 0; k < n_slots; ++k)
+                    if (tr_now[k] != tr_ref[i][k]) { ++first_bad_hist[k]; break; }
+            }
+            for (int i = 0; i < 3; ++i) {
+                CK(hipMemcpy(h0, ref[i], n_out * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1, out[i], n_out * 4, hipMemcpyDeviceToHost));
+                bad += memcmp(h0, h1, n_out * 4) != 0, ++total;
+            }
+            continue;
+        }
         for (int i = 0; i < 3; ++i)   /* copy i on stream i % ns: ns = 1 runs the three copies back to back on one queue */
             PK(pafuse_mixste2_forward(&w[i], x2d[i], x3d[i], t, B, P, out[i], ws[i], nbytes, s[i % ns]));
         CK(hipDeviceSynchronize());
@@ -129,5 +231,25 @@ int main(int argc, char** argv) {
     }
     printf("%s, mode %d, depth %d, %d stream(s): %d of %d concurrent outputs differ from the single-stream result\n",
            pafuse_version(), mode, depth, ns, bad, total);
+    {   /* guard zones */
+        unsigned char* hg = malloc(GUARD);
+        for (int gz = 0; gz < 4; ++gz) {
+            const char* gp = arena + gz * (slot + GUARD);
+            CK(hipMemcpy(hg, gp, GUARD, hipMemcpyDeviceToHost));
+            size_t nbad = 0, first = 0, last = 0;
+            for (size_t k = 0; k < GUARD; ++k)
+                if (hg[k] != 0xAB) { if (!nbad) first = k; last = k; ++nbad; }
+            printf("guard zone %d (%s workspace %d): %zu bytes modified", gz, gz ? "behind" : "in front of", gz ? gz - 1 : 0, nbad);
+            if (nbad) printf(" (offsets %zu .. %zu of %zu)", first, last, GUARD);
+            printf("\n");
+        }
+        free(hg);
+    }
+    if (diag_trace) {
+        printf("first differing traced tensor (slot: count):");
+        for (int k = 0; k < n_slots; ++k)
+            if (first_bad_hist[k]) printf(" %d:%d", k, first_bad_hist[k]);
+        printf("\n");
+    }
     return 0;
 }

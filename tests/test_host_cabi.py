@@ -27,6 +27,26 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.pafuse_version()
 
 
+def test_shipped_library_holds_no_packed_fp32_instructions():
+    """The build promise behind the side streams (pafuse_amd/build_flags.py): no v_pk_{add,mul,fma}_f32 anywhere in the
+    device code of the library that ships - checked on the binary, not on the flags."""
+    import subprocess
+    import tempfile
+    _built()
+    from pafuse_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin/"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, dev = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.check_call([llvm + "llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat])
+        subprocess.check_call([llvm + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev])
+        isa = subprocess.run([llvm + "llvm-objdump", "-d", dev], capture_output=True, text=True, check=True).stdout
+    assert len(re.findall(r"\bv_mfma_f32_32x32x16_bf16\b", isa)) > 100           # the right code object was read
+    packed = re.findall(r"\bv_pk_(?:add|mul|fma)_f32\b", isa)
+    assert not packed, f"{len(packed)} packed-fp32 instructions in libpafuse_hip.so"
+    assert b"no packed-fp32 VALU" in _lib.load().pafuse_version()
+
+
 def test_struct_layouts_match_header_sizes():
     """ctypes mirrors must have the C layout: check against sizes computed by the C compiler."""
     import ctypes, subprocess, tempfile

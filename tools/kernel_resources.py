@@ -12,13 +12,15 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import HIPCC_FLAGS  # noqa: E402  (the product's own flags: no packed-fp32 VALU)
+
 SRC = os.path.join(ROOT, "pafuse_amd", "csrc", "pafuse_hip.hip")
 
 
 def table(extra=(), src=SRC):
     with tempfile.TemporaryDirectory() as tmp:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-               "--cuda-device-only", "-c", src, "-o", os.path.join(tmp, "dev.o"),
+        cmd = ["/opt/rocm/bin/hipcc", *HIPCC_FLAGS, "--cuda-device-only", "-c", src, "-o", os.path.join(tmp, "dev.o"),
                "-Rpass-analysis=kernel-resource-usage", *extra]
         txt = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
     rows = []
