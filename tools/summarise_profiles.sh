@@ -14,6 +14,8 @@ python3 "$R/tools/pmc_traffic.py" "$O/fetch_counter_collection.csv" "$O/write_co
 cp "$O/stats_kernel_stats.csv" "$R/profiles/r03_kernel_stats_bench_P20_T10.csv"
 python3 "$R/tools/trace_by_grid.py" "$O/stats_kernel_trace.csv" "$N" "$SKIP" > "$R/profiles/r03_kernel_trace_by_grid.csv"
 python3 "$R/tools/pmc_mfma_util.py" "$O/mfma_counter_collection.csv" "$N" "$SKIP" > "$R/profiles/r03_pmc_mfma_util.json"
+cp "$O/stats1_kernel_stats.csv" "$R/profiles/r03_kernel_stats_bench_one_stream.csv"
+cp "$O/stats1_bench_line.json" "$R/profiles/r03_bench_line_one_stream_under_rocprof.json"
 cp "$O/train_kernel_stats.csv" "$R/profiles/r03_train_kernel_stats_B37.csv"
 cp "$O/bench_line.json" "$R/profiles/r03_bench_line.json"
 cp "$O/bench_line_f32.json" "$R/profiles/r03_bench_line_f32.json"
