@@ -58,6 +58,15 @@ typedef struct pafuse_block_weights {
      * weights, made by pafuse_split_weights from the fp32 tensors above (a cache - remake after a weight changes);
      * NULL otherwise */
     const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
+    /* split-precision mode, optional: LayerNorm folded into the GEMM that consumes it (all four set, in every block of a
+     * denoiser, or none).  With them set, qkv_ws / fc1_ws must be the images of W (.) g - the weight scaled along its
+     * input axis by norm1 / norm2's weight g - and
+     *   qkv_ls[n] = sum_k g_k W_nk,   qkv_lt[n] = sum_k beta_k W_nk + b_n     (norm1 -> qkv; fc1_* likewise with norm2)
+     * formed in fp64 and rounded once.  The whole-row kernels then emit a row's (mean, rstd) instead of the normalised
+     * row, and qkv / fc1 read the un-normalised row and apply rstd (acc - mean ls) + lt in their epilogue: the same
+     * function as LN(x) W^T + b (common/mixste.py:113-116) with one [M,C] store and one normalise pass less per
+     * whole-row launch.  pafuse_block_forward ignores them (it is handed a normalised-input-free block). */
+    const float *qkv_ls, *qkv_lt, *fc1_ls, *fc1_lt;
 } pafuse_block_weights;
 
 /* One MixSTE2 (common/mixste.py:141-210): F frames, J joints of this part, C channels, `depth` spatial +

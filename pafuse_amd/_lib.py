@@ -22,7 +22,8 @@ BLOCK_FIELDS = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
 class BlockWeights(C.Structure):
     _names = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
               "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-              "qkv_ws", "proj_ws", "fc1_ws", "fc2_ws")
+              "qkv_ws", "proj_ws", "fc1_ws", "fc2_ws",
+              "qkv_ls", "qkv_lt", "fc1_ls", "fc1_lt")
     _fields_ = [(n, C.c_void_p) for n in _names]
 
 

@@ -202,6 +202,15 @@ struct GemmParams {
     const float* head_b;
     float* out_head;
     // EPI_ROWLN_TRAIN only (training forward): y = resid + rowscale[seq(m)] * (A W^T + bias), out_pre = y
+    // LayerNorm folded into the consumer GEMM (split-precision inference only; run_blocks sets these up):
+    //   producer (EPI_ROWLN with ln_stats): the NEXT LayerNorm of the chain is not applied; the row's (mean, rstd) go to
+    //     ln_stats[m][2] and out_n is not written - one [M,C] store and one normalise pass less per whole-row launch;
+    //   consumer (EPI_BIAS with ln_in): A is the un-normalised row x, Wsplit the image of W (.) g (g = the LayerNorm's
+    //     weight, scaled along k), ln_s[n] = sum_k g_k W_nk, bias[n] = sum_k beta_k W_nk + b_n (both formed in fp64), and
+    //     out = act(rstd_m * (acc - mean_m * ln_s[n]) + bias[n])  ==  act(LN(x) W^T + b) up to rounding.
+    float* ln_stats;
+    const float* ln_in;
+    const float* ln_s;
     const float* rowscale;  // [nseq] DropPath factor of the row's sequence, or null (= 1)
     int rs_temporal, rs_J, rs_FJ;  // seq(m) = rs_temporal ? (m / rs_FJ) * rs_J + m % rs_J : m / rs_J
     float* out_pre;
@@ -286,6 +295,14 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
     const int64_t mo = (live ? m : p.M - 1) * p.N;
     const int nb = n0 + wn * NT * 32 + 4 * h;  // + 32*nt + 8*q
     if constexpr (EPI == EPI_BIAS) {
+        // folded LayerNorm (ln_in): out = rstd * acc + (-rstd * mean) * S[n] + T[n]; the lane owns the row
+        float rstd = 1.0f, nmr = 0.0f;
+        if (p.ln_in) {
+            const int64_t mm = live ? m : p.M - 1;
+            const float mean = p.ln_in[2 * mm];
+            rstd = p.ln_in[2 * mm + 1];
+            nmr = -mean * rstd;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -293,11 +310,17 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                 const int n = nb + 32 * nt + 8 * q;
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
                 f32x4 v;
+                if (p.ln_in) {
+                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[nt][4 * q + e] + b4[e];
-                    if (p.act) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[nt][4 * q + e], fmaf(nmr, s4[e], b4[e]));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e] + b4[e];
                 }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (p.act) v[e] = gelu_erf(v[e]);
                 if (live) *reinterpret_cast<f32x4*>(p.out + mo + n) = v;
             }
         PAFUSE_STAMP(2);
@@ -398,7 +421,29 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                     *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
                 }
         }
-        if (p.next_w) {
+        if (p.next_w && p.ln_stats) {
+            // the next LayerNorm is folded into the GEMM that consumes it: emit the row's statistics only (the same two
+            // fixed-order reductions layer_norm makes), no normalise pass, no out_n
+            float s = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += acc[nt][i];
+            const float mean = row_total(s, 2) * invC;
+            float qv = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float d = acc[nt][i] - mean;
+                    qv += d * d;
+                }
+            const float rstd = 1.0f / sqrtf(row_total(qv, 3) * invC + p.next_eps);
+            if (live && h == 0 && wn == 0) {
+                p.ln_stats[2 * m] = mean;
+                p.ln_stats[2 * m + 1] = rstd;
+            }
+        } else if (p.next_w) {
             layer_norm(p.next_w, p.next_b, p.next_eps, 2, 3);
             if (p.out_n && live) {
 #pragma unroll
@@ -645,31 +690,64 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
         constexpr int ST = 32 * NTH + 4;
         float* slab = smem + wave * 32 * ST;
         const int64_t mw = m0 + wm * 32;
+        // folded LayerNorm (ln_in): lane i < 32 fetches the statistics of the strip's row i now and parks (rstd, -mean rstd)
+        // in the slab's 4 pad columns behind the first barrier below, where phase 2 reads them from LDS
+        float st_a = 1.0f, st_b = 0.0f;
+        if (p.ln_in && lane < 32) {
+            const int64_t mm = mw + lane < p.M ? mw + lane : p.M - 1;
+            const float mean = p.ln_in[2 * mm];
+            st_a = p.ln_in[2 * mm + 1];
+            st_b = -mean * st_a;
+        }
 #pragma unroll
         for (int nt0 = 0; nt0 < NT; nt0 += NTH) {
             const int nth = (NT - nt0) < NTH ? (NT - nt0) : NTH;  // compile-time after unrolling
-#pragma unroll
-            for (int q = 0; q < NTH; ++q) {
-                if (q < nth) {
-                    const float bv = p.bias[n0 + (wn * NT + nt0 + q) * 32 + r];
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        float v = acc[nt0 + q][reg] + bv;
-                        if (p.act) v = gelu_erf(v);
-                        slab[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST + q * 32 + r] = v;
-                    }
-                }
-            }
-            __syncthreads();
             const int c4n = 8 * (nth == 3 ? 4 : nth);  // float4 per row segment (nth is 1, 2 or 4 by construction)
             const int rpi = 64 / c4n;
             const int row_in = lane / c4n, c4 = lane % c4n;
+            const int ncol = n0 + (wn * NT + nt0) * 32 + c4 * 4;
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.ln_in && c4 < 8 * nth) {   // this lane's column vectors of phase 2, in flight during phase 1
+                s4 = *reinterpret_cast<const f32x4*>(p.ln_s + ncol);
+                t4 = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+            }
+#pragma unroll
+            for (int q = 0; q < NTH; ++q) {
+                if (q < nth) {
+                    if (p.ln_in) {   // the row factors are applied after the transpose, where a lane owns row pieces
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            slab[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST + q * 32 + r] = acc[nt0 + q][reg];
+                    } else {
+                        const float bv = p.bias[n0 + (wn * NT + nt0 + q) * 32 + r];
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            float v = acc[nt0 + q][reg] + bv;
+                            if (p.act) v = gelu_erf(v);
+                            slab[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST + q * 32 + r] = v;
+                        }
+                    }
+                }
+            }
+            if (nt0 == 0 && p.ln_in && lane < 32) {
+                slab[lane * ST + 32 * NTH] = st_a;
+                slab[lane * ST + 32 * NTH + 1] = st_b;
+            }
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < 32 * 8 * NTH / 64; ++i) {
                 const int row = i * rpi + row_in;
                 if (row < 32 && c4 < 8 * nth && mw + row < p.M) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ST + c4 * 4);
-                    *reinterpret_cast<f32x4*>(p.out + (mw + row) * p.N + n0 + (wn * NT + nt0) * 32 + c4 * 4) = v;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ST + c4 * 4);
+                    if (p.ln_in) {
+                        const float rstd = slab[row * ST + 32 * NTH], nmr = slab[row * ST + 32 * NTH + 1];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaf(rstd, v[e], fmaf(nmr, s4[e], t4[e]));
+                            if (p.act) v[e] = gelu_erf(v[e]);
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(p.out + (mw + row) * p.N + ncol) = v;
                 }
             }
             if (nt0 + NTH < NT) __syncthreads();
@@ -1460,6 +1538,8 @@ struct EmbedParams {
     const float *n_w, *n_b;             // next LayerNorm
     float n_eps;
     float *x, *xn;  // [M,C]
+    float* stats;   // folded LayerNorm (GemmParams::ln_in of the first qkv GEMM): (mean, rstd) of row row0 + i at stats[2 i]
+    //                 instead of xn; null = write xn
     int B, P, F, J, J3, C, nflip;
     int do_clamp;
     float scale;  // (float)args.ft2d.scale: the divisor, as torch demotes the Python scalar
@@ -1539,6 +1619,13 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
             }
         }
     const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invC + p.n_eps);
+    if (p.stats) {
+        if (live && li == 0) {
+            p.stats[2 * local] = mean;
+            p.stats[2 * local + 1] = rstd;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < EMBED_NV; ++i) {
         const int c4 = li + 32 * i;

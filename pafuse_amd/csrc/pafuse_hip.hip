@@ -358,6 +358,8 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
     return o;
 }
 
+static bool ln_folded(const pafuse_mixste2_weights* w) { return w->ste[0].qkv_ls != nullptr; }
+
 int check_weights(const pafuse_mixste2_weights* w) {
     if (!w) return fail(PAFUSE_E_ARG, "null weights");
     static_assert(EMBED_NV * 128 >= 384, "embed kernel covers the widest part");
@@ -379,6 +381,15 @@ int check_weights(const pafuse_mixste2_weights* w) {
                 if (!b->qkv_ws || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)
                     return fail(PAFUSE_E_ARG, "split-precision mode needs the pre-split image of every linear weight "
                                               "(pafuse_split_weights)");
+    // a folded LayerNorm (pafuse_block_weights.qkv_ls ...) is a property of the whole denoiser: the producer of a block's
+    // statistics is the block before it
+    const bool fold = ln_folded(w);
+    for (int i = 0; i < w->depth; ++i)
+        for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]}) {
+            const int set = (b->qkv_ls != nullptr) + (b->qkv_lt != nullptr) + (b->fc1_ls != nullptr) + (b->fc1_lt != nullptr);
+            if (set != (fold ? 4 : 0)) return fail(PAFUSE_E_ARG, "folded-LayerNorm vectors must be set in every block or in none");
+        }
+    if (fold && w->operand_bf16 != 2) return fail(PAFUSE_E_ARG, "the folded LayerNorm exists in split-precision mode only");
     return PAFUSE_OK;
 }
 
@@ -402,13 +413,17 @@ struct BlockLaunch {
 
 BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
                        int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
-                       int bf16, int hidden = 0, float qk_scale = 0.f) {
+                       int bf16, int hidden = 0, float qk_scale = 0.f, bool fold = false) {
     if (hidden <= 0) hidden = 2 * C;  // mlp_ratio = 2, the PAFUSE configuration
     BlockLaunch b{};
+    // fold: the LayerNorm in front of qkv / fc1 is applied inside those GEMMs (GemmParams::ln_in); the statistics of a
+    // row live where xn would (2 floats per row at the start of the part's xn buffer - offset_rows keeps groups apart)
+    float* const stats = pb.xn;
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     GemmParams& g = b.qkv;
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
     g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws;
+    if (fold) g.A = pb.x, g.ln_in = stats, g.ln_s = bw.qkv_ls, g.bias = bw.qkv_lt;
     AttnParams& a = b.attn;
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
     a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
@@ -419,10 +434,12 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     pj.resid = pb.x, pj.out_x = pb.x, pj.out_n = pb.xn;
     pj.next_w = bw.norm2_w, pj.next_b = bw.norm2_b, pj.next_eps = 1e-6f;
     pj.bf16 = bf16, pj.Wsplit = (const uint8_t*)bw.proj_ws;
+    if (fold) pj.out_n = nullptr, pj.ln_stats = stats;
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
     GemmParams& f1 = b.fc1;
     f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = hidden, f1.K = C, f1.act = 1;
     f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
+    if (fold) f1.A = pb.x, f1.ln_in = stats, f1.ln_s = bw.fc1_ls, f1.bias = bw.fc1_lt;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
     GemmParams& f2 = b.fc2;
     f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = hidden;
@@ -432,6 +449,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     f2.next_w = tail.next_w, f2.next_b = tail.next_b, f2.next_eps = tail.next_eps;
     f2.head_w = tail.head_w, f2.head_b = tail.head_b, f2.out_head = tail.out_head;
     if (!tail.next_w) f2.out_n = nullptr;
+    if (fold && tail.next_w && !tail.out_head) f2.out_n = nullptr, f2.ln_stats = stats;   // the head keeps its own LayerNorm
     f2.bf16 = bf16, f2.Wsplit = (const uint8_t*)bw.fc2_ws;
     return b;
 }
@@ -535,7 +553,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
             t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
             bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16,
-                               w->mlp_hidden, w->qk_scale);
+                               w->mlp_hidden, w->qk_scale, ln_folded(w));
         }
         if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask))) return rc;
         for (int k = 0; k < n; ++k) {
@@ -552,7 +570,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
                 t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pbs[k].pred;
             }
             bl[k] = make_block(w->tte[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * J, F, J, (int64_t)F * J, 1, J, t,
-                               w->operand_bf16, w->mlp_hidden, w->qk_scale);
+                               w->operand_bf16, w->mlp_hidden, w->qk_scale, ln_folded(w));
         }
         if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask))) return rc;
     }
@@ -734,7 +752,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.x3d = x3d, e.x2d = x2d, e.x2d_flip = nullptr, e.joints = nullptr, e.perm = nullptr;
     e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb.temb;
     e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
-    e.x = pb.x, e.xn = pb.xn;
+    e.x = pb.x, e.xn = pb.xn, e.stats = ln_folded(w) ? pb.xn : nullptr;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
@@ -891,6 +909,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb[i].temb;
             e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
             e.x = pb[i].x, e.xn = pb[i].xn;
+            e.stats = ln_folded(w) ? pb[i].xn + row0 * w->channels : nullptr;   // where offset_rows puts this group's xn
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
             e.do_clamp = 1, e.scale = (float)cfg->scale, e.lim = (float)(1.1 * cfg->scale), e.row0 = row0, e.nrows = nrows;
             hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)),

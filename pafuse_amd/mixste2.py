@@ -106,6 +106,10 @@ class MixSTE2(nn.Module):
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
         self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA,
         #                                2 split precision "bf16x3" (fp32-equivalent, inference), 1 opt-in bf16 operands
+        self.fold_layernorm = True     # split-precision inference: norm1 / norm2 applied inside the qkv / fc1 GEMMs
+        #                                (pafuse_block_weights.qkv_ls ...: g-scaled weight images + two vectors per layer);
+        #                                False = the whole-row kernels write the normalised rows (same function, one more
+        #                                [M,C] store and normalise pass per whole-row launch)
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -120,8 +124,11 @@ class MixSTE2(nn.Module):
             return attrgetter(name)(self)
         mode = int(self.operand_bf16)
         key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode)
+        fold = mode == 2 and bool(self.fold_layernorm)
         if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
+        if fold:            # ... and so are the folded images / vectors: they also hold the LayerNorm and bias values
+            key += ("fold",) + tuple(get(n)._version for n in self._param_names if n.endswith(FOLD_SUFFIXES))
         dev = self._freqs.device
         # per device, in a dict the replicas of nn.DataParallel share with their parent (replicate() copies attributes
         # shallowly and makes fresh module objects on every forward: a per-object cache would never hit there, and every
@@ -134,7 +141,7 @@ class MixSTE2(nn.Module):
         w = _lib.MixSTE2Weights()
         images, event, stream = None, None, None
         if mode == 2:
-            images = self._split_images(get)
+            images = self._split_images(get, fold)
             stream = torch.cuda.current_stream(dev)
             event = torch.cuda.Event()
             event.record(stream)
@@ -146,14 +153,20 @@ class MixSTE2(nn.Module):
         self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
         return w
 
-    def _split_images(self, get):
+    def _split_images(self, get, fold=False):
         """Pre-split (bf16x3) images of every linear weight, made on the device by pafuse_split_weights: one uint8
-        tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct)."""
+        tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct).
+        `fold`: qkv / fc1 get the image of W (.) g and the two vectors of the folded LayerNorm (norm1 / norm2 of their
+        block, include/pafuse_hip.h pafuse_block_weights.qkv_ls): ls = W g, lt = W beta + b, formed in fp64."""
         images = {}
         for name in self._param_names:
             if not name.endswith(SPLIT_SUFFIXES):
                 continue
-            images[name] = split_image(get(name), name.endswith(("attn.proj.weight", "mlp.fc2.weight")))
+            if fold and name.endswith(tuple(FOLDED_LINEAR)):
+                stem = name[:-len("weight")]
+                images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name)
+            else:
+                images[name] = split_image(get(name), name.endswith(("attn.proj.weight", "mlp.fc2.weight")))
         return images
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -293,6 +306,10 @@ class _TrainFunction(torch.autograd.Function):
 
 
 SPLIT_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight")
+# the LayerNorm folded into a linear layer: linear weight suffix -> the norm of the same block in front of it
+FOLDED_LINEAR = {"attn.qkv.weight": "norm1", "mlp.fc1.weight": "norm2"}
+FOLD_SUFFIXES = ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.bias", "mlp.fc1.bias")
+BLOCK_FOLD = (("qkv_ls", "attn.qkv.ls"), ("qkv_lt", "attn.qkv.lt"), ("fc1_ls", "mlp.fc1.ls"), ("fc1_lt", "mlp.fc1.lt"))
 BLOCK_SPLIT = (("qkv_ws", "attn.qkv.weight"), ("proj_ws", "attn.proj.weight"), ("fc1_ws", "mlp.fc1.weight"),
                ("fc2_ws", "mlp.fc2.weight"))
 BLOCK_PARAMS = (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
@@ -323,6 +340,9 @@ def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, i
                 setattr(dst[i], field, _ptr(get(f"{prefix}.{i}.{key}"), f"{prefix}.{i}.{key}"))
             for field, key in BLOCK_SPLIT:
                 setattr(dst[i], field, split[f"{prefix}.{i}.{key}"].data_ptr() if split is not None else None)
+            for field, key in BLOCK_FOLD:       # present only when the images were made with the LayerNorm folded in
+                vec = split.get(f"{prefix}.{i}.{key}") if split is not None else None
+                setattr(dst[i], field, vec.data_ptr() if vec is not None else None)
 
 
 def split_image(weight, whole_row):
@@ -335,6 +355,20 @@ def split_image(weight, whole_row):
         _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(whole_row), img.data_ptr(),
                                             torch.cuda.current_stream(weight.device).cuda_stream))
     return img
+
+
+def folded_linear(get, name):
+    """(image, ls, lt) of the linear layer `name` (a state-dict key ending in attn.qkv.weight / mlp.fc1.weight) with the
+    LayerNorm in front of it folded in (include/pafuse_hip.h, pafuse_block_weights.qkv_ls): the split image of W (.) g
+    (one fp32 rounding per element, then split exactly), ls = W g and lt = W beta + b formed in fp64, rounded once."""
+    block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
+    weight = get(name).detach()
+    g, beta = get(f"{block}.{norm}.weight").detach(), get(f"{block}.{norm}.bias").detach()
+    bias = get(name[:-len("weight")] + "bias").detach()
+    w64 = weight.double()
+    ls = (w64 @ g.double()).float().contiguous()
+    lt = (w64 @ beta.double() + bias.double()).float().contiguous()
+    return split_image((weight * g[None, :]).contiguous(), False), ls, lt
 
 
 def fill_block_struct(dst, blk):

@@ -24,7 +24,8 @@ from typing import List
 import torch
 
 from . import _lib
-from .mixste2 import MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, sinusoid_frequencies, split_image
+from .mixste2 import (FOLDED_LINEAR, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear,
+                      sinusoid_frequencies, split_image)
 
 BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
@@ -84,6 +85,20 @@ def cached_split_image(weight, whole_row):
     return img
 
 
+def cached_folded_linear(table, name):
+    """(image, ls, lt) of a qkv / fc1 layer with its LayerNorm folded in (mixste2.folded_linear), made once per version of
+    the four tensors it is built from - the modules' own default in bf16x3 mode, so the ops return the modules' bits."""
+    block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
+    parts = (table[name], table[f"{block}.{norm}.weight"], table[f"{block}.{norm}.bias"], table[name[:-len("weight")] + "bias"])
+    key = ("fold",) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
+    hit = _image_cache.get(key)
+    if hit is None:
+        while len(_image_cache) >= _IMAGE_CACHE_MAX:
+            _image_cache.pop(next(iter(_image_cache)))
+        hit = _image_cache[key] = folded_linear(table.__getitem__, name)
+    return hit
+
+
 def _mode(precision):
     if precision not in PRECISIONS:
         raise _lib.PafuseError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
@@ -105,8 +120,12 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
     w = _lib.MixSTE2Weights()
     images = None
     if mode == 2:
-        images = {n: cached_split_image(t, n.endswith(("attn.proj.weight", "mlp.fc2.weight")))
-                  for n, t in table.items() if n.endswith(SPLIT_SUFFIXES)}
+        images = {}
+        for n, t in table.items():
+            if n.endswith(tuple(FOLDED_LINEAR)):
+                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n)
+            elif n.endswith(SPLIT_SUFFIXES):
+                images[n] = cached_split_image(t, n.endswith(("attn.proj.weight", "mlp.fc2.weight")))
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
     return w, (table, fr, images)
 

@@ -22,14 +22,14 @@ from tests.test_hip_parity import _assert_mpjpe_parity
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 T_FULL = 10
-CHECKED = (0, 7, 19, 83, 159)       # hypotheses the oracle re-computes live (the first three lie inside the P=20 run);
-#                                     ALL 20 hypotheses of the P=20 run are checked against the reference's own output
-#                                     (golden G19, test_g19_metric_config_vs_reference)
+CHECKED = tuple(range(20)) + (83, 159)   # hypotheses the oracle re-computes live: ALL 20 of the metric's P=20 run (= the first
+#                                          20 of the P=160 run, same noise) + two from the far shards.  The same 20 are also held
+#                                          against the reference's own output (golden G19, test_g19_metric_config_vs_reference)
 
 
 def fullsize_case():
-    """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on five of its hypotheses, all ten
-    steps (about a minute of host CPU).  Shared by the tests below and tests/reports/parity_report.py."""
+    """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on 22 of its hypotheses, all ten
+    steps (about a minute of host CPU at 16 threads).  Shared by the tests below and tests/reports/parity_report.py."""
     from __graft_entry__ import make_model
     model, sd = make_model(160, T_FULL, seed=51)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
@@ -41,7 +41,7 @@ def fullsize_case():
     return dict(model=model, sd=sd, x2d=x2d, x2f=x2f, noises=noises, out=out, ref=ref)
 
 
-FULLSIZE_SELECTIONS = {"fullsize_3of20_T10_bf16x3": slice(0, 3), "fullsize_5of160_T10_bf16x3": slice(0, 5)}
+FULLSIZE_SELECTIONS = {"fullsize_20of20_T10_bf16x3": slice(0, 20), "fullsize_22of160_T10_bf16x3": slice(0, 22)}
 
 
 @pytest.fixture(scope="module")
@@ -93,15 +93,15 @@ def test_p20_t10_equals_its_halves_and_the_p160_prefix(full160):
 
 
 def test_full_size_trajectories_vs_oracle(full160):
-    """the oracle on hypotheses {0, 7, 19} (inside the P=20 run) and {83, 159} of the P=160 run, all ten steps:
-    pointwise 1e-5, and the four MPJPE protocols over the checked hypotheses within the per-case bounds."""
+    """the oracle on ALL 20 hypotheses of the metric's P=20 run and {83, 159} of the P=160 run, all ten steps:
+    pointwise 1e-5, and the four MPJPE protocols (over the 20, and over all 22) within the per-case bounds."""
     out = full160["out"][:, :, list(CHECKED)].cpu()
     ref = full160["ref"]
     assert out.shape == ref.shape == (1, T_FULL, len(CHECKED), 27, 134, 3)
     d = (out - ref).abs()
     assert float(d.max()) <= 1e-5, [float(d[:, k].max()) for k in range(T_FULL)]
     target = orc.center_pose_parts(gu.synthetic_target_3d(1))
-    for case, sel in FULLSIZE_SELECTIONS.items():      # the P=20 members alone, then all five
+    for case, sel in FULLSIZE_SELECTIONS.items():      # the P=20 run's hypotheses, then all 22
         _assert_mpjpe_parity(out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, full160["x2d"], case)
 
 

@@ -287,6 +287,42 @@ def test_split_images_follow_in_place_weight_updates():
     assert torch.equal(after, other(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)))
 
 
+def test_folded_layernorm_is_the_same_function():
+    """Split-precision default: norm1 / norm2 are applied INSIDE the qkv / fc1 GEMMs (weight image of W (.) g, two vectors
+    per layer, row statistics from the producing whole-row kernel; include/pafuse_hip.h pafuse_block_weights.qkv_ls).
+    Against the same model with the fold off (the whole-row kernels write the normalised rows): the same function, i.e.
+    rounding-level differences, both equally close to the oracle; and a changed LayerNorm weight remakes the folded
+    images (they hold g)."""
+    from __graft_entry__ import make_model
+    model, sd = make_model(3, 2, seed=53)
+    x2d, x2f = gu.synthetic_inputs_2d(B=1)
+    noises = gu.synthetic_noises(B=1, P=3, n=2, seed=4)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    assert model.precision == "bf16x3"
+    parts = list(model.denoisers().values())
+    assert all(m.fold_layernorm for m in parts)
+    folded = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    for m in parts:
+        m.fold_layernorm = False
+    plain = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    ref = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    d_fold, d_plain = (folded - ref).abs(), (plain - ref).abs()
+    assert float((folded - plain).abs().max()) <= 4e-6, float((folded - plain).abs().max())
+    assert float(d_fold.max()) <= 1e-5 and float(d_plain.max()) <= 1e-5
+    assert float(d_fold.mean()) <= 1.25 * float(d_plain.mean()) + 1e-8, (float(d_fold.mean()), float(d_plain.mean()))
+    # in-place change of a LayerNorm weight: the folded images must follow
+    for m in parts:
+        m.fold_layernorm = True
+    with torch.no_grad():
+        parts[0].STEblocks[0].norm1.weight.mul_(1.5)
+        parts[0].TTEblocks[1].norm2.bias.add_(0.25)
+    sd2 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    changed = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    ref2 = orc.ddim_sample(sd2, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    assert float((changed - folded).abs().max()) > 1e-4
+    assert float((changed - ref2).abs().max()) <= 1e-5, float((changed - ref2).abs().max())
+
+
 def test_g5_p1t1_both_samplers_golden(g5):
     from __graft_entry__ import make_model
     z, _, sd = g5

@@ -332,6 +332,33 @@ int main() {
     time_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("ws-ref hands qkv split <4,1,2> s1 (r2 production)", p);
     time_ws<4, 2, 4, EPI_BIAS>("ws hands qkv <4,2,4> 128x256", p);
     time_ws<4, 2, 6, EPI_BIAS>("ws hands qkv <4,2,6> 128x384", p);
+    {   // lnfold: what the whole-row kernels save when the next LayerNorm is left to the consumer (stats only, no xn)
+        GemmParams q{};
+        q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = xo, q.out_n = xn, q.Wsplit = Wsp;
+        q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
+        GemmParams f = q;
+        f.out_n = nullptr, f.ln_stats = g_oimg ? (float*)g_oimg : xn;
+        for (int rep = 0; rep < 2; ++rep) {
+            q.M = f.M = 25920, q.N = f.N = 384, q.K = f.K = 768;
+            time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("lnfold body fc2  <2,2,6> st2 production (x and xn)", q);
+            time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("lnfold body fc2  <2,2,6> st2 stats only (x, mean, rstd)", f);
+            q.K = f.K = 384;
+            time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("lnfold body proj <2,2,6> st2 production (x and xn)", q);
+            time_dma<2, 2, 6, EPI_ROWLN, 2, 2, 0, 16>("lnfold body proj <2,2,6> st2 stats only (x, mean, rstd)", f);
+            q.M = f.M = 45360, q.N = f.N = 256, q.K = f.K = 512;
+            time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("lnfold hands fc2 <2,2,4> st2 production (x and xn)", q);
+            time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("lnfold hands fc2 <2,2,4> st2 stats only (x, mean, rstd)", f);
+            q.K = f.K = 256;
+            time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("lnfold hands proj <2,2,4> st2 production (x and xn)", q);
+            time_dma<2, 2, 4, EPI_ROWLN, 2, 2, 0, 16>("lnfold hands proj <2,2,4> st2 stats only (x, mean, rstd)", f);
+            q.M = f.M = 73440, q.N = f.N = 224, q.K = f.K = 448;
+            time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("lnfold face fc2  <4,1,7> st2 production (x and xn)", q);
+            time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("lnfold face fc2  <4,1,7> st2 stats only (x, mean, rstd)", f);
+            q.K = f.K = 224;
+            time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("lnfold face proj <4,1,7> st2 production (x and xn)", q);
+            time_dma<4, 1, 7, EPI_ROWLN, 2, 2, 0, 16>("lnfold face proj <4,1,7> st2 stats only (x, mean, rstd)", f);
+        }
+    }
     {
         GemmParams q{};
         q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = xo, q.out_n = xn, q.Wsplit = Wsp;

@@ -238,6 +238,7 @@ struct GemmParams {
     const float* rowscale;  // [nseq] DropPath factor of the row's sequence, or null (= 1)
     int rs_temporal, rs_J, rs_FJ;  // seq(m) = rs_temporal ? (m / rs_FJ) * rs_J + m % rs_J : m / rs_J
     float* out_pre;
+    float* ln_stats;    // experiment (lnfold): [M][2] row (mean, rstd) of the next LayerNorm instead of out_n
     unsigned long long* stamps;  // diagnostic builds (-DPAFUSE_STAMPS) only: per wave {start, loop end, end}
 };
 
@@ -428,7 +429,27 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                     *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
                 }
         }
-        if (p.next_w) {
+        if (p.next_w && p.ln_stats) {
+            // "fold the next LayerNorm into the next GEMM" (VERDICT r2 1c), producer side only: the row's (mean, rstd) instead of
+            // the normalised row - no normalise pass, no [M,C] store.  The consumer would multiply by a g-scaled W' and apply
+            // rstd * (acc - mean * S_n) + T_n in its epilogue.
+            float s = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += acc[nt][i];
+            const float mean = row_total(s, 2) * invC;
+            float qv = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float d = acc[nt][i] - mean;
+                    qv += d * d;
+                }
+            const float rstd = 1.0f / sqrtf(row_total(qv, 3) * invC + p.next_eps);
+            if (live && h == 0 && wn == 0) p.ln_stats[m * 2] = mean, p.ln_stats[m * 2 + 1] = rstd;
+        } else if (p.next_w) {
             layer_norm(p.next_w, p.next_b, p.next_eps, 2, 3);
             if (p.out_n_s) {  // the next linear layer's A operand as a split image (workgroup-uniform branch)
 #pragma unroll
