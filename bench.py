@@ -12,7 +12,7 @@ sharded (weak scaling: P = 20*N, 20 per rank) and every step ends with the singl
 per-rank predictions.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family, the linear-layer GEMMs (`gemm_kernel` / `gemm_dma_kernel`; with --streams 0
+  roofline      the dominant kernel family, the linear-layer GEMMs (`gemm16_kernel` / `gemm_kernel` / `gemm_dma_kernel`; with --streams 0
                 the single-stream schedule's shared grids `grouped_bias_kernel` / `grouped_rowln_kernel`): algorithmic
                 FLOPs of the GEMM launches of one flip-TTA denoiser pass (192 part by part; 128 when proj, fc1 and fc2
                 are grouped) divided by their HIP-event time, launched back to back on the stream torch uses, against
@@ -234,9 +234,9 @@ def main():
         achieved = flops.value / (ms * 1e-3) / 1e12
         # the same for each layer kind alone (pafuse_d3dp_replay_layers): which kernels of the family are how far from peak
         by_layer = {}
-        layer_kernel = ({1: "gemm_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
+        layer_kernel = ({1: "gemm16_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
                          8: "grouped_rowln_kernel"} if not per_part else
-                        {1: "gemm_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
+                        {1: "gemm16_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
                          4: "gemm_kernel (one launch per part)", 8: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)"}
                         if args.dtype == "bf16x3" else
                         {1: "gemm_kernel", 2: "gemm_kernel<..EPI_ROWLN>", 4: "gemm_kernel", 8: "gemm_kernel<..EPI_ROWLN>"})
@@ -281,16 +281,20 @@ def main():
         rows = 2 * B * P_local * 27
         mc = rows * (24 * 384 + 68 * 224 + 42 * 256)
         # (i) per token and block: qkv reads C writes 3C; proj reads o, x writes x, xn; fc1 reads C writes 2C; fc2 reads
-        #     2C, x writes x, xn = 16 C floats; 16 blocks per pass; + the 139.8 MB of weights once
-        alg_unfused = (mc * 4 * 16 * 16 + 139.8e6) / launches
+        #     2C, x writes x, xn = 16 C floats (14 with the LayerNorm folded into qkv / fc1: no xn, 8 B of statistics per
+        #     row instead); 16 blocks per pass; + the 139.8 MB of weights once
+        per_token = 14 if (args.dtype == "bf16x3" and not args.no_ln_fold) else 16
+        alg_unfused = (mc * 4 * per_token * 16 + 139.8e6) / launches
         alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
-        mfma = "v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16"
+        mfma = ("v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
+                "v_mfma_f32_32x32x16_bf16; the qkv layers v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16x3" else "v_mfma_f32_32x32x16_bf16")
         peak_note = {"f32": "dense f32-input matrix peak",
                      "bf16x3": "dense bf16 matrix peak 2500 / 6 products; the same FLOPs against the f32-input matrix "
                                f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
         products = 6 if args.dtype == "bf16x3" else 1          # matrix instructions executed per useful product
-        family = "gemm_kernel, gemm_dma_kernel" if per_part else "gemm_kernel, grouped_bias_kernel, grouped_rowln_kernel"
+        family = (("gemm16_kernel, gemm_kernel, gemm_dma_kernel" if per_part else
+                   "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype == "bf16x3" else "gemm_kernel")
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {family} ({mfma})",
                             "schedule": (f"timed loop: {lanes} streams, one body-part denoiser per stream; this object: the same "
                                          "launches replayed one after the other on one stream" if lanes > 1 else

@@ -55,8 +55,8 @@ typedef struct pafuse_block_weights {
     const float *fc1_w, *fc1_b;     /* [H,C], [H]   (H = mlp hidden width, 2C by default) */
     const float *fc2_w, *fc2_b;     /* [C,H], [C] */
     /* split-precision mode only (pafuse_mixste2_weights.operand_bf16 == 2): the pre-split images of the four linear
-     * weights, made by pafuse_split_weights from the fp32 tensors above (a cache - remake after a weight changes);
-     * NULL otherwise */
+     * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv), 1 (proj, fc2), 0 (fc1)
+     * (a cache - remake after a weight changes); NULL otherwise */
     const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
     /* split-precision mode, optional: LayerNorm folded into the GEMM that consumes it (all four set, in every block of a
      * denoiser, or none).  With them set, qkv_ws / fc1_ws must be the images of W (.) g - the weight scaled along its
@@ -140,12 +140,16 @@ int pafuse_linear(const float *A, const float *W, const float *bias, float *out,
 
 /* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K bytes
  * ([K/c][N][6c B] with c = 32 or 16: per row and K chunk, sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels'
- * LDS image; the library picks c from the shape and from `whole_row`: 1 for a weight used by a whole-row layer - attn.proj,
- * mlp.fc2 - 0 for attn.qkv, mlp.fc1 and pafuse_linear_split).  pafuse_linear_split is pafuse_linear on such an image
- * (made with whole_row = 0; act: 0 none, 1 GELU): the unit entry of the split-precision products, which replace the same
- * nn.Linear call sites (common/mixste.py:38-42,65,80). */
+ * LDS image).  `layout` names the layer the image is for - it decides c and the rotation of the sub-blocks inside a row:
+ *   0  mlp.fc1 (and pafuse_linear_split without PAFUSE_LINEAR_QKV_IMAGE): the 32x32x16-MFMA plain kernel
+ *   1  attn.proj, mlp.fc2: the whole-row kernels (c = 16 at the widths that have an LDS-DMA tile)
+ *   2  attn.qkv: the 16x16x32-MFMA kernel (pafuse_block_weights.qkv_ws must be made with layout 2)
+ * pafuse_linear_split is pafuse_linear on such an image (act: 0 none, 1 GELU, + PAFUSE_LINEAR_QKV_IMAGE when the image
+ * has layout 2): the unit entry of the split-precision products, which replace the same nn.Linear call sites
+ * (common/mixste.py:38-42,65,80). */
+#define PAFUSE_LINEAR_QKV_IMAGE 2
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K);
-int pafuse_split_weights(const float *W, int32_t N, int32_t K, int32_t whole_row, void *out, void *stream);
+int pafuse_split_weights(const float *W, int32_t N, int32_t K, int32_t layout, void *out, void *stream);
 int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, float *out, int64_t M, int32_t N,
                         int32_t K, int32_t act, void *stream);
 

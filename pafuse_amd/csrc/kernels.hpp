@@ -107,15 +107,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // The image is read as it lies: a tile's chunk is one contiguous run of BN * 6 * BKC bytes in HBM and in LDS.
 // BKC = 32 serves the plain linear layers (qkv, fc1), BKC = 16 the whole-row ones (proj, fc2), whose W' stage
 // (N = C rows) would not fit a multi-stage LDS ring at 32.
+// Third layout (M16 = 1, BKC = 32): the qkv layer runs on v_mfma_f32_16x16x32_bf16 (gemm16_tile), whose fragment read takes
+// 16 rows x 4 sub-blocks per wave instruction; that pattern is conflict-free with sub-block sb at (sb + (n >> 1)) & 3.
 constexpr int WSPLIT_ROW_BYTES = 192;  // BKC = 32
 __host__ __device__ inline size_t wsplit_bytes(int64_t N, int64_t K) { return (size_t)N * (size_t)K * 6; }
-template <int BKC = 32>
+template <int BKC = 32, int M16 = 0>
 __device__ __forceinline__ int wsplit_sub_offset(int n, int sb) {
-    static_assert(BKC == 32 || BKC == 16, "chunk depth");
+    static_assert(BKC == 32 || (BKC == 16 && !M16), "chunk depth");
+    if (M16) return ((sb + (n >> 1)) & 3) * 48;
     return BKC == 32 ? ((sb + (n >> 2)) & 3) * 48 : ((sb + (n >> 3)) & 1) * 48;
 }
 
-template <int BKC>
+template <int BKC, int M16 = 0>
 __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint8_t* out, int N, int K) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one (n, group of 8 k) per thread
     const int groups = K / 8;
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint
     const int chunk = g8 / SUBS, sb = g8 % SUBS;
     const float* src = W + (int64_t)n * K + g8 * 8;
     const bf16x8x3 s = split3(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
-    uint8_t* dst = out + ((int64_t)chunk * N + n) * ROW + wsplit_sub_offset<BKC>(n, sb);
+    uint8_t* dst = out + ((int64_t)chunk * N + n) * ROW + wsplit_sub_offset<BKC, M16>(n, sb);
     *reinterpret_cast<bf16x8*>(dst) = s.s0;
     *reinterpret_cast<bf16x8*>(dst + 16) = s.s1;
     *reinterpret_cast<bf16x8*>(dst + 32) = s.s2;
@@ -183,6 +186,7 @@ struct GemmParams {
     int N, K;
     int bf16;  // host-side only: matrix-product mode - 0 fp32 MFMA, 1 bf16-rounded operands, 2 split bf16x3 (needs Wsplit)
     const uint8_t* Wsplit;  // mode 2: the pre-split image of W (split_weights_kernel), wsplit_bytes(N, K) bytes
+    int wlayout;            // host-side only: 0 = the 32x32x16 kernels' image, 2 = the gemm16_tile (qkv) image
     int act;   // EPI_BIAS: 0 none, 1 GELU
     // EPI_ROWLN (the workgroup owns whole rows, N == BN; row-per-lane form only):  y = A W^T + bias + resid
     //   z  = post_w ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;  out_x = z
@@ -764,6 +768,169 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_kernel(const GemmParam
     PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     gemm_tile<WM, WN, NT, EPI, NSTAGE, TR, BF16>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Plain split-precision linear layer on v_mfma_f32_16x16x32_bf16 (round 3; the qkv layers):
+//   out = act(A[M,K] @ W'[N,K]^T + bias),  or with the LayerNorm folded in (p.ln_in)  act(rstd (acc - mean ls) + lt).
+//
+// The chip is power-limited under the bf16 matrix instructions, and the 16 x 16 x 32 shape costs less energy per FLOP than
+// 32 x 32 x 16 (half the accumulator traffic per MAC): the same six-product loop holds 2.1 - 2.3 GHz instead of 1.75 - 1.9
+// (tools/mfma_bf16_peak.hip, profiles/r03_mfma_shape_ab.log).  At the qkv shapes that is 3 - 10 % per launch against
+// gemm_tile<.., BF16 = 2> (profiles/r03_mfma16_plain_kernel.log); at fc1 the two are equal and fc1 stays where it was.
+// Same arithmetic per product as gemm_tile<.., BF16 = 2> (bf16 x bf16 exact in the fp32 accumulator, small terms first),
+// one rounding per 32-deep step instead of one per 16.
+// Workgroup = 4 waves, tile 128 tokens x BN columns, one 32-deep chunk per stage (register-staged, as gemm_tile):
+//   A stage : fp32 in FRAGMENT order - for every group of 16 tokens two 1 KiB blocks (o = 0, 1), block o holds for lane
+//             (c = l & 15, qd = l >> 4) the four floats k = 8 qd + 4 o .. + 3 of token c: fragment reads and staging writes
+//             are lane-linear 16-byte accesses (conflict-free without padding).
+//   W stage : the 32-deep W' image in its M16 layout as it lies ([n][192 B], sub-block sb at (sb + (n >> 1)) & 3).
+// The W' fragment is the MFMA's A operand, the token fragment its B operand: lane (c, qd) ends with token c's outputs
+// n = 16 nb + 4 qd + {0,1,2,3} of every 16-column block - one dwordx4 store each, 64 contiguous bytes per token.
+// ----------------------------------------------------------------------------------------------------------------
+template <int NB>   // NB = BN / 16 column blocks per wave (every wave spans the tile's columns)
+struct Tile16 {
+    static constexpr int NTHR = 256, BM = 128, BN = NB * 16;
+    static constexpr int A_BYTES = BM * 128, W_BYTES = BN * WSPLIT_ROW_BYTES, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int A_LD = BM * 8 / NTHR;                        // float4 per thread per chunk (4)
+    static constexpr int W_PIECES = W_BYTES / 16, W_LD = (W_PIECES + NTHR - 1) / NTHR;
+};
+
+__device__ __forceinline__ f32x4 mfma16_bf16_k32(const bf16x8 a, const bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NB>
+__device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, const int nb, float* smem) {
+    using T = Tile16<NB>;
+    constexpr int BM = T::BM, BN = T::BN, A_LD = T::A_LD, W_LD = T::W_LD, NTHR = T::NTHR;
+    uint8_t* const As = reinterpret_cast<uint8_t*>(smem);
+    uint8_t* const Ws = As + T::A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, qd = lane >> 4;
+    const int tiles_n = p.N / BN;
+    int tile;
+    {
+        const int xcd = b & 7, q = nb >> 3, rem = nb & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    if (m0 >= p.M) return;
+    const int n0 = tile_n * BN;
+    const int K = p.K, nk = K / 32;
+
+    // ---- staging.  A: load i of thread (wave, lane) covers token group g = 2 wave + (i >> 1), token c, 16-byte piece
+    // j = 4 (i & 1) + qd of the 128-byte row (lanes with equal c read 64 contiguous bytes); it lands at
+    // g * 2048 + (j & 1) * 1024 + ((j >> 1) * 16 + c) * 16.  W': the tile's chunk of the image, copied as it lies.
+    const float* const Abase = p.A + m0 * K;
+    int a_src[A_LD], a_dst[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int g = 2 * wave + (i >> 1), j = 4 * (i & 1) + qd;
+        const int row = 16 * g + c;
+        const int64_t lim = p.M - 1 - m0;  // >= 0: rows past the last token read a valid row (never stored)
+        a_src[i] = (row < lim ? row : (int)lim) * K + 4 * j;
+        a_dst[i] = g * 2048 + (j & 1) * 1024 + ((j >> 1) * 16 + c) * 16;
+    }
+    const uint8_t* const Wsbase = p.Wsplit + (int64_t)n0 * WSPLIT_ROW_BYTES + tid * 16;
+    const int64_t ws_chunk = (int64_t)p.N * WSPLIT_ROW_BYTES;
+    f32x4 a_reg[A_LD], w_reg[W_LD];
+    auto load_chunk = [&](int kc) {
+        const float* Ak = Abase + kc * 32;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(Ak + a_src[i]);
+        const uint8_t* Wk = Wsbase + kc * ws_chunk;
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            if ((i + 1) * NTHR <= T::W_PIECES || tid + i * NTHR < T::W_PIECES)
+                w_reg[i] = *reinterpret_cast<const f32x4*>(Wk + i * NTHR * 16);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(As + a_dst[i]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            if ((i + 1) * NTHR <= T::W_PIECES || tid + i * NTHR < T::W_PIECES)
+                *reinterpret_cast<f32x4*>(Ws + (tid + i * NTHR) * 16) = w_reg[i];
+    };
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint8_t* const a_frag = As + (2 * wave) * 2048 + lane * 16;                          // + g * 2048 + o * 1024
+    const uint8_t* const w_frag = Ws + c * WSPLIT_ROW_BYTES + wsplit_sub_offset<32, 1>(c, qd);  // + nb * 16 rows (same rotation)
+    for (int kc = 0; kc < nk; ++kc) {
+        const bool more = kc + 1 < nk;
+        if (more) load_chunk(kc + 1);
+        __builtin_amdgcn_s_setprio(1);
+        bf16x8x3 a[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            a[g] = split3(*reinterpret_cast<const f32x4*>(a_frag + g * 2048), *reinterpret_cast<const f32x4*>(a_frag + g * 2048 + 1024));
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const uint8_t* wp = w_frag + n * 16 * WSPLIT_ROW_BYTES;
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 16);
+            const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 32);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {   // small terms first, the leading product last
+                acc[g][n] = mfma16_bf16_k32(w0, a[g].s2, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w2, a[g].s0, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w1, a[g].s1, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w0, a[g].s1, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w1, a[g].s0, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w0, a[g].s0, acc[g][n]);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();  // everyone done reading before the single buffer is refilled
+        if (more) store_chunk();
+        __syncthreads();
+    }
+    // ---- epilogue: lane (c, qd) owns token 32 wave + 16 g + c, columns n0 + 16 n + 4 qd + {0,1,2,3}
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int64_t m = m0 + 32 * wave + 16 * g + c;
+        if (m >= p.M) continue;
+        float rstd = 1.0f, nmr = 0.0f;
+        if (p.ln_in) {   // folded LayerNorm: the lane owns the token
+            const float mean = p.ln_in[2 * m];
+            rstd = p.ln_in[2 * m + 1];
+            nmr = -mean * rstd;
+        }
+        float* const orow = p.out + m * p.N + n0 + 4 * qd;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
+            f32x4 v;
+            if (p.ln_in) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + 16 * n + 4 * qd);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (p.act) v[e] = gelu_erf(v[e]);
+            *reinterpret_cast<f32x4*>(orow + 16 * n) = v;
+        }
+    }
+}
+
+template <int NB, int MINW>
+__global__ void __launch_bounds__(256, MINW) gemm16_kernel(const GemmParams p) {
+    PAFUSE_XQ_GUARD();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm16_tile<NB>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -99,6 +99,18 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm_kernel");
 }
 
+// the qkv layers' kernel on v_mfma_f32_16x16x32_bf16 (kernels.hpp gemm16_tile); the image must be in the M16 layout
+template <int NB, int MINW>
+int launch_gemm16(const GemmParams& p, hipStream_t s) {
+    using T = Tile16<NB>;
+    static_assert(T::STAGE_BYTES <= 64 * 1024, "LDS budget without the attribute");
+    if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
+    const int64_t tiles = ((p.M + T::BM - 1) / T::BM) * (p.N / T::BN);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
+    hipLaunchKernelGGL((gemm16_kernel<NB, MINW>), dim3((unsigned)tiles), dim3(T::NTHR), T::STAGE_BYTES, s, p);
+    return check_launch("gemm16_kernel");
+}
+
 // split-precision GEMM, LDS-DMA pipelined form (one workgroup per CU, NSTAGE ring of 32-deep chunks)
 // K-chunk depth of the pre-split image of a weight (the image format is a property of the weight, fixed when it is
 // split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384, 288, 256
@@ -153,6 +165,15 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
+#ifdef PAFUSE_QKV_32X32   // A/B build (tools/): the qkv layers on the 32x32x16 tiles, their images in layout 0
+    p.wlayout = 0;
+#endif
+    if (p.bf16 == 2 && p.wlayout == 2) {  // the qkv layers: 16x16x32 MFMAs on the M16 image (3 - 10 % per launch, kernels.hpp)
+        if (p.N % 128 == 0) return launch_gemm16<8, 3>(p, s);    // body 1152, hands 768: 128 x 128 tiles, 3 workgroups per CU
+        if (p.N % 96 == 0) return launch_gemm16<6, 3>(p, s);     // face 672, single-model 864: 128 x 96
+        if (p.N % 64 == 0) return launch_gemm16<4, 4>(p, s);
+        return launch_gemm16<2, 4>(p, s);
+    }
     if (p.bf16 == 2) {  // split precision (bf16x3): fp32-equivalent products on the bf16 matrix cores
         // measured per shape with tools/gemm_bench.hip (profiles/r02_gemm_bench_split_v1.log): 128x128 tiles at two
         // workgroups per CU where N allows (159 TFLOP/s at the body qkv shape), 128x64 at four otherwise (148)
@@ -422,7 +443,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     GemmParams& g = b.qkv;
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
-    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws;
+    g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws, g.wlayout = 2;   // qkv images are in the M16 layout (include/pafuse_hip.h)
     if (fold) g.A = pb.x, g.ln_in = stats, g.ln_s = bw.qkv_ls, g.bias = bw.qkv_lt;
     AttnParams& a = b.attn;
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
@@ -647,13 +668,19 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
 
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
 
-int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t whole_row, void* out, void* stream) {
+int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t layout, void* out, void* stream) {
     StreamDevice on_stream_device(stream);
     if (!W || !out) return fail(PAFUSE_E_ARG, "split_weights: null pointer");
     if (N <= 0 || K <= 0 || K % BK) return fail(PAFUSE_E_SHAPE, "split_weights: N=%d, K=%d (K must be a positive multiple of 32)", N, K);
+    if (layout < 0 || layout > 2) return fail(PAFUSE_E_ARG, "split_weights: layout %d (0 plain, 1 whole-row, 2 qkv)", layout);
     const int64_t n = (int64_t)N * (K / 8);
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (wsplit_chunk(N, whole_row != 0) == 16)
+#ifdef PAFUSE_QKV_32X32
+    if (layout == 2) layout = 0;
+#endif
+    if (layout == 2)
+        hipLaunchKernelGGL((split_weights_kernel<32, 1>), grid, dim3(256), 0, (hipStream_t)stream, W, (uint8_t*)out, N, K);
+    else if (wsplit_chunk(N, layout == 1) == 16)
         hipLaunchKernelGGL(split_weights_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, W, (uint8_t*)out, N, K);
     else
         hipLaunchKernelGGL(split_weights_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, W, (uint8_t*)out, N, K);
@@ -666,7 +693,7 @@ int pafuse_linear_split(const float* A, const void* Wsplit, const float* bias, f
     if (!A || !Wsplit || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear_split: null pointer or negative M");
     GemmParams g{};
     g.A = A, g.Wsplit = (const uint8_t*)Wsplit, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1;
-    g.bf16 = 2;
+    g.bf16 = 2, g.wlayout = (act & 2) ? 2 : 0;
     return gemm_bias(g, (hipStream_t)stream);
 }
 

@@ -166,7 +166,7 @@ class MixSTE2(nn.Module):
                 stem = name[:-len("weight")]
                 images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name)
             else:
-                images[name] = split_image(get(name), name.endswith(("attn.proj.weight", "mlp.fc2.weight")))
+                images[name] = split_image(get(name), image_layout(name))
         return images
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -345,14 +345,22 @@ def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, i
                 setattr(dst[i], field, vec.data_ptr() if vec is not None else None)
 
 
-def split_image(weight, whole_row):
+LAYOUT_OF = {"attn.qkv.weight": 2, "attn.proj.weight": 1, "mlp.fc2.weight": 1, "mlp.fc1.weight": 0}
+
+
+def image_layout(name):
+    """pafuse_split_weights' layout argument for a state-dict key of a linear weight (include/pafuse_hip.h)."""
+    return LAYOUT_OF[name.split(".", 2)[2] if name.count(".") >= 3 else name]
+
+
+def split_image(weight, layout):
     """The pre-split (bf16x3) image of one linear weight [N,K] on its device (pafuse_split_weights): a uint8 tensor of
-    6 bytes per element; `whole_row` picks the chunk depth the whole-row layers (attn.proj, mlp.fc2) read."""
+    6 bytes per element; `layout`: 0 mlp.fc1 / the unit op, 1 the whole-row layers (attn.proj, mlp.fc2), 2 attn.qkv."""
     lib = _lib.load()
     N, K = weight.shape
     img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(whole_row), img.data_ptr(),
+        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(layout), img.data_ptr(),
                                             torch.cuda.current_stream(weight.device).cuda_stream))
     return img
 
@@ -368,7 +376,7 @@ def folded_linear(get, name):
     w64 = weight.double()
     ls = (w64 @ g.double()).float().contiguous()
     lt = (w64 @ beta.double() + bias.double()).float().contiguous()
-    return split_image((weight * g[None, :]).contiguous(), False), ls, lt
+    return split_image((weight * g[None, :]).contiguous(), image_layout(name)), ls, lt
 
 
 def fill_block_struct(dst, blk):

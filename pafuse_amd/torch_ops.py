@@ -24,7 +24,7 @@ from typing import List
 import torch
 
 from . import _lib
-from .mixste2 import (FOLDED_LINEAR, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear,
+from .mixste2 import (FOLDED_LINEAR, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear, image_layout,
                       sinusoid_frequencies, split_image)
 
 BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
@@ -73,15 +73,16 @@ _image_cache = {}        # (data_ptr, _version, device, whole_row) of a linear w
 _IMAGE_CACHE_MAX = 2048  # ~ three models' worth of linear weights; the oldest entries go first
 
 
-def cached_split_image(weight, whole_row):
-    """The pre-split image of a linear weight, made once per (storage, version): the schema'd ops take plain parameter
-    tensors, so they build and cache the images the split-precision kernels read (the modules keep theirs per module)."""
-    key = (weight.data_ptr(), weight._version, weight.device, bool(whole_row), tuple(weight.shape))
+def cached_split_image(weight, layout):
+    """The pre-split image of a linear weight, made once per (storage, version, layout): the schema'd ops take plain
+    parameter tensors, so they build and cache the images the split-precision kernels read (the modules keep theirs per
+    module).  layout: pafuse_split_weights' (0 fc1, 1 proj / fc2, 2 qkv)."""
+    key = (weight.data_ptr(), weight._version, weight.device, int(layout), tuple(weight.shape))
     img = _image_cache.get(key)
     if img is None:
         while len(_image_cache) >= _IMAGE_CACHE_MAX:
             _image_cache.pop(next(iter(_image_cache)))
-        img = _image_cache[key] = split_image(weight, whole_row)
+        img = _image_cache[key] = split_image(weight, layout)
     return img
 
 
@@ -125,7 +126,7 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
             if n.endswith(tuple(FOLDED_LINEAR)):
                 images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n)
             elif n.endswith(SPLIT_SUFFIXES):
-                images[n] = cached_split_image(t, n.endswith(("attn.proj.weight", "mlp.fc2.weight")))
+                images[n] = cached_split_image(t, image_layout(n))
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
     return w, (table, fr, images)
 
@@ -209,8 +210,8 @@ def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int, precision: s
         setattr(w, field, _ptr(t, name))
     images = []
     if mode == 2:
-        for field, idx, whole_row in (("qkv_ws", 2, False), ("proj_ws", 4, True), ("fc1_ws", 8, False), ("fc2_ws", 10, True)):
-            images.append(cached_split_image(weights[idx], whole_row))
+        for field, idx, layout in (("qkv_ws", 2, 2), ("proj_ws", 4, 1), ("fc1_ws", 8, 0), ("fc2_ws", 10, 1)):
+            images.append(cached_split_image(weights[idx], layout))
             setattr(w, field, images[-1].data_ptr())
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)

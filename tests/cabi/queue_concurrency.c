@@ -34,10 +34,10 @@ static float* dev_rand(size_t n, float scale, float offset) {
     free(h);
     return d;
 }
-static void* split_of(const float* W, int N, int K, int whole_row) {
+static void* split_of(const float* W, int N, int K, int layout) {   /* pafuse_split_weights: 0 fc1, 1 proj / fc2, 2 qkv */
     void* img;
     CK(hipMalloc(&img, pafuse_split_weights_bytes(N, K)));
-    PK(pafuse_split_weights(W, N, K, whole_row, img, NULL));
+    PK(pafuse_split_weights(W, N, K, layout, img, NULL));
     return img;
 }
 
@@ -51,7 +51,7 @@ static void make_block(pafuse_block_weights* b, int mode) {
     b->fc1_w = dev_rand((size_t)2 * C * C, 0.05f, 0.0f), b->fc1_b = dev_rand(2 * C, 0.02f, 0.0f);
     b->fc2_w = dev_rand((size_t)2 * C * C, 0.05f, 0.0f), b->fc2_b = dev_rand(C, 0.02f, 0.0f);
     if (mode == 2) {
-        b->qkv_ws = split_of(b->qkv_w, 3 * C, C, 0), b->proj_ws = split_of(b->proj_w, C, C, 1);
+        b->qkv_ws = split_of(b->qkv_w, 3 * C, C, 2), b->proj_ws = split_of(b->proj_w, C, C, 1);
         b->fc1_ws = split_of(b->fc1_w, 2 * C, C, 0), b->fc2_ws = split_of(b->fc2_w, C, 2 * C, 1);
     }
 }

@@ -120,10 +120,14 @@ def test_linear_exact_integers():
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 1152, 384), (77, 384, 768), (300, 672, 224),
                                    (129, 448, 224), (64, 768, 256), (1, 512, 256), (50, 96, 64), (33, 32, 32)])
 @pytest.mark.parametrize("act", [None, "gelu"])
-def test_linear_split(M, N, K, act):
+@pytest.mark.parametrize("layout", [0, 2])
+def test_linear_split(M, N, K, act, layout):
     """split-precision (bf16x3) products against fp64: the same bound as the fp32 FMA chain of test_linear (the six
-    kept terms carry every operand bit above 2^-24 relative; accumulation is fp32, one rounding per 16-deep MFMA)."""
+    kept terms carry every operand bit above 2^-24 relative; accumulation is fp32, one rounding per 16-deep MFMA).
+    layout 0: the 32x32x16-MFMA tiles (mlp.fc1); layout 2: the 16x16x32-MFMA tiles of the qkv layers."""
     from pafuse_amd import ops
+    from functools import partial
+    ops = type("ops", (), {"linear": staticmethod(ops.linear), "linear_split": staticmethod(partial(ops.linear_split, layout=layout))})
     x, w, b = _seeded((M, K), 1), _seeded((N, K), 2, K ** -0.5), _seeded((N,), 3, 0.1)
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     if act:
@@ -135,11 +139,15 @@ def test_linear_split(M, N, K, act):
         assert (out.double() - ref).abs().mean() <= 1.05 * (plain.double() - ref).abs().mean()
 
 
-def test_linear_split_exact_integers_and_slices():
+@pytest.mark.parametrize("layout,M,N,K", [(0, 96, 224, 64), (2, 96, 224, 64), (2, 200, 1152, 384), (2, 131, 672, 224),
+                                          (2, 70, 768, 256), (2, 300, 96, 64)])
+def test_linear_split_exact_integers_and_slices(layout, M, N, K):
     """exact data: small integers (any row/col/k-permutation or sub-block rotation slip shows exactly), and operands
-    that need all three bf16 slices (24-bit integers times powers of two: products exact in fp32)."""
+    that need all three bf16 slices (24-bit integers times powers of two: products exact in fp32); both image layouts /
+    kernels (0: 32x32x16 tiles, 2: the qkv layers' 16x16x32 tiles at their three tile widths and a ragged M)."""
     from pafuse_amd import ops
-    M, N, K = 96, 224, 64
+    from functools import partial
+    ops = type("ops", (), {"linear_split": staticmethod(partial(ops.linear_split, layout=layout))})
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (M, K), generator=g).float()
     w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
