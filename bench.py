@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
     ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
+    ap.add_argument("--fuse-qkv-attention", action="store_true",
+                    help="A/B: the opt-in fused qkv + attention kernel (pafuse_amd.MixSTE2.fuse_qkv_attention) where it exists")
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
@@ -112,9 +114,10 @@ def main():
     model.n_aux_streams = args.streams
     model.use_graph = args.graph
     model.precision = args.dtype
-    if args.no_ln_fold:
-        for m in model.denoisers().values():
+    for m in model.denoisers().values():
+        if args.no_ln_fold:
             m.fold_layernorm = False
+        m.fuse_qkv_attention = bool(args.fuse_qkv_attention)
     sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)
     x2d, x2f = x2d.to(dev), x2f.to(dev)
@@ -197,6 +200,7 @@ def main():
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
         "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype == "bf16x3" and not args.no_ln_fold),
+        "qkv_attention_fused": bool(args.dtype == "bf16x3" and args.fuse_qkv_attention),
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
         "allgather_ms": gather_ms, "allgather_ms_note": "collective + the one layout pass, max over ranks", "gather_copy_ms": copy_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,

@@ -67,6 +67,16 @@ typedef struct pafuse_block_weights {
      * function as LN(x) W^T + b (common/mixste.py:113-116) with one [M,C] store and one normalise pass less per
      * whole-row launch.  pafuse_block_forward ignores them (it is handed a normalised-input-free block). */
     const float *qkv_ls, *qkv_lt, *fc1_ls, *fc1_lt;
+    /* split-precision mode, optional: the qkv projection and the attention of a block in ONE kernel (fqa_kernel: one
+     * workgroup = whole sequences x one head; q, k, v never reach memory).  qkv_hs is the layout-2 image of the HEAD-MAJOR
+     * qkv weight: for head h = 0 .. heads-1 the d rows of q_h, then zero rows up to DP, then k_h and v_h likewise
+     * (DP = 32 for head dim d <= 32, else 48; [heads * 3 * DP, C] in all) - of W (.) g when the LayerNorm is folded;
+     * qkv_hb [heads * 3 * DP] is the bias (folded: qkv_lt) and qkv_hl the folded qkv_ls in that row order, zeros in the
+     * padding.  Used when set and the sequence length has a fused form (L <= 48); otherwise, and for
+     * pafuse_block_forward, the block runs qkv GEMM + attention from qkv_ws.  Same arithmetic per product and the same
+     * attention as the two kernels. */
+    const void *qkv_hs;
+    const float *qkv_hb, *qkv_hl;
 } pafuse_block_weights;
 
 /* One MixSTE2 (common/mixste.py:141-210): F frames, J joints of this part, C channels, `depth` spatial +
@@ -174,6 +184,11 @@ int pafuse_block_forward(const pafuse_block_weights *w, float *x, int64_t S, int
 /* temb[B,C] = time_mlp(t[B]);  hid_scratch: [B,2C] floats of device scratch */
 int pafuse_time_embed(const pafuse_mixste2_weights *w, const int64_t *t, int32_t B, float *temb, float *hid_scratch,
                       void *stream);
+
+/* How many of the 2 * depth blocks of `w` will run qkv + attention as the one fused kernel (pafuse_block_weights.qkv_hs
+ * set and the block's sequence length / head dim have a fused form); negative = an error code.  Callers and tests use
+ * it to know which path a configuration takes. */
+int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights *w);
 
 /* MixSTE2.forward, eval: x2d[B,F,J,2], x3d[B,P,F,J,3], t[B] -> out[B,P,F,J,3]. */
 size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights *w, int32_t B, int32_t P);

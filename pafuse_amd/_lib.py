@@ -23,7 +23,8 @@ class BlockWeights(C.Structure):
     _names = ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
               "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
               "qkv_ws", "proj_ws", "fc1_ws", "fc2_ws",
-              "qkv_ls", "qkv_lt", "fc1_ls", "fc1_lt")
+              "qkv_ls", "qkv_lt", "fc1_ls", "fc1_lt",
+              "qkv_hs", "qkv_hb", "qkv_hl")
     _fields_ = [(n, C.c_void_p) for n in _names]
 
 
@@ -71,6 +72,7 @@ SIGNATURES = {
                                        C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pafuse_time_embed": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
+    "pafuse_mixste2_fused_blocks": (C.c_int, [C.POINTER(MixSTE2Weights)]),
     "pafuse_mixste2_workspace_bytes": (C.c_size_t, [C.POINTER(MixSTE2Weights), C.c_int32, C.c_int32]),
     "pafuse_mixste2_forward": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

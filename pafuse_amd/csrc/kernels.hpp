@@ -1603,6 +1603,255 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
 }
 
 // ----------------------------------------------------------------------------------------------------------------
+// qkv projection + attention of one head in ONE kernel (round 3; split-precision inference):
+//   o[rows of the tile, head] = softmax(q k^T * scale) v,   (q | k | v) = A[rows] @ W'_head^T + b_head   (+ folded LayerNorm)
+// replaces a qkv GEMM launch + an attn_kernel launch (common/mixste.py:65-79) and the [M,3C] buffer between them: q, k, v
+// of the tile's tokens never leave the CU.
+// Workgroup = 4 waves = one tile of whole sequences x one head.  The tile holds NSEQ = 128 / L sequences, token i of
+// sequence s at tile row s L + i (rows past NSEQ L are computed on a valid row and dropped).
+//   phase 1  gemm16_tile's K loop (v_mfma_f32_16x16x32_bf16, six products) on the gathered rows against the head's slice
+//            of the HEAD-MAJOR image: per head 3 DP rows - q, k, v of the head, each zero-padded from d to DP rows - so a
+//            tile's W' stage is one contiguous run; bias / ls / lt are in the same order.
+//   phase 2  the accumulators (token on the lane, 4 consecutive columns per register quad) go to LDS as three
+//            [rows][DP + 4] fp32 tiles (over the dead staging buffers);
+//   phase 3  attn_kernel's arithmetic per (sequence, 16-query tile) - S^T = K Q^T and O^T = V^T P^T on 16x16x4 fp32 MFMAs,
+//            softmax in registers - with Q, K, V read from those tiles; o is written once.
+// Blocks: b -> XCD x = b & 7, then (tile, head) = ((b >> 3) / heads * 8 + x, (b >> 3) % heads): the eight heads of a tile
+// run on one XCD (its A rows are L2 hits for seven of them) and every XCD keeps the whole image (2.6 MB) in its L2.
+// ----------------------------------------------------------------------------------------------------------------
+struct FqaParams {
+    GemmParams g;      // A [M,K = C], Wsplit = head-major M16 image, bias / ln_in / ln_s (head-major order); N = heads * 3 * DP
+    float* o;          // [M, C]
+    int64_t nseq;
+    int L, C, heads, d, nseq_tile;
+    int64_t group, group_stride, seq_stride, tok_stride;   // sequence addressing, as AttnParams
+    float scale;
+};
+
+template <int LP, int DP>
+struct FqaTile {
+    static constexpr int NB = 3 * DP / 16, LDV = DP + 4, ROWS = 128 + (LP == 48 ? 4 : 0);
+    static constexpr int STAGE_BYTES = Tile16<NB>::STAGE_BYTES, QKV_BYTES = 3 * ROWS * LDV * 4;
+    static constexpr int LDS_BYTES = STAGE_BYTES > QKV_BYTES ? STAGE_BYTES : QKV_BYTES;
+};
+
+template <int LP, int DP>
+__global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
+    PAFUSE_XQ_GUARD();
+    using FT = FqaTile<LP, DP>;
+    constexpr int NB = FT::NB, LDV = FT::LDV, ROWS = FT::ROWS;
+    using T = Tile16<NB>;
+    constexpr int A_LD = T::A_LD, W_LD = T::W_LD, NTHR = T::NTHR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GemmParams& p = fp.g;
+    uint8_t* const As = reinterpret_cast<uint8_t*>(smem);
+    uint8_t* const Ws = As + T::A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, qd = lane >> 4;
+    const int L = fp.L, NSEQ = fp.nseq_tile;
+    const int64_t ntiles = (fp.nseq + NSEQ - 1) / NSEQ;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int64_t tile = (int64_t)(idx / fp.heads) * 8 + xcd;
+    const int head = idx % fp.heads;
+    if (tile >= ntiles) return;   // (workgroup-uniform: the grid is padded to a multiple of 8 tiles)
+    const int K = p.K, nk = K / 32;
+    const int64_t seq0 = tile * NSEQ;
+    const int64_t last_seq = fp.nseq - 1;
+    // token (row of A / o) of tile row r: sequence seq0 + r / L, position r % L; rows of absent sequences alias the last one
+    auto token_of = [&](int r) -> int64_t {
+        int sl = r / L, t = r - sl * L;
+        if (sl >= NSEQ) sl = NSEQ - 1, t = L - 1;
+        int64_t sq = seq0 + sl;
+        if (sq > last_seq) sq = last_seq;
+        return (sq / fp.group) * fp.group_stride + (sq % fp.group) * fp.seq_stride + t * fp.tok_stride;
+    };
+
+    // ---- phase 1: the K loop of gemm16_tile on gathered rows
+    const float* a_ptr[A_LD];
+    int a_dst[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int g = 2 * wave + (i >> 1), j = 4 * (i & 1) + qd;
+        a_ptr[i] = p.A + token_of(16 * g + c) * K + 4 * j;
+        a_dst[i] = g * 2048 + (j & 1) * 1024 + ((j >> 1) * 16 + c) * 16;
+    }
+    const int n0 = head * 3 * DP;
+    const uint8_t* const Wsbase = p.Wsplit + (int64_t)n0 * WSPLIT_ROW_BYTES + tid * 16;
+    const int64_t ws_chunk = (int64_t)p.N * WSPLIT_ROW_BYTES;
+    f32x4 a_reg[A_LD], w_reg[W_LD];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) a_reg[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + kc * 32);
+        const uint8_t* Wk = Wsbase + kc * ws_chunk;
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            if ((i + 1) * NTHR <= T::W_PIECES || tid + i * NTHR < T::W_PIECES)
+                w_reg[i] = *reinterpret_cast<const f32x4*>(Wk + i * NTHR * 16);
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<f32x4*>(As + a_dst[i]) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            if ((i + 1) * NTHR <= T::W_PIECES || tid + i * NTHR < T::W_PIECES)
+                *reinterpret_cast<f32x4*>(Ws + (tid + i * NTHR) * 16) = w_reg[i];
+    };
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint8_t* const a_frag = As + (2 * wave) * 2048 + lane * 16;
+    const uint8_t* const w_frag = Ws + c * WSPLIT_ROW_BYTES + wsplit_sub_offset<32, 1>(c, qd);
+    for (int kc = 0; kc < nk; ++kc) {
+        const bool more = kc + 1 < nk;
+        if (more) load_chunk(kc + 1);
+        __builtin_amdgcn_s_setprio(1);
+        bf16x8x3 a[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            a[g] = split3(*reinterpret_cast<const f32x4*>(a_frag + g * 2048), *reinterpret_cast<const f32x4*>(a_frag + g * 2048 + 1024));
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const uint8_t* wp = w_frag + n * 16 * WSPLIT_ROW_BYTES;
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 16);
+            const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(wp + 32);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                acc[g][n] = mfma16_bf16_k32(w0, a[g].s2, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w2, a[g].s0, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w1, a[g].s1, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w0, a[g].s1, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w1, a[g].s0, acc[g][n]);
+                acc[g][n] = mfma16_bf16_k32(w0, a[g].s0, acc[g][n]);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();  // everyone done reading before the single buffer is refilled (after the last chunk: before phase 2)
+        if (more) store_chunk();
+        if (more) __syncthreads();
+    }
+
+    // ---- phase 2: q | k | v of the tile's tokens to LDS (bias or the folded LayerNorm applied), over the staging buffers
+    float* const Qs = smem;                    // [ROWS][LDV] each
+    float* const Ks = Qs + ROWS * LDV;
+    float* const Vs = Ks + ROWS * LDV;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int r = 32 * wave + 16 * g + c;
+        float rstd = 1.0f, nmr = 0.0f;
+        if (p.ln_in) {
+            const int64_t m = token_of(r);
+            const float mean = p.ln_in[2 * m];
+            rstd = p.ln_in[2 * m + 1];
+            nmr = -mean * rstd;
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+            f32x4 v;
+            if (p.ln_in) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
+            }
+            const int part = (16 * n) / DP, cc = col - part * DP;
+            *reinterpret_cast<f32x4*>(Qs + part * ROWS * LDV + r * LDV + cc) = v;
+        }
+    }
+    if (ROWS > 128)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
+        for (int i = tid; i < 3 * (ROWS - 128) * LDV; i += NTHR) {
+            const int part = i / ((ROWS - 128) * LDV), rem = i % ((ROWS - 128) * LDV);
+            Qs[part * ROWS * LDV + 128 * LDV + rem] = 0.f;
+        }
+    __syncthreads();
+
+    // ---- phase 3: attention per (sequence of the tile, 16-query tile), one item per wave at a time (attn_kernel's arithmetic)
+    constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16;
+    const int l15 = c, g4 = qd;
+    const int nseq_here = (int)((fp.nseq - seq0) < NSEQ ? (fp.nseq - seq0) : NSEQ);
+    for (int item = wave; item < nseq_here * QT; item += 4) {
+        const int sl = item / QT, qt = item % QT;
+        const int rb = sl * L;
+        if (qt * 16 >= L) continue;
+        f32x4 qf[SD];
+#pragma unroll
+        for (int sd = 0; sd < SD; ++sd) qf[sd] = *reinterpret_cast<const f32x4*>(Qs + (rb + qt * 16 + l15) * LDV + 16 * sd + 4 * g4);
+        const float* Kb = Ks + rb * LDV;
+        const float* Vb = Vs + rb * LDV;
+        f32x4 sc[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sd = 0; sd < SD; ++sd) {
+            f32x4 kf[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) kf[kt] = *reinterpret_cast<const f32x4*>(Kb + (kt * 16 + l15) * LDV + 16 * sd + 4 * g4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j], qf[sd][j], sc[kt], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int key = kt * 16 + 4 * g4 + reg;
+                const float v = key < L ? sc[kt][reg] * fp.scale : -INFINITY;
+                sc[kt][reg] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float e = __builtin_amdgcn_exp2f((sc[kt][reg] - mx) * 1.44269504088896340736f);
+                sc[kt][reg] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) sc[kt][reg] *= inv;
+        f32x4 oc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) oc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float* vrow = Vb + (kt * 16 + 4 * g4 + reg) * LDV + l15;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    oc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ct * 16], sc[kt][reg], oc[ct], 0, 0, 0);
+            }
+        const int q = qt * 16 + l15;
+        if (q < L) {
+            float* orow = fp.o + token_of(rb + q) * fp.C + head * fp.d + 4 * g4;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct * 16 + 4 * g4 < fp.d) *reinterpret_cast<f32x4*>(orow + ct * 16) = oc[ct];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
 // Row-wise LayerNorm, one wave per row (stand-alone form; inside the loop the norms live in GEMM epilogues)
 // ----------------------------------------------------------------------------------------------------------------
 constexpr int LN_MAX_PER_LANE = 12;  // C <= 768

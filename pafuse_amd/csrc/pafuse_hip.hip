@@ -99,6 +99,40 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm_kernel");
 }
 
+// qkv projection + attention of one head per workgroup (kernels.hpp fqa_kernel)
+template <int LP, int DP>
+int launch_fqa(const FqaParams& f, hipStream_t s) {
+    using FT = FqaTile<LP, DP>;
+    static_assert(FT::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    auto k = fqa_kernel<LP, DP>;
+    if (FT::LDS_BYTES > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
+    }
+    const int64_t ntiles = (f.nseq + f.nseq_tile - 1) / f.nseq_tile;
+    const int64_t blocks = (ntiles + 7) / 8 * 8 * f.heads;
+    if (blocks <= 0 || blocks > 0x7fffffff) return fail(PAFUSE_E_ARG, "fused qkv-attention grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), FT::LDS_BYTES, s, f);
+    return check_launch("fqa_kernel");
+}
+
+// padded sizes of the fused kernel for a sequence length / head dim, 0 = no fused form (the caller keeps qkv GEMM + attention)
+static int fqa_lp(int L) { return L <= 32 ? 32 : (L <= 48 ? 48 : 0); }
+static int fqa_dp(int d) { return (d % 4 || d > 48) ? 0 : (d <= 32 ? 32 : 48); }
+static bool fqa_has(int L, int d) {   // (48, 48) would need 80.4 KB of LDS: one workgroup per CU, not built
+    const int lp = fqa_lp(L), dp = fqa_dp(d);
+    return lp && dp && !(lp == 48 && dp == 48);
+}
+
+int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
+    if (f.nseq <= 0) return PAFUSE_OK;
+    const int lp = fqa_lp(f.L), dp = fqa_dp(f.d);
+    if (lp == 32 && dp == 48) return launch_fqa<32, 48>(f, s);
+    if (lp == 32 && dp == 32) return launch_fqa<32, 32>(f, s);
+    if (lp == 48 && dp == 32) return launch_fqa<48, 32>(f, s);
+    return fail(PAFUSE_E_SHAPE, "fused qkv-attention: no kernel for L=%d, d=%d", f.L, f.d);
+}
+
 // the qkv layers' kernel on v_mfma_f32_16x16x32_bf16 (kernels.hpp gemm16_tile); the image must be in the M16 layout
 template <int NB, int MINW>
 int launch_gemm16(const GemmParams& p, hipStream_t s) {
@@ -326,6 +360,9 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 
 int attention(const AttnParams& p, hipStream_t s) {
     if (p.nseq <= 0) return PAFUSE_OK;
+#ifdef PAFUSE_ABL_NO_ATTENTION   // timing ablation (tools/): what the loop costs with every attention launch removed (results wrong)
+    return PAFUSE_OK;
+#endif
     if (p.d % 4 || p.d > 48 || p.L > 144 || p.L <= 0)
         return fail(PAFUSE_E_SHAPE, "attention: head dim %d (need %%4, <=48) / length %d (need <=144)", p.d, p.L);
     const int dp = p.d <= 32 ? 32 : 48;
@@ -430,6 +467,8 @@ struct BlockTail {
 struct BlockLaunch {
     GemmParams qkv, proj, fc1, fc2;
     AttnParams attn;
+    FqaParams fqa;   // qkv + attention in one kernel (fused == true: replaces the qkv and attn launches)
+    bool fused;
 };
 
 BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
@@ -449,6 +488,20 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
     a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
     a.scale = qk_scale != 0.f ? qk_scale : 1.0f / sqrtf((float)(C / heads));  // qk_scale or head_dim ** -0.5  mixste.py:52
+    // the two in one kernel where a head-major image was supplied and the shape has a fused form
+    b.fused = false;
+    if (bf16 == 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads) && (!fold || bw.qkv_hl)) {
+        const int lp = fqa_lp(L), dp = fqa_dp(C / heads), rows = 128 + (lp == 48 ? 4 : 0);
+        FqaParams& f = b.fqa;
+        f.g = g;
+        f.g.Wsplit = (const uint8_t*)bw.qkv_hs, f.g.bias = bw.qkv_hb, f.g.ln_s = fold ? bw.qkv_hl : nullptr;
+        f.g.N = heads * 3 * dp;
+        f.o = pb.o, f.nseq = nseq, f.L = L, f.C = C, f.heads = heads, f.d = C / heads;
+        f.nseq_tile = (rows - lp) / L + 1;    // whole sequences per 128-row tile, the last one's LP-row key tile inside the buffer
+        f.group = group, f.group_stride = group_stride, f.seq_stride = seq_stride, f.tok_stride = tok_stride;
+        f.scale = a.scale;
+        b.fused = f.nseq_tile * L <= 128;
+    }
     // x = x + o Wproj^T + b ; xn = LN2(x)                                               mixste.py:80,114-115
     GemmParams& pj = b.proj;
     pj.A = pb.o, pj.W = bw.proj_w, pj.bias = bw.proj_b, pj.M = M, pj.N = C, pj.K = C;
@@ -535,6 +588,11 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
     // attention launches of a block pair get 21 us slower, more than the shared qkv grid saves (9 us; rocprofv3, r02)
     for (int i = 0; i < n; ++i) {
         g[i] = bl[i].qkv;
+        if (bl[i].fused) {   // one kernel: the GEMM replay (gemms_only) cannot leave its attention phase out
+            if ((layer_mask & 1) && (rc = fused_qkv_attention(bl[i].fqa, s))) return rc;
+            PAFUSE_TRACE(bl[i].attn.o, (size_t)g[i].M * bl[i].attn.C * 4, s);
+            continue;
+        }
         if ((layer_mask & 1) && (rc = gemm_bias(g[i], s))) return rc;
         PAFUSE_TRACE(g[i].out, (size_t)g[i].M * g[i].N * 4, s);
         if (!gemms_only && (rc = attention(bl[i].attn, s))) return rc;
@@ -667,6 +725,24 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
 }
 
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
+
+int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights* w) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    const int d = w->channels / w->heads;
+    const bool fold = ln_folded(w);
+    int n = 0;
+    for (int i = 0; i < w->depth; ++i) {
+        const pafuse_block_weights* pair[2] = {&w->ste[i], &w->tte[i]};
+        const int len[2] = {w->joints, w->frames};
+        for (int k = 0; k < 2; ++k)   // the condition of make_block, plus the tile-capacity check it makes
+            if (w->operand_bf16 == 2 && pair[k]->qkv_hs && pair[k]->qkv_hb && fqa_has(len[k], d) && (!fold || pair[k]->qkv_hl)) {
+                const int lp = fqa_lp(len[k]), rows = 128 + (lp == 48 ? 4 : 0);
+                n += (((rows - lp) / len[k] + 1) * len[k] <= 128) ? 1 : 0;
+            }
+    }
+    return n;
+}
 
 int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t layout, void* out, void* stream) {
     StreamDevice on_stream_device(stream);

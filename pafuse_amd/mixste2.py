@@ -110,6 +110,10 @@ class MixSTE2(nn.Module):
         #                                (pafuse_block_weights.qkv_ls ...: g-scaled weight images + two vectors per layer);
         #                                False = the whole-row kernels write the normalised rows (same function, one more
         #                                [M,C] store and normalise pass per whole-row launch)
+        self.fuse_qkv_attention = False  # split-precision inference, opt-in: qkv projection + attention of a block in ONE kernel
+        #                                where the sequence length has a fused form (include/pafuse_hip.h pafuse_block_weights.qkv_hs):
+        #                                q, k, v never reach memory.  Measured equal to the two kernels in time,
+        #                                so the default keeps the two kernels, whose GEMM is the better-utilised one
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -127,8 +131,9 @@ class MixSTE2(nn.Module):
         fold = mode == 2 and bool(self.fold_layernorm)
         if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
-        if fold:            # ... and so are the folded images / vectors: they also hold the LayerNorm and bias values
-            key += ("fold",) + tuple(get(n)._version for n in self._param_names if n.endswith(FOLD_SUFFIXES))
+        fuse = mode == 2 and bool(self.fuse_qkv_attention)
+        if fold or fuse:    # ... and so are the folded / head-major images and vectors: they also hold LayerNorm and bias values
+            key += ("fold", fold, fuse) + tuple(get(n)._version for n in self._param_names if n.endswith(FOLD_SUFFIXES))
         dev = self._freqs.device
         # per device, in a dict the replicas of nn.DataParallel share with their parent (replicate() copies attributes
         # shallowly and makes fresh module objects on every forward: a per-object cache would never hit there, and every
@@ -141,7 +146,7 @@ class MixSTE2(nn.Module):
         w = _lib.MixSTE2Weights()
         images, event, stream = None, None, None
         if mode == 2:
-            images = self._split_images(get, fold)
+            images = self._split_images(get, fold, fuse)
             stream = torch.cuda.current_stream(dev)
             event = torch.cuda.Event()
             event.record(stream)
@@ -153,7 +158,7 @@ class MixSTE2(nn.Module):
         self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
         return w
 
-    def _split_images(self, get, fold=False):
+    def _split_images(self, get, fold=False, fuse=False):
         """Pre-split (bf16x3) images of every linear weight, made on the device by pafuse_split_weights: one uint8
         tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct).
         `fold`: qkv / fc1 get the image of W (.) g and the two vectors of the folded LayerNorm (norm1 / norm2 of their
@@ -162,11 +167,13 @@ class MixSTE2(nn.Module):
         for name in self._param_names:
             if not name.endswith(SPLIT_SUFFIXES):
                 continue
+            stem = name[:-len("weight")]
             if fold and name.endswith(tuple(FOLDED_LINEAR)):
-                stem = name[:-len("weight")]
                 images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name)
             else:
                 images[name] = split_image(get(name), image_layout(name))
+            if fuse and name.endswith("attn.qkv.weight"):
+                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = head_major_qkv(get, name, self.num_heads, fold)
         return images
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -309,7 +316,8 @@ SPLIT_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.
 # the LayerNorm folded into a linear layer: linear weight suffix -> the norm of the same block in front of it
 FOLDED_LINEAR = {"attn.qkv.weight": "norm1", "mlp.fc1.weight": "norm2"}
 FOLD_SUFFIXES = ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.bias", "mlp.fc1.bias")
-BLOCK_FOLD = (("qkv_ls", "attn.qkv.ls"), ("qkv_lt", "attn.qkv.lt"), ("fc1_ls", "mlp.fc1.ls"), ("fc1_lt", "mlp.fc1.lt"))
+BLOCK_FOLD = (("qkv_ls", "attn.qkv.ls"), ("qkv_lt", "attn.qkv.lt"), ("fc1_ls", "mlp.fc1.ls"), ("fc1_lt", "mlp.fc1.lt"),
+              ("qkv_hs", "attn.qkv.hs"), ("qkv_hb", "attn.qkv.hb"), ("qkv_hl", "attn.qkv.hl"))
 BLOCK_SPLIT = (("qkv_ws", "attn.qkv.weight"), ("proj_ws", "attn.proj.weight"), ("fc1_ws", "mlp.fc1.weight"),
                ("fc2_ws", "mlp.fc2.weight"))
 BLOCK_PARAMS = (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
@@ -377,6 +385,35 @@ def folded_linear(get, name):
     ls = (w64 @ g.double()).float().contiguous()
     lt = (w64 @ beta.double() + bias.double()).float().contiguous()
     return split_image((weight * g[None, :]).contiguous(), image_layout(name)), ls, lt
+
+
+def head_major_qkv(get, name, heads, fold):
+    """(image, hb, hl) for the fused qkv + attention kernel (include/pafuse_hip.h pafuse_block_weights.qkv_hs): the qkv weight
+    [3C, C] re-ordered head by head - q_h, k_h, v_h, each zero-padded from d to DP rows (DP = 32 for d <= 32, else 48) - as
+    a layout-2 image; hb = the bias in that order; with the LayerNorm folded the image is that of W (.) g, hb = W beta + b
+    and hl = W g (folded_linear's vectors, re-ordered)."""
+    weight = get(name).detach()
+    C3, C = weight.shape
+    d = C3 // 3 // heads
+    dp = 32 if d <= 32 else 48
+    stem = name[:-len("weight")]
+    bias = get(stem + "bias").detach()
+    hl = None
+    if fold:
+        block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
+        g, beta = get(f"{block}.{norm}.weight").detach(), get(f"{block}.{norm}.bias").detach()
+        w64 = weight.double()
+        hl = (w64 @ g.double()).float()
+        bias = (w64 @ beta.double() + bias.double()).float()
+        weight = weight * g[None, :]
+
+    def reorder(t):                     # [3C, ...] -> [heads * 3 * dp, ...]
+        t = t.reshape(3, heads, d, *t.shape[1:])
+        out = t.new_zeros((heads, 3, dp) + tuple(t.shape[3:]))
+        out[:, :, :d] = t.transpose(0, 1)
+        return out.reshape(heads * 3 * dp, *t.shape[3:]).contiguous()
+    image = split_image(reorder(weight), 2)
+    return image, reorder(bias), (reorder(hl) if hl is not None else None)
 
 
 def fill_block_struct(dst, blk):

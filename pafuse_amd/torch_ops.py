@@ -125,6 +125,7 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
         for n, t in table.items():
             if n.endswith(tuple(FOLDED_LINEAR)):
                 images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n)
+
             elif n.endswith(SPLIT_SUFFIXES):
                 images[n] = cached_split_image(t, image_layout(n))
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
