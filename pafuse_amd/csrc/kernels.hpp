@@ -1774,6 +1774,10 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
         }
     __syncthreads();
 
+#ifdef PAFUSE_FQA_ABL   // timing ablation (tools/fqa_ablation.sh): K loop + phase 2, no attention
+    if (Qs[tid] == 12345.678f) fp.o[0] = Ks[tid];
+    return;
+#endif
     // ---- phase 3: attention per (sequence of the tile, 16-query tile), one item per wave at a time (attn_kernel's arithmetic)
     constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16;
     const int l15 = c, g4 = qd;
