@@ -1,5 +1,5 @@
 /* queue_concurrency.c - torch-free reproducer of the multi-queue hazard of the bf16-MFMA modes (VERDICT r2 item 5,
- * profiles/r02_bf16_mfma_concurrency.md): three independent copies of ONE body-part denoiser (own weights, own split
+ * profiles/r03_bf16_mfma_concurrency.md has the root cause): three independent copies of ONE body-part denoiser (own weights, own split
  * images, own workspaces, own outputs) run pafuse_mixste2_forward at the same time on three HIP streams; every output is
  * compared bit for bit with the same copy's single-stream result.  Plain C + the HIP runtime + the C ABI only.
  *   gcc tests/cabi/queue_concurrency.c -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Lpafuse_amd -lpafuse_hip \

@@ -1,3 +1,10 @@
+#!/bin/bash
+# One GPU call: library builds with / without packed-fp32 VALU instructions x 1 / 3 / 6 streams (profiles/r03_slp_streams_ab.json).
+# The variant libraries are NOT kept in the tree; build them first from the product flags of pafuse_amd/build_flags.py:
+#   noslp        product flags minus the -Xclang feature switch, plus -fno-slp-vectorize
+#   noslp_lanes  the same plus -DPAFUSE_ALLOW_BF16_LANES          slp_lanes  neither switch, plus -DPAFUSE_ALLOW_BF16_LANES
+#   (hipcc <flags> -shared pafuse_amd/csrc/pafuse_hip.hip -o tools/bin/<variant>/libpafuse_hip.so)
+# "product" in this script was the round-2 build (packed fp32, bf16 modes on one stream); today's product build is the fixed one.
 set -x
 mkdir -p gpurun_out/r3u
 O=gpurun_out/r3u
