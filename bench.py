@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--dump-output", default=None, metavar="FILE",
                     help="rank 0 saves the last step's gathered predictions [B,T,P,F,J,3] (torch.save): the rehearsal tests "
                          "compare them with a single-process run of the same seed")
+    ap.add_argument("--train-dtype", choices=("f32", "bf16x3"), default="bf16x3",
+                    help="--train: matrix products of the plain GEMMs (qkv, fc1, dX): split precision (default) or fp32 MFMA")
     ap.add_argument("--train", action="store_true",
                     help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
                          "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
@@ -380,6 +382,8 @@ def train_bench(args, rank, local_rank, world, dev):
     B = args.batch if args.batch > 1 else 37
     model, _ = ge.make_model(1, 1, seed=51, device=dev, is_train=True)
     model.n_aux_streams = args.streams
+    train_dtype = args.train_dtype     # 'bf16x3' (default): split products in qkv / fc1 / every dX GEMM; 'f32': fp32 MFMA everywhere
+    model.precision = train_dtype
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
     x2d, _ = gu.synthetic_inputs_2d(B=B, seed=1234 + rank)
     target = gu.synthetic_target_3d(B=B, seed=1235 + rank).to(dev)
@@ -444,7 +448,7 @@ def train_bench(args, rank, local_rank, world, dev):
             "metric": "training clips/sec (H3WB 27x134 clips, fwd+bwd+AdamW)", "value": round(B * world / sec, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": train_dtype, "data": "synthetic",
             "config": {"workload": f"D3DP train step, B={B} clips/GPU, per-part MixSTE2 384/224/256 ch depth 8, "
                                    f"DropPath 0.1, AdamW", "B_per_gpu": B,
                        "parallelism": f"DDP x{world} (RCCL all-reduce of 35 M fp32 grads)" if world > 1 else "single GPU",

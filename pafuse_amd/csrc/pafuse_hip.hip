@@ -418,7 +418,8 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
 
 static bool ln_folded(const pafuse_mixste2_weights* w) { return w->ste[0].qkv_ls != nullptr; }
 
-int check_weights(const pafuse_mixste2_weights* w) {
+// `training`: the training entry points make the images of the weights they multiply themselves (weights change every step)
+int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
     if (!w) return fail(PAFUSE_E_ARG, "null weights");
     static_assert(EMBED_NV * 128 >= 384, "embed kernel covers the widest part");
     if (w->in_chans != 5) return fail(PAFUSE_E_SHAPE, "in_chans must be 5, got %d", w->in_chans);
@@ -433,7 +434,8 @@ int check_weights(const pafuse_mixste2_weights* w) {
     if (w->mlp_hidden < 0 || (w->mlp_hidden > 0 && (w->mlp_hidden % 32 || w->mlp_hidden > 3 * w->channels)))
         return fail(PAFUSE_E_SHAPE, "mlp hidden width %d must be a multiple of 32 and at most 3C = %d", w->mlp_hidden, 3 * w->channels);
     if (!(w->qk_scale >= 0.f)) return fail(PAFUSE_E_ARG, "qk_scale must be positive (0 = head_dim^-0.5)");
-    if (w->operand_bf16 == 2)
+    if (training && w->operand_bf16 == 1) return fail(PAFUSE_E_ARG, "training runs fp32 ('f32') or split-precision ('bf16x3') products");
+    if (w->operand_bf16 == 2 && !training)
         for (int i = 0; i < w->depth; ++i)
             for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]})
                 if (!b->qkv_ws || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)
@@ -1181,7 +1183,7 @@ int pafuse_d3dp_replay_layers(const pafuse_d3dp_config* cfg, int32_t B, int32_t 
 
 // ------------------------------------------------------------------------------------------------- training
 size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights* w, int32_t B) {
-    if (!w || B <= 0 || check_weights(w)) return 0;
+    if (!w || B <= 0 || check_weights(w, true)) return 0;
     return train_bytes(w, B);
 }
 
@@ -1189,7 +1191,7 @@ int pafuse_mixste2_train_forward(const pafuse_mixste2_weights* w, const float* x
                                  int32_t B, const float* drop_path, float* out, void* saved, size_t saved_bytes,
                                  void* stream) {
     StreamDevice on_stream_device(stream);
-    int rc = check_weights(w);
+    int rc = check_weights(w, true);
     if (rc) return rc;
     if (!x2d || !x3d || !t || !out || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_forward: bad argument");
     if ((w->mlp_hidden && w->mlp_hidden != 2 * w->channels) || w->qk_scale != 0.f)
@@ -1207,7 +1209,7 @@ int pafuse_mixste2_train_backward(const pafuse_mixste2_weights* w, const pafuse_
                                   int32_t B, const float* drop_path, void* saved, size_t saved_bytes, void* stream,
                                   void* side_stream) {
     StreamDevice on_stream_device(stream);
-    int rc = check_weights(w);
+    int rc = check_weights(w, true);
     if (rc) return rc;
     if (!grads || !dout || !saved || B <= 0) return fail(PAFUSE_E_ARG, "mixste2_train_backward: bad argument");
     if (saved_bytes < train_bytes(w, B)) return fail(PAFUSE_E_WORKSPACE, "mixste2_train_backward: buffer too small");

@@ -119,15 +119,28 @@ class MixSTE2(nn.Module):
         self._side_by_device = {}
 
     # ------------------------------------------------------------------------------------------- C structs
-    def weights_struct(self):
-        """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes)."""
+    def weights_struct(self, images=True):
+        """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes).
+        images=False (training): no pre-split / folded images - the training entry points split the weight a GEMM is
+        about to read themselves (weights change every step)."""
         # attribute access, not named_parameters(): nn.DataParallel replicas keep their copies as plain attributes
         def get(name):
             if name.endswith("attn.qkv.bias") and not self.qkv_bias:
                 return self._zero_qkv_bias
             return attrgetter(name)(self)
         mode = int(self.operand_bf16)
-        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode)
+        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode, bool(images))
+        if not images:
+            hit = self._wcache_by_device.get(("train", self._freqs.device.index))
+            if hit is not None and hit[0] == key:
+                return hit[1]
+            w = _lib.MixSTE2Weights()
+            fill_weights_struct(w, get, self._freqs, self.num_frame, self.num_joints, self.embed_dim,
+                                self.block_depth, self.num_heads, self.in_chans, mode, None)
+            w.mlp_hidden = self.mlp_hidden
+            w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
+            self._wcache_by_device[("train", self._freqs.device.index)] = (key, w)
+            return w
         fold = mode == 2 and bool(self.fold_layernorm)
         if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
@@ -188,9 +201,9 @@ class MixSTE2(nn.Module):
                     or self.attn_drop_rate):
                 raise NotImplementedError("training implements the PAFUSE configuration: qkv_bias=True, qk_scale=None, "
                                           "mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
-            if self.operand_bf16:
-                raise NotImplementedError("bf16 / split-precision products are inference options; training runs the "
-                                          "fp32 matrix cores (set precision = 'f32')")
+            if self.operand_bf16 == 1:
+                raise NotImplementedError("rounded-bf16 products are an inference option; training runs fp32 ('f32') or "
+                                          "split-precision ('bf16x3') products")
             return self._forward_train(x_2d, x_3d, t)
         B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()
@@ -268,7 +281,7 @@ class _TrainFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x_2d, x_3d, t, drop, *params):
         lib = _lib.load()
-        w = module.weights_struct()
+        w = module.weights_struct(images=False)
         B, F, J, _ = x_3d.shape
         nbytes = lib.pafuse_mixste2_train_bytes(C.byref(w), B)
         if nbytes == 0:
@@ -287,7 +300,7 @@ class _TrainFunction(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         module = ctx.module
-        w = module.weights_struct()
+        w = module.weights_struct(images=False)
         shapes = [attrgetter(n)(module).shape for n in module._param_names]
         sizes = [(s.numel() + 3) // 4 * 4 for s in shapes]               # keep every gradient 16-byte aligned
         flat = torch.zeros(sum(sizes), device=dout.device, dtype=torch.float32)    # one fill instead of 208

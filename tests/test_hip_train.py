@@ -87,9 +87,13 @@ def test_g13_d3dp_train_golden():
         assert torch.allclose(got[2:], want[2:], rtol=2e-3, atol=2e-4 * scale), k
 
 
-@pytest.mark.parametrize("part,B,depth,rate,rel", [("body", 3, 2, 0.3, 2e-4), ("face", 2, 2, 0.3, 2e-4), ("hands", 2, 2, 0.3, 2e-4),
-                                                   ("body", 37, 8, 0.1, 5e-4)])
-def test_train_gradients_vs_oracle_real_widths(part, B, depth, rate, rel):
+@pytest.mark.parametrize("part,B,depth,rate,rel,precision",
+                         [("body", 3, 2, 0.3, 2e-4, "f32"), ("face", 2, 2, 0.3, 2e-4, "f32"), ("hands", 2, 2, 0.3, 2e-4, "f32"),
+                          ("body", 37, 8, 0.1, 5e-4, "f32"),
+                          # split-precision products in the plain GEMMs of training (qkv, fc1, every dX): the same bounds
+                          ("body", 3, 2, 0.3, 2e-4, "bf16x3"), ("face", 2, 2, 0.3, 2e-4, "bf16x3"),
+                          ("hands", 2, 2, 0.3, 2e-4, "bf16x3"), ("body", 37, 8, 0.1, 5e-4, "bf16x3")])
+def test_train_gradients_vs_oracle_real_widths(part, B, depth, rate, rel, precision):
     """one part at its real width, DropPath active with seeded factors, against torch autograd over the oracle on the
     CPU: depth 2 at small batches for every part, and BASELINE configs[4]'s own size for the body denoiser - depth 8,
     B = 37 clips (1024 // 27, main_h3wb.py:781), drop_path_rate 0.1 (diffusionpose.py:147): 23 976 tokens, every one of
@@ -101,6 +105,7 @@ def test_train_gradients_vs_oracle_real_widths(part, B, depth, rate, rel):
     sd = {k: gu.seeded_tensor(k, v.shape, 77) for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
     m = m.to(DEV).train()
+    m.operand_bf16 = {"f32": 0, "bf16x3": 2}[precision]
     g = torch.Generator().manual_seed(78)
     drops = []
     for r in orc.drop_path_rates(rate, depth):

@@ -27,6 +27,7 @@ run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o train -- pyt
 run python3 "$R/bench.py" > "$O/bench_line.json" 2> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --dtype f32 --no-cpu-baseline > "$O/bench_line_f32.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --train --no-cpu-baseline > "$O/train_bench_line_unprofiled.json" 2>> "$O/bench.err" || exit 1
+run python3 "$R/bench.py" --train --train-dtype f32 --no-cpu-baseline > "$O/train_bench_line_f32_unprofiled.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/tools/soak_determinism.py" 200 > "$O/soak_determinism.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/tests/reports/error_budget.py" --out "$O/error_budget.json" > "$O/error_budget.log" 2>&1 || exit 1
 run python3 "$R/tests/reports/parity_report.py" --out "$O/parity_report.json" > "$O/parity_report.log" 2>&1 || exit 1

@@ -22,6 +22,7 @@ cp "$O/bench_line_f32.json" "$R/profiles/r03_bench_line_f32.json"
 cp "$O/stats_bench_line.json" "$R/profiles/r03_bench_line_under_rocprof.json"
 cp "$O/train_bench_line.json" "$R/profiles/r03_train_bench_line_under_rocprof.json"
 cp "$O/train_bench_line_unprofiled.json" "$R/profiles/r03_train_bench_line_unprofiled.json"
+cp "$O/train_bench_line_f32_unprofiled.json" "$R/profiles/r03_train_bench_line_f32_unprofiled.json"
 cp "$O/soak_determinism.json" "$R/profiles/r03_soak_determinism.json"
 cp "$O/parity_report.json" "$R/profiles/r03_parity_report.json"
 cp "$O/error_budget.json" "$R/profiles/r03_error_budget.json"
