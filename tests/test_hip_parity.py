@@ -30,13 +30,19 @@ DEV = "cuda"
 # that case and protocol on MI355X and committed in profiles/r03_parity_report.json (tests/reports/parity_report.py runs
 # exactly the case functions of this module), never more than the old blanket 5e-4 mm.  The per-case numbers are a
 # property of both roundings; when the CPU oracle's arithmetic on this box is not the recorded one (its output hash
-# differs: another BLAS code path), only the blanket bound is meaningful and only it is asserted.
+# differs: another BLAS / libm code path), only a host-spread bound is meaningful and only it is asserted
+# (UNRECORDED_HOST_TOL_MM below; the terminal summary then says so).
 # J-Agg additionally picks, per (frame, joint), the hypothesis with the smallest 2-D reprojection error: where two
 # hypotheses tie to within rounding the two runs may pick differently, and one different pick moves the clip mean by
 # (difference of the two hypotheses' 3-D errors) / 3618 (measured once in 20 steps x 3 618 joints: 1.1e-2 mm).  J-Agg is
 # therefore compared on the joints where both runs make the same pick, and the picks that differ are bounded: few, and
 # each a genuine near-tie (_j_agg_compare).
 BLANKET_TOL_MM = 5e-4
+# The CPU oracle's own fp32 result depends on the host it runs on (libm's sin / cos / exp in the timestep embedding, BLAS
+# code paths): profiles/r03_host_variation.json measures up to 1.6e-3 mm between two x86 hosts on identical inputs.  On a host
+# whose oracle output is not the recorded one (hash mismatch) the per-case numbers and the 5e-4 cap describe another
+# arithmetic; what can be asserted there is that the HIP path is within that host-to-host spread of the oracle.
+UNRECORDED_HOST_TOL_MM = 2e-3
 BOUND_FACTOR = 1.25
 BOUND_FLOOR_MM = 2e-5          # below this a measured value says nothing about the next weight seed's rounding
 PARITY_REPORT = "profiles/r03_parity_report.json"
@@ -60,7 +66,7 @@ def parity_bounds(case, ref):
     if e is None:
         pytest.fail(f"{PARITY_REPORT} has no case '{case}': regenerate it with tests/reports/parity_report.py on the GPU box")
     if ref is not None and e["oracle_sha256"] != tensor_sha256(ref):
-        return {k: BLANKET_TOL_MM for k in PROTOCOLS}, False
+        return {k: UNRECORDED_HOST_TOL_MM for k in PROTOCOLS}, False
     m = dict(e["mpjpe_mm_abs_diff_max"])
     m["J-Agg"] = e["j_agg_same_picks_mm_abs_diff_max"]
     # ref None: the case compares with a committed golden made on ANOTHER host (G19: the reference on the build container's
@@ -435,7 +441,7 @@ def _assert_mpjpe_parity(out, ref, target, x2d, case):
     PARITY_LINES.append(f"{case}: |dMPJPE| max mm " + ", ".join(f"{k} {float(v.max()):.2e} (<= {bounds[k]:.2e})" for k, v in diffs.items()) +
                         f", J-Agg same picks {d:.2e} (<= {bounds['J-Agg']:.2e}), different picks {frac:.1e} of joints; north_star "
                         f"1e-4 mm met at {met} of {total} (step, protocol) pairs; bounds: "
-                        + ("1.25 x committed measurement" if per_case else "blanket (oracle arithmetic differs from the recorded one)"))
+                        + ("1.25 x committed measurement" if per_case else "host-spread bound 2e-3 mm (the oracle's arithmetic on this host is not the recorded one)"))
     for k, v in diffs.items():
         assert v.max() <= bounds[k], (case, k, float(v.max()), bounds[k])
     # same picks: the case's bound; different picks: rare, and only where the two best hypotheses tie to within the
