@@ -232,6 +232,17 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
     if (p.bf16 == 2 && (debug_f32_mask() & 2)) p.bf16 = 0;
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
+    if constexpr (EPI == EPI_ROWLN_TRAIN) {   // training forward with split products: the three PAFUSE widths (train_host.inc)
+        if (p.bf16 == 2) {
+            switch (p.N) {
+                case 384: return launch_gemm_dma<2, 2, 6, EPI, 2, 2, 16>(p, s);
+                case 256: return launch_gemm_dma<2, 2, 4, EPI, 2, 2, 16>(p, s);
+                case 224: if (p.M >= 4096) return launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16>(p, s); break;
+                default: break;
+            }
+            p.bf16 = 0;   // no split whole-row tile for this shape: the fp32 kernels below
+        }
+    }
     if constexpr (EPI == EPI_ROWLN) {
         if (p.bf16 == 2) {
             switch (p.N) {
