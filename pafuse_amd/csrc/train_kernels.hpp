@@ -118,6 +118,106 @@ __global__ void __launch_bounds__(256) ln_backward_kernel(const LnBackwardParams
     }
 }
 
+// The same for the PAFUSE widths (C % 4 == 0, C <= 384): a HALF-wave per row - lane li owns the channel quads li, li + 32,
+// li + 64 as 16-byte loads / stores, the two rows of a wave run side by side and every row reduction is a 32-lane
+// shuffle chain (the one-wave-per-row form above issues 6 scalar loads per tensor and row and walks its 16 rows one after
+// the other behind five 64-lane reductions each: 86 us per launch against a 37 us byte floor).  Eight half-waves per
+// workgroup, 8 rows each: the same 64 rows per workgroup and the same partial[block][3][C] layout.
+constexpr int LNB_NV = 3;  // channel quads per lane (C <= 384)
+
+__global__ void __launch_bounds__(256) ln_backward_quad_kernel(const LnBackwardParams p) {
+    __shared__ __attribute__((aligned(16))) float red[8][3][4 * 32 * LNB_NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, hw = wave * 2 + (lane >> 5), C = p.C;
+    const int NQ = C / 4;
+    const float invC = 1.0f / (float)C;
+    f32x4 dw[LNB_NV], db[LNB_NV], ds[LNB_NV], wv[LNB_NV];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LNB_NV; ++i) {
+        dw[i] = db[i] = ds[i] = zero;
+        wv[i] = (li + 32 * i < NQ) ? *reinterpret_cast<const f32x4*>(p.w + 4 * (li + 32 * i)) : zero;
+    }
+    constexpr int ROWS = LNB_ROWS_PER_BLOCK / 8;
+    const int64_t row0 = (int64_t)blockIdx.x * LNB_ROWS_PER_BLOCK + hw * ROWS;
+    for (int rr = 0; rr < ROWS; ++rr) {
+        const int64_t row = row0 + rr;
+        const bool live = row < p.M;              // uniform per half-wave; a dead half still takes part in the shuffles
+        const int64_t ro = (live ? row : p.M - 1) * C;
+        f32x4 x[LNB_NV], dy[LNB_NV], ad[LNB_NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_NV; ++i) {
+            const bool in = li + 32 * i < NQ;
+            x[i] = in ? *reinterpret_cast<const f32x4*>(p.x + ro + 4 * (li + 32 * i)) : zero;
+            dy[i] = (in && live) ? *reinterpret_cast<const f32x4*>(p.dy + ro + 4 * (li + 32 * i)) : zero;
+            ad[i] = (in && p.add) ? *reinterpret_cast<const f32x4*>(p.add + ro + 4 * (li + 32 * i)) : zero;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += x[i][e];
+        }
+        const float mean = half_wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_NV; ++i)
+            if (li + 32 * i < NQ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = x[i][e] - mean;
+                    q += dlt * dlt;
+                }
+            }
+        const float rstd = 1.0f / sqrtf(half_wave_sum(q) * invC + p.eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_NV; ++i)
+            if (li + 32 * i < NQ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[i][e] = (x[i][e] - mean) * rstd;  // xh
+                    const float g = dy[i][e] * wv[i][e];
+                    sg += g;
+                    sgx += g * x[i][e];
+                    dw[i][e] += dy[i][e] * x[i][e];
+                    db[i][e] += dy[i][e];
+                }
+            }
+        const float c1 = half_wave_sum(sg) * invC, c2 = half_wave_sum(sgx) * invC;
+        const float d = (p.drop && live) ? p.drop[seq_of(row, p.map)] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < LNB_NV; ++i) {
+            const int c4 = li + 32 * i;
+            if (c4 < NQ && live) {
+                f32x4 v, sv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = rstd * (dy[i][e] * wv[i][e] - c1 - x[i][e] * c2);
+                    if (p.add) v[e] += ad[i][e];
+                    sv[e] = d * v[e];
+                }
+                *reinterpret_cast<f32x4*>(p.dx + ro + 4 * c4) = v;
+                if (p.out_scaled) {
+                    *reinterpret_cast<f32x4*>(p.out_scaled + ro + 4 * c4) = sv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds[i][e] += sv[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LNB_NV; ++i) {
+        *reinterpret_cast<f32x4*>(&red[hw][0][4 * (li + 32 * i)]) = dw[i];
+        *reinterpret_cast<f32x4*>(&red[hw][1][4 * (li + 32 * i)]) = db[i];
+        *reinterpret_cast<f32x4*>(&red[hw][2][4 * (li + 32 * i)]) = ds[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        float t = red[0][which][c];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) t += red[h][which][c];   // fixed order
+        p.partial[((int64_t)blockIdx.x * 3 + which) * C + c] = t;
+    }
+}
+
 // out[i] = (accumulate ? out[i] : 0) + sum_s partial[s * stride + i], in a fixed order: a workgroup owns 256 / G
 // columns; its G lane groups each sum the parts s = g, g + G, ... in ascending order, then the G group sums are added
 // in ascending g.  G = 1 for wide outputs (plenty of columns to fill the chip), 16 for narrow ones with many parts
