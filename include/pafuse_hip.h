@@ -86,10 +86,12 @@ typedef struct pafuse_mixste2_weights {
     int32_t operand_bf16; /* matrix-product mode of the linear layers (activations, LayerNorm, softmax, attention and
                              everything in memory are fp32 in every mode):
                              0: fp32-input matrix cores (v_mfma_f32_32x32x2_f32): a k-ordered fp32 FMA chain.
-                             2: split precision "bf16x3" (inference): every fp32 operand is the exact sum of three
-                                bf16 slices, products keep the six terms above 2^-24 relative on the bf16 matrix cores
-                                with fp32 accumulation - fp32-equivalent results (closer to exact arithmetic than the
-                                FMA chain) at 2.7x the matrix rate; needs the *_ws weight images.
+                             2: split precision "bf16x3": every fp32 operand is the exact sum of three bf16 slices,
+                                products keep the six terms above 2^-24 relative on the bf16 matrix cores with fp32
+                                accumulation - fp32-equivalent results (closer to exact arithmetic than the FMA
+                                chain) at 2.7x the matrix rate.  Inference entry points need the *_ws weight images;
+                                the training entry points do not (they split the weight a GEMM is about to read
+                                themselves - weights change every step) and run every GEMM of the step this way.
                              1: opt-in reduced precision - operands rounded to ONE bf16 (RNE), fp32 accumulate
                                 (BASELINE configs[1]; inference only) */
     int32_t mlp_hidden;   /* MixSTE2(mlp_ratio=...): hidden width int(C * mlp_ratio) of every block's MLP, a multiple of 32,
@@ -283,7 +285,9 @@ int pafuse_d3dp_replay_layers(const pafuse_d3dp_config *cfg, int32_t B, int32_t 
  * Backward: dout [B,F,J,3] -> ADDS the gradient of every parameter into the buffer the like-named pointer of `grads`
  * addresses (same struct as the weights; `freqs` and the dimensions are ignored).  All row reductions are two-stage
  * in a fixed order: bit-reproducible, no atomics.  `side_stream` (may be NULL): a second HIP stream the weight-gradient
- * GEMMs run on next to the input-gradient chain (forked and joined with events inside the call; results identical). */
+ * GEMMs run on next to the input-gradient chain (forked and joined with events inside the call; results identical).
+ * w->operand_bf16: 0 = every GEMM on the fp32 matrix cores; 2 = split-precision products in the GEMMs of the step
+ * (qkv, fc1, the whole-row proj / fc2, every dX and dW; fp32-equivalent, gradients within the same bounds); 1 is refused. */
 size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights *w, int32_t B);
 int pafuse_mixste2_train_forward(const pafuse_mixste2_weights *w, const float *x2d, const float *x3d, const int64_t *t,
                                  int32_t B, const float *drop_path, float *out, void *saved, size_t saved_bytes,
