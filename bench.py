@@ -40,6 +40,8 @@ GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md 
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 matrix peak (opt-in --dtype bf16 runs are priced against this)
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # bf16x3: six bf16 MFMA products per fp32-equivalent product = 416.7
+PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3   # f16x2: three fp16 MFMA products per fp32-equivalent product = 833.3
+SPLIT_DTYPES = ("bf16x3", "f16x2")             # the fp32-equivalent split-precision modes (same kernels, same schedule)
 
 
 def main():
@@ -59,10 +61,12 @@ def main():
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
-    ap.add_argument("--dtype", choices=("f32", "bf16x3", "bf16"), default=DEFAULT_DTYPE,
+    ap.add_argument("--dtype", choices=("f32", "bf16x3", "f16x2", "bf16"), default=DEFAULT_DTYPE,
                     help="matrix-product mode of the linear layers: f32 = fp32-input matrix cores; bf16x3 = split "
                          "precision (fp32 operands as three bf16 slices, six bf16 MFMA products, fp32 accumulate: "
-                         "fp32-equivalent results, same parity bounds); bf16 = opt-in reduced precision (operands "
+                         "fp32-equivalent results, same parity bounds); f16x2 = split precision on the fp16 matrix cores "
+                         "(activations as two fp16 slices, scaled weights as three, three MFMA products: fp32-equivalent, "
+                         "same parity bounds); bf16 = opt-in reduced precision (operands "
                          "rounded to one bf16) - never the contract's line")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the contract's line); gloo only for "
@@ -179,10 +183,13 @@ def main():
     # HIP streams (hardware queues) the library spread one rank's loop over
     lanes = _lib.check(_lib.load().pafuse_d3dp_lanes(C.byref(model.config_struct(True)), B, P_local, args.streams))
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
-    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "f16x2": PEAK_F16X2_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
     dtype_label = {"f32": "f32",
                    "bf16x3": "bf16x3 (fp32 operands split into three bf16 slices, six bf16 MFMA products per fp32-"
                              "equivalent product, fp32 accumulate; activations and everything in memory fp32)",
+                   "f16x2": "f16x2 (fp32 activations split into two fp16 slices, power-of-two-scaled fp32 weights into three, "
+                            "three fp16 MFMA products per fp32-equivalent product, fp32 accumulate; activations and everything "
+                            "in memory fp32)",
                    "bf16": "bf16 operands, f32 accumulate (opt-in, not the parity path)"}[args.dtype]
 
     line = {
@@ -201,8 +208,8 @@ def main():
                    "single_device_rehearsal": bool(args.single_device),
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
-        "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype == "bf16x3" and not args.no_ln_fold),
-        "qkv_attention_fused": bool(args.dtype == "bf16x3" and args.fuse_qkv_attention),
+        "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype in SPLIT_DTYPES and not args.no_ln_fold),
+        "qkv_attention_fused": bool(args.dtype in SPLIT_DTYPES and args.fuse_qkv_attention),
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
         "allgather_ms": gather_ms, "allgather_ms_note": "collective + the one layout pass, max over ranks", "gather_copy_ms": copy_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
@@ -221,7 +228,7 @@ def main():
         reps = 3
         # the replay launches what the timed loop launched: part by part when the loop ran on side streams, the shared
         # grids of the single-stream schedule otherwise (pafuse_set_grouped_launches: the library's process-wide option)
-        per_part = lanes > 1 or args.dtype != "bf16x3"
+        per_part = lanes > 1 or args.dtype not in SPLIT_DTYPES
         was_grouped = lib.pafuse_set_grouped_launches(0 if per_part else 1)
         flops = C.c_double(0.0)
         launches = _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
@@ -244,7 +251,7 @@ def main():
                          8: "grouped_rowln_kernel"} if not per_part else
                         {1: "gemm16_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
                          4: "gemm_kernel (one launch per part)", 8: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)"}
-                        if args.dtype == "bf16x3" else
+                        if args.dtype in SPLIT_DTYPES else
                         {1: "gemm_kernel", 2: "gemm_kernel<..EPI_ROWLN>", 4: "gemm_kernel", 8: "gemm_kernel<..EPI_ROWLN>"})
         for bit, name in ((1, "qkv"), (2, "proj+LN"), (4, "fc1+GELU"), (8, "fc2+LN")):
             fl = C.c_double(0.0)
@@ -289,18 +296,21 @@ def main():
         # (i) per token and block: qkv reads C writes 3C; proj reads o, x writes x, xn; fc1 reads C writes 2C; fc2 reads
         #     2C, x writes x, xn = 16 C floats (14 with the LayerNorm folded into qkv / fc1: no xn, 8 B of statistics per
         #     row instead); 16 blocks per pass; + the 139.8 MB of weights once
-        per_token = 14 if (args.dtype == "bf16x3" and not args.no_ln_fold) else 16
+        per_token = 14 if (args.dtype in SPLIT_DTYPES and not args.no_ln_fold) else 16
         alg_unfused = (mc * 4 * per_token * 16 + 139.8e6) / launches
         alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
         mfma = ("v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
-                "v_mfma_f32_32x32x16_bf16; the qkv layers v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16x3" else "v_mfma_f32_32x32x16_bf16")
+                "v_mfma_f32_32x32x16_bf16; the qkv layers v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16x3" else
+                "v_mfma_f32_32x32x16_f16; the qkv layers v_mfma_f32_16x16x32_f16" if args.dtype == "f16x2" else "v_mfma_f32_32x32x16_bf16")
         peak_note = {"f32": "dense f32-input matrix peak",
                      "bf16x3": "dense bf16 matrix peak 2500 / 6 products; the same FLOPs against the f32-input matrix "
                                f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
+                     "f16x2": "dense fp16 matrix peak 2500 / 3 products; the same FLOPs against the f32-input matrix "
+                              f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
-        products = 6 if args.dtype == "bf16x3" else 1          # matrix instructions executed per useful product
+        products = {"bf16x3": 6, "f16x2": 3}.get(args.dtype, 1)          # matrix instructions executed per useful product
         family = (("gemm16_kernel, gemm_kernel, gemm_dma_kernel" if per_part else
-                   "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype == "bf16x3" else "gemm_kernel")
+                   "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype in SPLIT_DTYPES else "gemm_kernel")
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {family} ({mfma})",
                             "schedule": (f"timed loop: {lanes} streams, one body-part denoiser per stream; this object: the same "
                                          "launches replayed one after the other on one stream" if lanes > 1 else
@@ -313,7 +323,7 @@ def main():
                             # dense peak of the instruction that runs
                             "frac_of_bf16_dense_peak": None if args.dtype == "f32" else round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                             "mfma_pipe_frac": round(achieved * products / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
-                            "mfma_pipe_note": "executed matrix FLOPs (useful x 6 products in bf16x3) / dense peak of the instruction; "
+                            "mfma_pipe_note": "executed matrix FLOPs (useful x 6 products in bf16x3, x 3 in f16x2) / dense peak of the instruction; "
                                               "SQ_VALU_MFMA_BUSY_CYCLES of the same launches: profiles/r03_pmc_mfma_util.json",
                             "traffic": traffic,
                             "traffic_unit": "HBM bytes per launch",

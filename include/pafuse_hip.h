@@ -54,7 +54,7 @@ typedef struct pafuse_block_weights {
     const float *norm2_w, *norm2_b; /* [C] */
     const float *fc1_w, *fc1_b;     /* [H,C], [H]   (H = mlp hidden width, 2C by default) */
     const float *fc2_w, *fc2_b;     /* [C,H], [C] */
-    /* split-precision mode only (pafuse_mixste2_weights.operand_bf16 == 2): the pre-split images of the four linear
+    /* split-precision modes only (pafuse_mixste2_weights.operand_bf16 == 2 or 3): the pre-split images of the four linear
      * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv), 1 (proj, fc2), 0 (fc1)
      * (a cache - remake after a weight changes); NULL otherwise */
     const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
@@ -92,6 +92,9 @@ typedef struct pafuse_mixste2_weights {
                                 chain) at 2.7x the matrix rate.  Inference entry points need the *_ws weight images;
                                 the training entry points do not (they split the weight a GEMM is about to read
                                 themselves - weights change every step) and run every GEMM of the step this way.
+                             3: split precision "f16x2" (inference only): activations as two fp16 slices, weights as three
+                                (images made with PAFUSE_SPLIT_F16X2), three products per k on the fp16 matrix cores -
+                                fp32-equivalent results at 5.3x the fp32 matrix rate; needs the *_ws images.
                              1: opt-in reduced precision - operands rounded to ONE bf16 (RNE), fp32 accumulate
                                 (BASELINE configs[1]; inference only) */
     int32_t mlp_hidden;   /* MixSTE2(mlp_ratio=...): hidden width int(C * mlp_ratio) of every block's MLP, a multiple of 32,
@@ -150,7 +153,7 @@ int pafuse_set_grouped_launches(int32_t on);
 int pafuse_linear(const float *A, const float *W, const float *bias, float *out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void *stream);
 
-/* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K bytes
+/* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K + 256 bytes
  * ([K/c][N][6c B] with c = 32 or 16: per row and K chunk, sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels'
  * LDS image).  `layout` names the layer the image is for - it decides c and the rotation of the sub-blocks inside a row:
  *   0  mlp.fc1 (and pafuse_linear_split without PAFUSE_LINEAR_QKV_IMAGE): the 32x32x16-MFMA plain kernel
@@ -160,6 +163,16 @@ int pafuse_linear(const float *A, const float *W, const float *bias, float *out,
  * has layout 2): the unit entry of the split-precision products, which replace the same nn.Linear call sites
  * (common/mixste.py:38-42,65,80). */
 #define PAFUSE_LINEAR_QKV_IMAGE 2
+/* Second split-precision scheme, "f16x2" (operand_bf16 == 3): `layout | PAFUSE_SPLIT_F16X2` makes the image of that layout
+ * for it - the weight scaled by a power of two 2^k (the tensor's largest |W 2^k| in [2^14, 2^15)) as three fp16 slices
+ * w0 = f16(Ws), w1 = f16(Ws - w0), w2 = f16(w0 2^-11) in the geometry of the bf16x3 image, 2^-k in the image's tail; the
+ * kernels split an activation a into hi = f16(a), lo = f16((a - hi) 2^11) and keep hi w0 + hi w1 + lo w2 - THREE products
+ * per k on the fp16 matrix cores, fp32 accumulate, the accumulator multiplied by 2^-k in the epilogue.  fp32-equivalent
+ * (same bounds as bf16x3 against exact arithmetic, tests/test_hip_parity.py); activations must stay below 65504 in
+ * magnitude (beyond it the row's outputs are inf / NaN, never silently wrong).  pafuse_linear_split on such an image: add
+ * PAFUSE_LINEAR_F16X2_IMAGE to `act`.  Every image is pafuse_split_weights_bytes(N, K) = 6*N*K + 256 bytes (the tail). */
+#define PAFUSE_SPLIT_F16X2 4
+#define PAFUSE_LINEAR_F16X2_IMAGE 4
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K);
 int pafuse_split_weights(const float *W, int32_t N, int32_t K, int32_t layout, void *out, void *stream);
 int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, float *out, int64_t M, int32_t N,

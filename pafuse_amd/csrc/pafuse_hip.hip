@@ -75,15 +75,15 @@ struct StreamDevice {
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
-    constexpr size_t stage_bytes = (size_t)NSTAGE * (BF16 == 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * sizeof(float);
-    if (BF16 == 2 && !p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
+    constexpr size_t stage_bytes = (size_t)NSTAGE * (BF16 >= 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * sizeof(float);
+    if (BF16 >= 2 && !p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     static_assert(EPI == EPI_BIAS || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
     static_assert(stage_bytes <= 160 * 1024, "LDS budget");
     size_t lds = stage_bytes;
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, BF16>;
 #ifdef PAFUSE_DIAG
     static const int dbg_pad = [] { const char* e = getenv("PAFUSE_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
-    if (dbg_pad && BF16 == 2 && EPI == EPI_BIAS) {  // diagnostic: keep other kernels off this workgroup's CU
+    if (dbg_pad && BF16 >= 2 && EPI == EPI_BIAS) {  // diagnostic: keep other kernels off this workgroup's CU
         lds = std::max(lds, (size_t)dbg_pad);
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     } else
@@ -100,11 +100,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 // qkv projection + attention of one head per workgroup (kernels.hpp fqa_kernel)
-template <int LP, int DP>
+template <int LP, int DP, int F16 = 0>
 int launch_fqa(const FqaParams& f, hipStream_t s) {
     using FT = FqaTile<LP, DP>;
     static_assert(FT::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-    auto k = fqa_kernel<LP, DP>;
+    auto k = fqa_kernel<LP, DP, F16>;
     if (FT::LDS_BYTES > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
@@ -127,6 +127,11 @@ static bool fqa_has(int L, int d) {   // (48, 48) would need 80.4 KB of LDS: one
 int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
     if (f.nseq <= 0) return PAFUSE_OK;
     const int lp = fqa_lp(f.L), dp = fqa_dp(f.d);
+    if (f.g.bf16 == 3) {   // f16x2 products in the projection phase
+        if (lp == 32 && dp == 48) return launch_fqa<32, 48, 1>(f, s);
+        if (lp == 32 && dp == 32) return launch_fqa<32, 32, 1>(f, s);
+        if (lp == 48 && dp == 32) return launch_fqa<48, 32, 1>(f, s);
+    }
     if (lp == 32 && dp == 48) return launch_fqa<32, 48>(f, s);
     if (lp == 32 && dp == 32) return launch_fqa<32, 32>(f, s);
     if (lp == 48 && dp == 32) return launch_fqa<48, 32>(f, s);
@@ -134,14 +139,14 @@ int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
 }
 
 // the qkv layers' kernel on v_mfma_f32_16x16x32_bf16 (kernels.hpp gemm16_tile); the image must be in the M16 layout
-template <int NB, int MINW>
+template <int NB, int MINW, int F16 = 0>
 int launch_gemm16(const GemmParams& p, hipStream_t s) {
     using T = Tile16<NB>;
     static_assert(T::STAGE_BYTES <= 64 * 1024, "LDS budget without the attribute");
     if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     const int64_t tiles = ((p.M + T::BM - 1) / T::BM) * (p.N / T::BN);
     if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
-    hipLaunchKernelGGL((gemm16_kernel<NB, MINW>), dim3((unsigned)tiles), dim3(T::NTHR), T::STAGE_BYTES, s, p);
+    hipLaunchKernelGGL((gemm16_kernel<NB, MINW, F16>), dim3((unsigned)tiles), dim3(T::NTHR), T::STAGE_BYTES, s, p);
     return check_launch("gemm16_kernel");
 }
 
@@ -151,7 +156,7 @@ int launch_gemm16(const GemmParams& p, hipStream_t s) {
 // and 224 run on the LDS-DMA kernel with 16-deep chunks, everything else on 32-deep chunks.
 int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 288 || N == 256 || N == 224)) ? 16 : 32; }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32, int F16 = 0>
 int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     using T = DmaTile<WM, WN, NT, BKC>;
     constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
@@ -159,7 +164,7 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
     if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     if (p.K % BKC) return fail(PAFUSE_E_SHAPE, "split GEMM: K=%d is not a multiple of %d", p.K, BKC);
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, 0, BKC>;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, 0, BKC, F16>;
     if (lds > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -187,6 +192,7 @@ constexpr int debug_f32_mask() { return 0; }
 
 int gemm_bias(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
+    if (p.bf16 < 0 || p.bf16 > 3) return fail(PAFUSE_E_ARG, "linear: matrix-product mode %d", p.bf16);
     if (p.bf16 == 2 && (debug_f32_mask() & 1)) p.bf16 = 0;
     if (p.bf16 == 2 && (debug_f32_mask() & 4) && !p.act) p.bf16 = 0;   // qkv only
     if (p.bf16 == 2 && (debug_f32_mask() & 8) && p.act) p.bf16 = 0;    // fc1 only
@@ -207,6 +213,18 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
         if (p.N % 96 == 0) return launch_gemm16<6, 3>(p, s);     // face 672, single-model 864: 128 x 96
         if (p.N % 64 == 0) return launch_gemm16<4, 4>(p, s);
         return launch_gemm16<2, 4>(p, s);
+    }
+    if (p.bf16 == 3 && p.wlayout == 2) {  // f16x2, the qkv layers: the same tiles, three products on v_mfma_f32_16x16x32_f16
+        if (p.N % 128 == 0) return launch_gemm16<8, 3, 1>(p, s);
+        if (p.N % 96 == 0) return launch_gemm16<6, 3, 1>(p, s);
+        if (p.N % 64 == 0) return launch_gemm16<4, 4, 1>(p, s);
+        return launch_gemm16<2, 4, 1>(p, s);
+    }
+    if (p.bf16 == 3) {  // f16x2: the tiles of the bf16x3 dispatch below, three products per k instead of six
+        if (p.N % 128 == 0 && p.M >= 4096) return launch_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 3>(p, s);
+        if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 3>(p, s);
+        if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 3>(p, s);
+        return launch_gemm<4, 1, 1, EPI_BIAS, 1, 1, 0, 3>(p, s);
     }
     if (p.bf16 == 2) {  // split precision (bf16x3): fp32-equivalent products on the bf16 matrix cores
         // measured per shape with tools/gemm_bench.hip (profiles/r02_gemm_bench_split_v1.log): 128x128 tiles at two
@@ -232,6 +250,7 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
     if (p.bf16 == 2 && (debug_f32_mask() & 2)) p.bf16 = 0;
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
+    if (p.bf16 < 0 || p.bf16 > 3 || (EPI == EPI_ROWLN_TRAIN && p.bf16 == 3)) return fail(PAFUSE_E_ARG, "rowln: matrix-product mode %d", p.bf16);
     if constexpr (EPI == EPI_ROWLN_TRAIN) {   // training forward with split products: the three PAFUSE widths (train_host.inc)
         if (p.bf16 == 2) {
             switch (p.N) {
@@ -244,6 +263,18 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
         }
     }
     if constexpr (EPI == EPI_ROWLN) {
+        if (p.bf16 == 3) {   // f16x2: the bf16x3 tiles below with three products per k
+            switch (p.N) {
+                case 384: return launch_gemm_dma<2, 2, 6, EPI, 2, 2, 16, 1>(p, s);
+                case 288: return launch_gemm_dma<2, 3, 3, EPI, 2, 2, 16, 1>(p, s);
+                case 256: return launch_gemm_dma<2, 2, 4, EPI, 2, 2, 16, 1>(p, s);
+                case 224:
+                    return p.M >= 4096 ? launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16, 1>(p, s) : launch_gemm_dma<2, 1, 7, EPI, 2, 2, 16, 1>(p, s);
+                case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 3>(p, s);
+                case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 3>(p, s);
+                default: return fail(PAFUSE_E_SHAPE, "no f16x2 whole-row kernel for channel width %d", p.N);
+            }
+        }
         if (p.bf16 == 2) {
             switch (p.N) {
                 // picked per width with tools/gemm_bench.hip (profiles/r02_gemm_bench_*.log): the LDS-DMA kernel on 16-deep
@@ -292,11 +323,12 @@ int gemm_rowln_train(const GemmParams& p, hipStream_t s) { return gemm_rowln_as<
 // Only the split-precision mode has them (the fp32 mode overlaps parts on streams instead); anything a grouped kernel
 // has no variant for goes part by part through the dispatch above - same tiles, same arithmetic, same results.
 bool group_ok_rowln(const GemmParams& p) {
-    return p.bf16 == 2 && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 && p.K > 0 &&
-           !(debug_f32_mask() & 2);
+    return (p.bf16 == 2 || p.bf16 == 3) && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 &&
+           p.K > 0 && !(debug_f32_mask() & 2);
 }
 bool group_ok_bias(const GemmParams& p) {
-    return p.bf16 == 2 && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 && !(debug_f32_mask() & 29);
+    return (p.bf16 == 2 || p.bf16 == 3) && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 &&
+           !(debug_f32_mask() & 29);
 }
 // process-wide schedule option (pafuse_set_grouped_launches): the same layer of the parts in shared grids (default) or
 // part by part - same tiles, same arithmetic, same bits either way
@@ -306,7 +338,8 @@ bool grouping_enabled() { return g_grouped.load(std::memory_order_relaxed) != 0;
 template <bool ROWLN>
 int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
     bool ok = grouping_enabled() && n >= 2 && n <= GROUP_MAX;
-    for (int i = 0; i < n && ok; ++i) ok = ps[i].M > 0 && (ROWLN ? group_ok_rowln(ps[i]) : group_ok_bias(ps[i]));
+    for (int i = 0; i < n && ok; ++i)   // (one product scheme per grid)
+        ok = ps[i].M > 0 && ps[i].bf16 == ps[0].bf16 && (ROWLN ? group_ok_rowln(ps[i]) : group_ok_bias(ps[i]));
     if (!ok) {
         for (int i = 0; i < n; ++i) {
             const int rc = ROWLN ? gemm_rowln(ps[i], s) : gemm_bias(ps[i], s);
@@ -342,6 +375,13 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
     if (ROWLN) {
         constexpr size_t lds = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES;  // the widest variant's ring
         static_assert(lds >= 2 * DmaTile<2, 2, 4, 16>::STAGE_BYTES && lds >= 2 * DmaTile<4, 1, 7, 16>::STAGE_BYTES && lds <= 80 * 1024, "LDS");
+        if (ps[0].bf16 == 3) {
+            auto k = grouped_rowln_kernel<EPI_ROWLN, 1>;
+            static DeviceOnce once;
+            if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k, dim3((unsigned)first), dim3(256), lds, s, g);
+            return check_launch("grouped_rowln_kernel");
+        }
         auto k = grouped_rowln_kernel<EPI_ROWLN>;
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -350,7 +390,10 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
     } else {
         constexpr size_t lds = GemmTile<4, 1, 4>::STAGE_FLOATS_SPLIT * sizeof(float);
         static_assert(lds <= 64 * 1024, "LDS");
-        hipLaunchKernelGGL(grouped_bias_kernel<EPI_BIAS>, dim3((unsigned)first), dim3(256), lds, s, g);
+        if (ps[0].bf16 == 3)
+            hipLaunchKernelGGL((grouped_bias_kernel<EPI_BIAS, 3>), dim3((unsigned)first), dim3(256), lds, s, g);
+        else
+            hipLaunchKernelGGL((grouped_bias_kernel<EPI_BIAS, 2>), dim3((unsigned)first), dim3(256), lds, s, g);
         return check_launch("grouped_bias_kernel");
     }
 }
@@ -441,12 +484,13 @@ int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
     if (d % 4 || d > 48) return fail(PAFUSE_E_SHAPE, "head dim %d unsupported", d);
     if (w->joints < 1 || w->joints > 144 || w->frames < 1 || w->frames > 144)
         return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..144", w->joints, w->frames);
-    if (w->operand_bf16 < 0 || w->operand_bf16 > 2) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
+    if (w->operand_bf16 < 0 || w->operand_bf16 > 3) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
     if (w->mlp_hidden < 0 || (w->mlp_hidden > 0 && (w->mlp_hidden % 32 || w->mlp_hidden > 3 * w->channels)))
         return fail(PAFUSE_E_SHAPE, "mlp hidden width %d must be a multiple of 32 and at most 3C = %d", w->mlp_hidden, 3 * w->channels);
     if (!(w->qk_scale >= 0.f)) return fail(PAFUSE_E_ARG, "qk_scale must be positive (0 = head_dim^-0.5)");
-    if (training && w->operand_bf16 == 1) return fail(PAFUSE_E_ARG, "training runs fp32 ('f32') or split-precision ('bf16x3') products");
-    if (w->operand_bf16 == 2 && !training)
+    if (training && (w->operand_bf16 == 1 || w->operand_bf16 == 3))
+        return fail(PAFUSE_E_ARG, "training runs fp32 ('f32') or split-precision ('bf16x3') products");
+    if (w->operand_bf16 >= 2 && !training)
         for (int i = 0; i < w->depth; ++i)
             for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]})
                 if (!b->qkv_ws || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)
@@ -460,7 +504,7 @@ int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
             const int set = (b->qkv_ls != nullptr) + (b->qkv_lt != nullptr) + (b->fc1_ls != nullptr) + (b->fc1_lt != nullptr);
             if (set != (fold ? 4 : 0)) return fail(PAFUSE_E_ARG, "folded-LayerNorm vectors must be set in every block or in none");
         }
-    if (fold && w->operand_bf16 != 2) return fail(PAFUSE_E_ARG, "the folded LayerNorm exists in split-precision mode only");
+    if (fold && w->operand_bf16 < 2) return fail(PAFUSE_E_ARG, "the folded LayerNorm exists in the split-precision modes only");
     return PAFUSE_OK;
 }
 
@@ -503,7 +547,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     a.scale = qk_scale != 0.f ? qk_scale : 1.0f / sqrtf((float)(C / heads));  // qk_scale or head_dim ** -0.5  mixste.py:52
     // the two in one kernel where a head-major image was supplied and the shape has a fused form
     b.fused = false;
-    if (bf16 == 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads) && (!fold || bw.qkv_hl)) {
+    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads) && (!fold || bw.qkv_hl)) {
         const int lp = fqa_lp(L), dp = fqa_dp(C / heads), rows = 128 + (lp == 48 ? 4 : 0);
         FqaParams& f = b.fqa;
         f.g = g;
@@ -678,7 +722,9 @@ int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, in
 bool parts_groupable(const pafuse_d3dp_config* cfg) {
     if (!grouping_enabled() || cfg->num_parts < 2 || cfg->num_parts > GROUP_MAX) return false;
     for (int i = 0; i < cfg->num_parts; ++i)
-        if (cfg->part[i].operand_bf16 != 2 || cfg->part[i].depth != cfg->part[0].depth) return false;
+        if (cfg->part[i].operand_bf16 < 2 || cfg->part[i].operand_bf16 != cfg->part[0].operand_bf16 ||
+            cfg->part[i].depth != cfg->part[0].depth)
+            return false;
     return true;
 }
 
@@ -708,9 +754,9 @@ extern "C" {
 
 const char* pafuse_version(void) {
 #ifdef PAFUSE_NO_PACKED_F32
-    return "pafuse_hip 0.3 (gfx950, f32 MFMA + split-bf16x3 MFMA, no packed-fp32 VALU)";
+    return "pafuse_hip 0.4 (gfx950, f32 MFMA + split bf16x3 / f16x2 MFMA, no packed-fp32 VALU)";
 #else
-    return "pafuse_hip 0.3 (gfx950, f32 MFMA + split-bf16x3 MFMA, packed-fp32 VALU: bf16 modes on one stream)";
+    return "pafuse_hip 0.4 (gfx950, f32 MFMA + split bf16x3 / f16x2 MFMA, packed-fp32 VALU: 16-bit MFMA modes on one stream)";
 #endif
 }
 const char* pafuse_last_error(void) { return g_err; }
@@ -749,7 +795,7 @@ int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights* w) {
         const pafuse_block_weights* pair[2] = {&w->ste[i], &w->tte[i]};
         const int len[2] = {w->joints, w->frames};
         for (int k = 0; k < 2; ++k)   // the condition of make_block, plus the tile-capacity check it makes
-            if (w->operand_bf16 == 2 && pair[k]->qkv_hs && pair[k]->qkv_hb && fqa_has(len[k], d) && (!fold || pair[k]->qkv_hl)) {
+            if (w->operand_bf16 >= 2 && pair[k]->qkv_hs && pair[k]->qkv_hb && fqa_has(len[k], d) && (!fold || pair[k]->qkv_hl)) {
                 const int lp = fqa_lp(len[k]), rows = 128 + (lp == 48 ? 4 : 0);
                 n += (((rows - lp) / len[k] + 1) * len[k] <= 128) ? 1 : 0;
             }
@@ -761,9 +807,26 @@ int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t layout, v
     StreamDevice on_stream_device(stream);
     if (!W || !out) return fail(PAFUSE_E_ARG, "split_weights: null pointer");
     if (N <= 0 || K <= 0 || K % BK) return fail(PAFUSE_E_SHAPE, "split_weights: N=%d, K=%d (K must be a positive multiple of 32)", N, K);
-    if (layout < 0 || layout > 2) return fail(PAFUSE_E_ARG, "split_weights: layout %d (0 plain, 1 whole-row, 2 qkv)", layout);
+    const bool f16 = (layout & PAFUSE_SPLIT_F16X2) != 0;
+    layout &= ~PAFUSE_SPLIT_F16X2;
+    if (layout < 0 || layout > 2) return fail(PAFUSE_E_ARG, "split_weights: layout %d (0 plain, 1 whole-row, 2 qkv; + PAFUSE_SPLIT_F16X2)", layout);
     const int64_t n = (int64_t)N * (K / 8);
     const dim3 grid((unsigned)((n + 255) / 256));
+    if (f16) {   // the f16x2 image: the tensor's largest |W| first (into the tail's scratch word), then the scaled slices
+        hipStream_t st = (hipStream_t)stream;
+        uint8_t* const tail = (uint8_t*)out + (size_t)N * K * 6;
+        if (hipMemsetAsync(tail, 0, WSPLIT_TAIL_BYTES, st) != hipSuccess) return fail(PAFUSE_E_HIP, "split_weights: memset failed");
+        const int64_t elems = (int64_t)N * K;
+        hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((elems + 255) / 256, 1024)), dim3(256), 0, st, W, elems,
+                           reinterpret_cast<uint32_t*>(tail) + 1);
+        if (layout == 2)
+            hipLaunchKernelGGL((split_weights_f16_kernel<32, 1>), grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
+        else if (wsplit_chunk(N, layout == 1) == 16)
+            hipLaunchKernelGGL(split_weights_f16_kernel<16>, grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
+        else
+            hipLaunchKernelGGL(split_weights_f16_kernel<32>, grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
+        return check_launch("split_weights_f16_kernel");
+    }
 #ifdef PAFUSE_QKV_32X32
     if (layout == 2) layout = 0;
 #endif
@@ -782,7 +845,7 @@ int pafuse_linear_split(const float* A, const void* Wsplit, const float* bias, f
     if (!A || !Wsplit || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear_split: null pointer or negative M");
     GemmParams g{};
     g.A = A, g.Wsplit = (const uint8_t*)Wsplit, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1;
-    g.bf16 = 2, g.wlayout = (act & 2) ? 2 : 0;
+    g.bf16 = (act & PAFUSE_LINEAR_F16X2_IMAGE) ? 3 : 2, g.wlayout = (act & PAFUSE_LINEAR_QKV_IMAGE) ? 2 : 0;
     return gemm_bias(g, (hipStream_t)stream);
 }
 
@@ -815,8 +878,8 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
                          int32_t operand_bf16, void* workspace, size_t workspace_bytes, void* stream) {
     StreamDevice on_stream_device(stream);
     if (!w || !x || !workspace || S < 0) return fail(PAFUSE_E_ARG, "block_forward: bad argument");
-    if (operand_bf16 < 0 || operand_bf16 > 2) return fail(PAFUSE_E_ARG, "block_forward: matrix-product mode %d", operand_bf16);
-    if (operand_bf16 == 2 && (!w->qkv_ws || !w->proj_ws || !w->fc1_ws || !w->fc2_ws))
+    if (operand_bf16 < 0 || operand_bf16 > 3) return fail(PAFUSE_E_ARG, "block_forward: matrix-product mode %d", operand_bf16);
+    if (operand_bf16 >= 2 && (!w->qkv_ws || !w->proj_ws || !w->fc1_ws || !w->fc2_ws))
         return fail(PAFUSE_E_ARG, "block_forward: split-precision mode needs the pre-split image of every linear weight");
     if (!width_supported(C)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", C);
     if (heads <= 0 || C % heads) return fail(PAFUSE_E_SHAPE, "block_forward: heads %d must divide C %d", heads, C);

@@ -127,7 +127,7 @@ class D3DP(nn.Module):
         for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS["bf16x3"]
 
-    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
 
     def denoisers(self):
         """{name: MixSTE2} in the order of the library's part table: the per-part models, or {'all': the single model}."""
@@ -139,6 +139,8 @@ class D3DP(nn.Module):
         'f32'    fp32-input matrix cores, a k-ordered fp32 FMA chain per output;
         'bf16x3' split precision (inference): fp32 operands as three bf16 slices, six bf16 MFMA products, fp32
                  accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h);
+        'f16x2'  split precision (inference): activations as two fp16 slices, weights as three (power-of-two scaled), THREE
+                 fp16 MFMA products, fp32 accumulation - fp32-equivalent results at 5.3x the matrix rate;
         'bf16'   opt-in reduced precision: operands rounded to one bf16 (BASELINE configs[1])."""
         modes = {int(m.operand_bf16) for m in self.denoisers().values()}
         if len(modes) != 1:
@@ -149,8 +151,8 @@ class D3DP(nn.Module):
     def precision(self, value):
         if value not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
-        if self.is_train and value == "bf16":
-            raise ValueError("training runs fp32 ('f32') or split-precision ('bf16x3') products, not rounded bf16")
+        if self.is_train and value in ("bf16", "f16x2"):
+            raise ValueError("training runs fp32 ('f32') or split-precision ('bf16x3') products")
         for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS[value]
         self._graphs.clear()

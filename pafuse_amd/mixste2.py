@@ -105,7 +105,8 @@ class MixSTE2(nn.Module):
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
         self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA,
-        #                                2 split precision "bf16x3" (fp32-equivalent, inference), 1 opt-in bf16 operands
+        #                                2 split precision "bf16x3", 3 split precision "f16x2" (both fp32-equivalent; 3 is
+        #                                inference only), 1 opt-in bf16 operands
         self.fold_layernorm = True     # split-precision inference: norm1 / norm2 applied inside the qkv / fc1 GEMMs
         #                                (pafuse_block_weights.qkv_ls ...: g-scaled weight images + two vectors per layer);
         #                                False = the whole-row kernels write the normalised rows (same function, one more
@@ -141,25 +142,31 @@ class MixSTE2(nn.Module):
             w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
             self._wcache_by_device[("train", self._freqs.device.index)] = (key, w)
             return w
-        fold = mode == 2 and bool(self.fold_layernorm)
-        if mode == 2:       # the split images are values, not views: an in-place update of a weight must remake them
+        split = mode in (2, 3)
+        fold = split and bool(self.fold_layernorm)
+        if split:           # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
-        fuse = mode == 2 and bool(self.fuse_qkv_attention)
+        fuse = split and bool(self.fuse_qkv_attention)
         if fold or fuse:    # ... and so are the folded / head-major images and vectors: they also hold LayerNorm and bias values
             key += ("fold", fold, fuse) + tuple(get(n)._version for n in self._param_names if n.endswith(FOLD_SUFFIXES))
         dev = self._freqs.device
         # per device, in a dict the replicas of nn.DataParallel share with their parent (replicate() copies attributes
         # shallowly and makes fresh module objects on every forward: a per-object cache would never hit there, and every
         # replica would re-split all its weights on every call)
-        hit = self._wcache_by_device.get(dev.index)
+        # A replica made by nn.DataParallel never reads the cache: its parameters are fresh broadcast copies on every forward
+        # (version 0, and the caching allocator hands out the same addresses again), so pointer + version cannot tell the
+        # copies of two different parent states apart - the images (value copies) are remade per forward there, and kept
+        # alive on the replica object itself.
+        replica = bool(getattr(self, "_is_replica", False))
+        hit = None if replica else self._wcache_by_device.get(dev.index)
         if hit is not None and hit[0] == key:
-            if mode == 2 and hit[3] is not None and torch.cuda.current_stream(dev) != hit[4]:
+            if split and hit[3] is not None and torch.cuda.current_stream(dev) != hit[4]:
                 torch.cuda.current_stream(dev).wait_event(hit[3])     # images were made on another stream
             return hit[1]
         w = _lib.MixSTE2Weights()
         images, event, stream = None, None, None
-        if mode == 2:
-            images = self._split_images(get, fold, fuse)
+        if split:
+            images = self._split_images(get, fold, fuse, f16=(mode == 3))
             stream = torch.cuda.current_stream(dev)
             event = torch.cuda.Event()
             event.record(stream)
@@ -168,12 +175,15 @@ class MixSTE2(nn.Module):
                             self.block_depth, self.num_heads, self.in_chans, mode, images)
         w.mlp_hidden = self.mlp_hidden
         w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
-        self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
+        if replica:
+            self._replica_keep = (w, images, event)      # alive as long as the replica (one forward)
+        else:
+            self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
         return w
 
-    def _split_images(self, get, fold=False, fuse=False):
-        """Pre-split (bf16x3) images of every linear weight, made on the device by pafuse_split_weights: one uint8
-        tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct).
+    def _split_images(self, get, fold=False, fuse=False, f16=False):
+        """Pre-split images (bf16x3, or f16x2 with `f16`) of every linear weight, made on the device by pafuse_split_weights:
+        one uint8 tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct).
         `fold`: qkv / fc1 get the image of W (.) g and the two vectors of the folded LayerNorm (norm1 / norm2 of their
         block, include/pafuse_hip.h pafuse_block_weights.qkv_ls): ls = W g, lt = W beta + b, formed in fp64."""
         images = {}
@@ -182,11 +192,11 @@ class MixSTE2(nn.Module):
                 continue
             stem = name[:-len("weight")]
             if fold and name.endswith(tuple(FOLDED_LINEAR)):
-                images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name)
+                images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name, f16)
             else:
-                images[name] = split_image(get(name), image_layout(name))
+                images[name] = split_image(get(name), image_layout(name), f16)
             if fuse and name.endswith("attn.qkv.weight"):
-                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = head_major_qkv(get, name, self.num_heads, fold)
+                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = head_major_qkv(get, name, self.num_heads, fold, f16)
         return images
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -201,9 +211,9 @@ class MixSTE2(nn.Module):
                     or self.attn_drop_rate):
                 raise NotImplementedError("training implements the PAFUSE configuration: qkv_bias=True, qk_scale=None, "
                                           "mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
-            if self.operand_bf16 == 1:
-                raise NotImplementedError("rounded-bf16 products are an inference option; training runs fp32 ('f32') or "
-                                          "split-precision ('bf16x3') products")
+            if self.operand_bf16 in (1, 3):
+                raise NotImplementedError("rounded-bf16 and f16x2 products are inference options; training runs fp32 ('f32') "
+                                          "or split-precision ('bf16x3') products")
             return self._forward_train(x_2d, x_3d, t)
         B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()
@@ -374,19 +384,24 @@ def image_layout(name):
     return LAYOUT_OF[name.split(".", 2)[2] if name.count(".") >= 3 else name]
 
 
-def split_image(weight, layout):
-    """The pre-split (bf16x3) image of one linear weight [N,K] on its device (pafuse_split_weights): a uint8 tensor of
-    6 bytes per element; `layout`: 0 mlp.fc1 / the unit op, 1 the whole-row layers (attn.proj, mlp.fc2), 2 attn.qkv."""
+SPLIT_F16X2 = 4      # include/pafuse_hip.h PAFUSE_SPLIT_F16X2: added to the layout, the image is for the f16x2 scheme
+
+
+def split_image(weight, layout, f16=False):
+    """The pre-split image of one linear weight [N,K] on its device (pafuse_split_weights): a uint8 tensor of 6 bytes per
+    element + a 256-byte tail; `layout`: 0 mlp.fc1 / the unit op, 1 the whole-row layers (attn.proj, mlp.fc2), 2 attn.qkv;
+    `f16`: the f16x2 scheme's image (three fp16 slices of the power-of-two-scaled weight) instead of bf16x3's."""
     lib = _lib.load()
     N, K = weight.shape
     img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(layout), img.data_ptr(),
+        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(layout) | (SPLIT_F16X2 if f16 else 0),
+                                            img.data_ptr(),
                                             torch.cuda.current_stream(weight.device).cuda_stream))
     return img
 
 
-def folded_linear(get, name):
+def folded_linear(get, name, f16=False):
     """(image, ls, lt) of the linear layer `name` (a state-dict key ending in attn.qkv.weight / mlp.fc1.weight) with the
     LayerNorm in front of it folded in (include/pafuse_hip.h, pafuse_block_weights.qkv_ls): the split image of W (.) g
     (one fp32 rounding per element, then split exactly), ls = W g and lt = W beta + b formed in fp64, rounded once."""
@@ -397,10 +412,10 @@ def folded_linear(get, name):
     w64 = weight.double()
     ls = (w64 @ g.double()).float().contiguous()
     lt = (w64 @ beta.double() + bias.double()).float().contiguous()
-    return split_image((weight * g[None, :]).contiguous(), image_layout(name)), ls, lt
+    return split_image((weight * g[None, :]).contiguous(), image_layout(name), f16), ls, lt
 
 
-def head_major_qkv(get, name, heads, fold):
+def head_major_qkv(get, name, heads, fold, f16=False):
     """(image, hb, hl) for the fused qkv + attention kernel (include/pafuse_hip.h pafuse_block_weights.qkv_hs): the qkv weight
     [3C, C] re-ordered head by head - q_h, k_h, v_h, each zero-padded from d to DP rows (DP = 32 for d <= 32, else 48) - as
     a layout-2 image; hb = the bias in that order; with the LayerNorm folded the image is that of W (.) g, hb = W beta + b
@@ -425,7 +440,7 @@ def head_major_qkv(get, name, heads, fold):
         out = t.new_zeros((heads, 3, dp) + tuple(t.shape[3:]))
         out[:, :, :d] = t.transpose(0, 1)
         return out.reshape(heads * 3 * dp, *t.shape[3:]).contiguous()
-    image = split_image(reorder(weight), 2)
+    image = split_image(reorder(weight), 2, f16)
     return image, reorder(bias), (reorder(hl) if hl is not None else None)
 
 

@@ -64,7 +64,7 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
     return o
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
 
 
 def block_forward(block_params, x, heads=8, precision="f32"):
@@ -78,10 +78,10 @@ def block_forward(block_params, x, heads=8, precision="f32"):
     w = _lib.BlockWeights()
     fill_block_struct(w, block_params)
     images = []
-    if precision == "bf16x3":
+    if precision in ("bf16x3", "f16x2"):
         for field, lin, layout in (("qkv_ws", block_params.attn.qkv, 2), ("proj_ws", block_params.attn.proj, 1),
                                    ("fc1_ws", block_params.mlp.fc1, 0), ("fc2_ws", block_params.mlp.fc2, 1)):
-            images.append(split_image(lin.weight, layout))
+            images.append(split_image(lin.weight, layout, precision == "f16x2"))
             setattr(w, field, images[-1].data_ptr())
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -181,33 +181,38 @@ def ddim_finalize(preds, joint_part, joint_local, img, step_scalars, noise=None,
     return out, img
 
 
-def split_weights(weight, layout=0):
-    """Pre-split (bf16x3) image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights);
-    layout 0: the 32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers."""
+def split_weights(weight, layout=0, scheme="bf16x3"):
+    """Pre-split image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights);
+    layout 0: the 32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers;
+    scheme 'bf16x3' (three bf16 slices) or 'f16x2' (three fp16 slices of the power-of-two-scaled weight)."""
     lib = _lib.load()
     _need(weight.dim() == 2 and weight.shape[1] % 32 == 0, "split_weights: weight must be [N, K] with K % 32 == 0")
     _need(layout in (0, 2), "split_weights: layout 0 (fc1 kernel) or 2 (qkv kernel)")
+    _need(scheme in ("bf16x3", "f16x2"), "split_weights: scheme 'bf16x3' or 'f16x2'")
     N, K = weight.shape
     img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, layout, img.data_ptr(), _stream(weight)))
+        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, layout | (4 if scheme == "f16x2" else 0), img.data_ptr(),
+                                            _stream(weight)))
     return img
 
 
-def linear_split(x, weight, bias, act=None, image=None, layout=0):
-    """nn.Linear (+ exact GELU) with split-precision (bf16x3) products: fp32 operands as three bf16 slices each, six
-    bf16 MFMA products per pair, fp32 accumulation.  ``image`` = split_weights(weight, layout) to reuse a cached image;
+def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3"):
+    """nn.Linear (+ exact GELU) with split-precision products, fp32 accumulation: scheme 'bf16x3' - fp32 operands as three
+    bf16 slices each, six bf16 MFMA products per pair; 'f16x2' - two fp16 slices of the activation, three of the scaled
+    weight, three fp16 MFMA products.  ``image`` = split_weights(weight, layout, scheme) to reuse a cached image;
     ``layout`` picks the kernel: 0 the 32x32x16-MFMA tiles (mlp.fc1), 2 the 16x16x32-MFMA tiles (attn.qkv)."""
     lib = _lib.load()
     K = x.shape[-1]
     N = weight.shape[0]
     _need(tuple(weight.shape) == (N, K) and bias.numel() == N, f"linear: x [..,{K}] needs weight [N,{K}] and bias [N]")
-    img = split_weights(weight, layout) if image is None else image
+    img = split_weights(weight, layout, scheme) if image is None else image
     _need(img.numel() == lib.pafuse_split_weights_bytes(N, K), "linear_split: image size does not match the weight")
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
     with torch.cuda.device(x.device):
         _lib.check(lib.pafuse_linear_split(_ptr(x2, "x"), img.data_ptr(), _ptr(bias, "bias"), out.data_ptr(),
-                                           x2.shape[0], N, K, (1 if act == "gelu" else 0) + (2 if layout == 2 else 0),
+                                           x2.shape[0], N, K,
+                                           (1 if act == "gelu" else 0) + (2 if layout == 2 else 0) + (4 if scheme == "f16x2" else 0),
                                            _stream(x)))
     return out.view(*x.shape[:-1], N)

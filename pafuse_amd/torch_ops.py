@@ -10,8 +10,8 @@ there is no fallback), with fake-tensor shape functions so the ops trace under `
   pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads, precision)  MixSTE2.forward, eval  common/mixste.py:278-298
   pafuse::ddim_loop(..., precision)                        D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
 
-``precision`` ('bf16x3' default = the modules' inference default, 'f32', 'bf16') is the matrix-product mode of the linear
-layers; in 'bf16x3' the ops build and cache the pre-split weight images themselves (cached_split_image).
+``precision`` ('bf16x3' default, 'f16x2', 'f32', 'bf16') is the matrix-product mode of the linear
+layers; in the split modes the ops build and cache the pre-split weight images themselves (cached_split_image).
 
 ``weights`` lists are in ``named_parameters()`` order of the corresponding module (= the reference's state-dict
 order), so ``list(model.parameters())`` is the argument.  The modules in pafuse_amd call the C ABI directly; these ops
@@ -68,36 +68,40 @@ def _freqs(channels, device):
     return _freq_cache[key]
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2}
-_image_cache = {}        # (data_ptr, _version, device, whole_row) of a linear weight -> its split image (bf16x3 mode)
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
+_image_cache = {}        # (data_ptr, _version, device, layout, shape, scheme) of a linear weight -> (its split image, the weight)
 _IMAGE_CACHE_MAX = 2048  # ~ three models' worth of linear weights; the oldest entries go first
 
 
-def cached_split_image(weight, layout):
-    """The pre-split image of a linear weight, made once per (storage, version, layout): the schema'd ops take plain
+def cached_split_image(weight, layout, f16=False):
+    """The pre-split image of a linear weight, made once per (storage, version, layout, scheme): the schema'd ops take plain
     parameter tensors, so they build and cache the images the split-precision kernels read (the modules keep theirs per
-    module).  layout: pafuse_split_weights' (0 fc1, 1 proj / fc2, 2 qkv)."""
-    key = (weight.data_ptr(), weight._version, weight.device, int(layout), tuple(weight.shape))
-    img = _image_cache.get(key)
-    if img is None:
-        while len(_image_cache) >= _IMAGE_CACHE_MAX:
-            _image_cache.pop(next(iter(_image_cache)))
-        img = _image_cache[key] = split_image(weight, layout)
-    return img
-
-
-def cached_folded_linear(table, name):
-    """(image, ls, lt) of a qkv / fc1 layer with its LayerNorm folded in (mixste2.folded_linear), made once per version of
-    the four tensors it is built from - the modules' own default in bf16x3 mode, so the ops return the modules' bits."""
-    block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
-    parts = (table[name], table[f"{block}.{norm}.weight"], table[f"{block}.{norm}.bias"], table[name[:-len("weight")] + "bias"])
-    key = ("fold",) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
+    module).  layout: pafuse_split_weights' (0 fc1, 1 proj / fc2, 2 qkv).
+    An entry keeps a reference to the tensor it was made from: while the entry lives that storage cannot be freed, so no
+    other tensor can come to sit at its address with a matching version and shape and hit a stale image (a freed temporary
+    such as `w.float()` or `w.detach().clone()` made per call would otherwise do exactly that)."""
+    key = (weight.data_ptr(), weight._version, weight.device, int(layout), tuple(weight.shape), bool(f16))
     hit = _image_cache.get(key)
     if hit is None:
         while len(_image_cache) >= _IMAGE_CACHE_MAX:
             _image_cache.pop(next(iter(_image_cache)))
-        hit = _image_cache[key] = folded_linear(table.__getitem__, name)
-    return hit
+        hit = _image_cache[key] = (split_image(weight, layout, f16), weight)
+    return hit[0]
+
+
+def cached_folded_linear(table, name, f16=False):
+    """(image, ls, lt) of a qkv / fc1 layer with its LayerNorm folded in (mixste2.folded_linear), made once per version of
+    the four tensors it is built from - the modules' own default in the split modes, so the ops return the modules' bits.
+    The entry pins its four source tensors (see cached_split_image)."""
+    block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
+    parts = (table[name], table[f"{block}.{norm}.weight"], table[f"{block}.{norm}.bias"], table[name[:-len("weight")] + "bias"])
+    key = ("fold", bool(f16)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
+    hit = _image_cache.get(key)
+    if hit is None:
+        while len(_image_cache) >= _IMAGE_CACHE_MAX:
+            _image_cache.pop(next(iter(_image_cache)))
+        hit = _image_cache[key] = (folded_linear(table.__getitem__, name, f16), parts)
+    return hit[0]
 
 
 def _mode(precision):
@@ -120,14 +124,13 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
     fr = _freqs(channels, weights[0].device)
     w = _lib.MixSTE2Weights()
     images = None
-    if mode == 2:
+    if mode in (2, 3):
         images = {}
         for n, t in table.items():
             if n.endswith(tuple(FOLDED_LINEAR)):
-                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n)
-
+                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, mode == 3)
             elif n.endswith(SPLIT_SUFFIXES):
-                images[n] = cached_split_image(t, image_layout(n))
+                images[n] = cached_split_image(t, image_layout(n), mode == 3)
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
     return w, (table, fr, images)
 
@@ -210,9 +213,9 @@ def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int, precision: s
     for field, t, name in zip(_lib.BLOCK_FIELDS, weights, BLOCK_KEYS):
         setattr(w, field, _ptr(t, name))
     images = []
-    if mode == 2:
+    if mode in (2, 3):
         for field, idx, layout in (("qkv_ws", 2, 2), ("proj_ws", 4, 1), ("fc1_ws", 8, 0), ("fc2_ws", 10, 1)):
-            images.append(cached_split_image(weights[idx], layout))
+            images.append(cached_split_image(weights[idx], layout, mode == 3))
             setattr(w, field, images[-1].data_ptr())
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)

@@ -127,13 +127,17 @@ def test_linear_exact_integers():
                                    (129, 448, 224), (64, 768, 256), (1, 512, 256), (50, 96, 64), (33, 32, 32)])
 @pytest.mark.parametrize("act", [None, "gelu"])
 @pytest.mark.parametrize("layout", [0, 2])
-def test_linear_split(M, N, K, act, layout):
-    """split-precision (bf16x3) products against fp64: the same bound as the fp32 FMA chain of test_linear (the six
-    kept terms carry every operand bit above 2^-24 relative; accumulation is fp32, one rounding per 16-deep MFMA).
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+def test_linear_split(M, N, K, act, layout, scheme):
+    """split-precision products against fp64: the same bound as the fp32 FMA chain of test_linear, and closer to exact
+    arithmetic than that chain on average.  bf16x3: the six kept terms carry every operand bit above 2^-24 relative,
+    one rounding per 16-deep MFMA.  f16x2 (round 4): two fp16 slices of the activation, three of the power-of-two-scaled
+    weight, three products; operands carry 22-23 bits, one rounding per MFMA.
     layout 0: the 32x32x16-MFMA tiles (mlp.fc1); layout 2: the 16x16x32-MFMA tiles of the qkv layers."""
     from pafuse_amd import ops
     from functools import partial
-    ops = type("ops", (), {"linear": staticmethod(ops.linear), "linear_split": staticmethod(partial(ops.linear_split, layout=layout))})
+    ops = type("ops", (), {"linear": staticmethod(ops.linear),
+                           "linear_split": staticmethod(partial(ops.linear_split, layout=layout, scheme=scheme))})
     x, w, b = _seeded((M, K), 1), _seeded((N, K), 2, K ** -0.5), _seeded((N,), 3, 0.1)
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     if act:
@@ -173,6 +177,52 @@ def test_linear_split_exact_integers_and_slices(layout, M, N, K):
     x[torch.arange(M), km] = 0.5
     out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV)).cpu()
     assert torch.equal(out, (w[:, km] * 0.5).t())
+
+
+@pytest.mark.parametrize("layout,M,N,K", [(0, 96, 224, 64), (2, 96, 224, 64), (2, 200, 1152, 384), (2, 131, 672, 224),
+                                          (2, 70, 768, 256), (2, 300, 96, 64), (0, 200, 768, 384)])
+def test_linear_f16x2_exact_integers_and_slices(layout, M, N, K):
+    """the f16x2 scheme on exact data: small integers (row / col / k-permutation and sub-block rotation slips show exactly);
+    22-bit operands that need both activation slices (hi and the 2^11-scaled lo) resp. both weight slices; activations so
+    small that hi is an fp16 SUBNORMAL (the matrix cores must not flush them); weights spanning 2^-20 .. 1 inside one tensor
+    (one power-of-two scale per tensor: the small ones live in fp16 subnormals of w1 / w2 and still come out exact)."""
+    from pafuse_amd import ops
+    from functools import partial
+    lin = partial(ops.linear_split, layout=layout, scheme="f16x2")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
+    b = torch.arange(N).float()
+    assert torch.equal(lin(x.to(DEV), w.to(DEV), b.to(DEV)).cpu(), x @ w.t() + b)
+    zero = torch.zeros(N, device=DEV)
+    sign = torch.randint(0, 2, (M, K), generator=g) * 2 - 1
+    x = torch.randint(2 ** 21, 2 ** 22, (M, K), generator=g).float() * sign * 2.0 ** -8          # 22 bits, |x| < 65504
+    kn = torch.randint(0, K, (N,), generator=g)
+    w = torch.zeros(N, K)
+    w[torch.arange(N), kn] = 2.0 ** torch.randint(-3, 4, (N,), generator=g).float()
+    assert torch.equal(lin(x.to(DEV), w.to(DEV), zero).cpu(), x[:, kn] * w[torch.arange(N), kn])
+    w = torch.randint(2 ** 21, 2 ** 22, (N, K), generator=g).float()                             # 22-bit weights
+    x = torch.zeros(M, K)
+    km = torch.randint(0, K, (M,), generator=g)
+    x[torch.arange(M), km] = 0.5
+    assert torch.equal(lin(x.to(DEV), w.to(DEV), zero).cpu(), (w[:, km] * 0.5).t())
+    x = torch.randint(1, 2 ** 10, (M, K), generator=g).float() * 2.0 ** -26                      # hi is an fp16 subnormal
+    w = torch.zeros(N, K)
+    w[torch.arange(N), kn] = 1.0
+    assert torch.equal(lin(x.to(DEV), w.to(DEV), zero).cpu(), x[:, kn])
+    w[torch.arange(N), kn] = 2.0 ** torch.randint(-20, 1, (N,), generator=g).float()             # one scale, 2^-20 .. 1
+    x = torch.randint(2 ** 21, 2 ** 22, (M, K), generator=g).float() * 2.0 ** -22
+    assert torch.equal(lin(x.to(DEV), w.to(DEV), zero).cpu(), x[:, kn] * w[torch.arange(N), kn])
+
+
+def test_linear_f16x2_overflow_is_loud():
+    """|activation| >= 65504 does not fit the fp16 hi slice: the affected outputs are inf / NaN, never a finite wrong number."""
+    from pafuse_amd import ops
+    x = torch.ones(64, 64)
+    x[3, 5] = 1e5
+    w, b = torch.eye(64), torch.zeros(64)
+    out = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), scheme="f16x2").cpu()
+    assert not torch.isfinite(out[3, 5]) and torch.isfinite(out[:3]).all() and torch.isfinite(out[4:]).all()
 
 
 @pytest.mark.parametrize("C,eps", [(384, 1e-6), (224, 1e-5), (256, 1e-6), (64, 1e-6)])
@@ -232,7 +282,7 @@ def test_g3_time_embed_golden():
         assert torch.allclose(out, z[f"{part}.out"], rtol=0, atol=5e-6), (part, (out - z[f"{part}.out"]).abs().max())
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_g4_blocks_golden(precision):
     """golden G4 (one real-width block per part, spatial and temporal, outputs of the reference) through pafuse_block_forward in
     both fp32-grade product modes.  (G3, the timestep MLP, has no product mode: time_embed_kernel is fp32 VALU arithmetic.)"""
@@ -272,7 +322,7 @@ def test_g5_part_denoisers_golden(g5):
         assert torch.allclose(out, ref, rtol=0, atol=1e-5), (part, (out - ref).abs().max())
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_g5_flip_loop_golden(g5, precision):
     """the reference's own output (golden G5: flip loop P=2, T=2), in both fp32-grade product modes"""
     z, model, sd = g5
