@@ -35,7 +35,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_DTYPE = "bf16x3"   # the fp32-equivalent split-precision path (pafuse_amd.D3DP's inference default)
+DEFAULT_DTYPE = "f16x2"    # the fp32-equivalent split-precision path (pafuse_amd.D3DP's inference default, round 4)
 GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md section 3 (one denoiser pass)
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 matrix peak (opt-in --dtype bf16 runs are priced against this)
@@ -56,8 +56,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
     ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
-    ap.add_argument("--fuse-qkv-attention", action="store_true",
-                    help="A/B: the opt-in fused qkv + attention kernel (pafuse_amd.MixSTE2.fuse_qkv_attention) where it exists")
+    ap.add_argument("--fuse-qkv-attention", choices=("auto", "on", "off"), default="auto",
+                    help="A/B: the fused qkv + attention kernel (pafuse_amd.MixSTE2.fuse_qkv_attention) where it exists; auto = "
+                         "the modules' default: on in f16x2, off in bf16x3")
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
@@ -123,7 +124,7 @@ def main():
     for m in model.denoisers().values():
         if args.no_ln_fold:
             m.fold_layernorm = False
-        m.fuse_qkv_attention = bool(args.fuse_qkv_attention)
+        m.fuse_qkv_attention = {"auto": None, "on": True, "off": False}[args.fuse_qkv_attention]
     sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)
     x2d, x2f = x2d.to(dev), x2f.to(dev)
@@ -209,7 +210,8 @@ def main():
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
         "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype in SPLIT_DTYPES and not args.no_ln_fold),
-        "qkv_attention_fused": bool(args.dtype in SPLIT_DTYPES and args.fuse_qkv_attention),
+        "qkv_attention_fused_blocks": {name: _lib.check(_lib.load().pafuse_mixste2_fused_blocks(C.byref(m.weights_struct())))
+                                       for name, m in model.denoisers().items()} if args.dtype in SPLIT_DTYPES else None,
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
         "allgather_ms": gather_ms, "allgather_ms_note": "collective + the one layout pass, max over ranks", "gather_copy_ms": copy_ms,
         "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
@@ -227,9 +229,9 @@ def main():
         stream = torch.cuda.current_stream(dev)
         reps = 3
         # the replay launches what the timed loop launched: part by part when the loop ran on side streams, the shared
-        # grids of the single-stream schedule otherwise (pafuse_set_grouped_launches: the library's process-wide option)
-        per_part = lanes > 1 or args.dtype not in SPLIT_DTYPES
-        was_grouped = lib.pafuse_set_grouped_launches(0 if per_part else 1)
+        # grids of the single-stream bf16x3 schedule otherwise (pafuse_d3dp_config.part_by_part_launches, per call)
+        per_part = lanes > 1 or args.dtype != "bf16x3"
+        cfg.part_by_part_launches = int(per_part)
         flops = C.c_double(0.0)
         launches = _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
                                                            stream.cuda_stream, C.byref(flops)))       # warm-up
@@ -247,7 +249,10 @@ def main():
         achieved = flops.value / (ms * 1e-3) / 1e12
         # the same for each layer kind alone (pafuse_d3dp_replay_layers): which kernels of the family are how far from peak
         by_layer = {}
-        layer_kernel = ({1: "gemm16_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
+        layer_kernel = ({1: "hfqa_kernel: qkv projection + attention in one kernel (the face's spatial blocks: hgemm_kernel, qkv only)",
+                         2: "hgemm_kernel<..EPI_ROWLN> (one launch per part)", 4: "hgemm_kernel<..EPI_BIAS> (one launch per part)",
+                         8: "hgemm_kernel<..EPI_ROWLN> (one launch per part)"} if args.dtype == "f16x2" else
+                        {1: "gemm16_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
                          8: "grouped_rowln_kernel"} if not per_part else
                         {1: "gemm16_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
                          4: "gemm_kernel (one launch per part)", 8: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)"}
@@ -269,7 +274,6 @@ def main():
             by_layer[name] = {"kernel": layer_kernel[bit], "launches": nl * reps, "avg_launch_us": round(t * 1e3 / (nl * reps), 2),
                               "achieved": round(fl.value / (t * 1e-3) / 1e12, 2),
                               "frac": round(fl.value / (t * 1e-3) / 1e12 / peak, 4)}
-        lib.pafuse_set_grouped_launches(was_grouped)
         # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
         # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
         traffic, traffic_info = None, {"traffic_source": None}
@@ -309,8 +313,9 @@ def main():
                               f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
         products = {"bf16x3": 6, "f16x2": 3}.get(args.dtype, 1)          # matrix instructions executed per useful product
-        family = (("gemm16_kernel, gemm_kernel, gemm_dma_kernel" if per_part else
-                   "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype in SPLIT_DTYPES else "gemm_kernel")
+        family = ("hgemm_kernel, hfqa_kernel (whose attention phase is inside the timed launches)" if args.dtype == "f16x2" else
+                  ("gemm16_kernel, gemm_kernel, gemm_dma_kernel" if per_part else
+                   "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype == "bf16x3" else "gemm_kernel")
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {family} ({mfma})",
                             "schedule": (f"timed loop: {lanes} streams, one body-part denoiser per stream; this object: the same "
                                          "launches replayed one after the other on one stream" if lanes > 1 else

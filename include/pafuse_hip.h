@@ -55,8 +55,8 @@ typedef struct pafuse_block_weights {
     const float *fc1_w, *fc1_b;     /* [H,C], [H]   (H = mlp hidden width, 2C by default) */
     const float *fc2_w, *fc2_b;     /* [C,H], [C] */
     /* split-precision modes only (pafuse_mixste2_weights.operand_bf16 == 2 or 3): the pre-split images of the four linear
-     * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv), 1 (proj, fc2), 0 (fc1)
-     * (a cache - remake after a weight changes); NULL otherwise */
+     * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv), 1 (proj, fc2), 0 (fc1) -
+     * mode 3: with PAFUSE_SPLIT_F16X2 - (a cache - remake after a weight changes); NULL otherwise */
     const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
     /* split-precision mode, optional: LayerNorm folded into the GEMM that consumes it (all four set, in every block of a
      * denoiser, or none).  With them set, qkv_ws / fc1_ws must be the images of W (.) g - the weight scaled along its
@@ -92,9 +92,9 @@ typedef struct pafuse_mixste2_weights {
                                 chain) at 2.7x the matrix rate.  Inference entry points need the *_ws weight images;
                                 the training entry points do not (they split the weight a GEMM is about to read
                                 themselves - weights change every step) and run every GEMM of the step this way.
-                             3: split precision "f16x2" (inference only): activations as two fp16 slices, weights as three
-                                (images made with PAFUSE_SPLIT_F16X2), three products per k on the fp16 matrix cores -
-                                fp32-equivalent results at 5.3x the fp32 matrix rate; needs the *_ws images.
+                             3: split precision "f16x2" (inference only): activations as two fp16 slices, weights as two
+                                stored + one derived (PAFUSE_SPLIT_F16X2 images in *_ws), three products per k on the fp16
+                                matrix cores - fp32-equivalent results at 5.3x the fp32 matrix rate.
                              1: opt-in reduced precision - operands rounded to ONE bf16 (RNE), fp32 accumulate
                                 (BASELINE configs[1]; inference only) */
     int32_t mlp_hidden;   /* MixSTE2(mlp_ratio=...): hidden width int(C * mlp_ratio) of every block's MLP, a multiple of 32,
@@ -127,6 +127,11 @@ typedef struct pafuse_d3dp_config {
     const int32_t *joint_part;         /* device [num_kps]: part id of every joint */
     const int32_t *joint_local;        /* device [num_kps]: index of the joint inside its part */
     const int32_t *flip_perm;          /* device [num_kps]: flipped[j] = orig[perm[j]] (diffusionpose.py:197-198) */
+    int32_t part_by_part_launches;     /* launch-schedule option of the single-stream bf16x3 schedule (no aux streams): 0 (default) runs
+                                          the same layer of the independent body-part denoisers in ONE grid (grouped_*_kernel), 1 launches
+                                          every layer part by part.  A tile's arithmetic does not depend on the grid it runs in, so both
+                                          give the same bits (tests/test_hip_fullsize.py); it exists for that test and for A/B timing.
+                                          Per call: the library keeps no process-wide schedule state and reads no environment variable. */
 } pafuse_d3dp_config;
 
 /* Per-step scalars of the loop, computed by the host exactly as the reference does in fp64
@@ -142,18 +147,12 @@ typedef struct pafuse_ddim_step {
 const char *pafuse_version(void);
 const char *pafuse_last_error(void);
 
-/* Process-wide launch-schedule option (default 1): in the split-precision mode the same layer of the independent body-part
- * denoisers runs in ONE grid (grouped_*_kernel); 0 launches every layer part by part.  A tile's arithmetic does not depend
- * on the grid it runs in, so both schedules give the same bits (tests/test_hip_fullsize.py); the switch exists for that
- * test and for A/B timing.  Returns the previous setting.  The library reads no environment variable. */
-int pafuse_set_grouped_launches(int32_t on);
-
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU; +2: bf16 operands (see operand_bf16).
  * K,N multiples of 32. */
 int pafuse_linear(const float *A, const float *W, const float *bias, float *out, int64_t M, int32_t N, int32_t K,
                   int32_t act, void *stream);
 
-/* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K + 256 bytes
+/* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K bytes
  * ([K/c][N][6c B] with c = 32 or 16: per row and K chunk, sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels'
  * LDS image).  `layout` names the layer the image is for - it decides c and the rotation of the sub-blocks inside a row:
  *   0  mlp.fc1 (and pafuse_linear_split without PAFUSE_LINEAR_QKV_IMAGE): the 32x32x16-MFMA plain kernel
@@ -163,20 +162,32 @@ int pafuse_linear(const float *A, const float *W, const float *bias, float *out,
  * has layout 2): the unit entry of the split-precision products, which replace the same nn.Linear call sites
  * (common/mixste.py:38-42,65,80). */
 #define PAFUSE_LINEAR_QKV_IMAGE 2
-/* Second split-precision scheme, "f16x2" (operand_bf16 == 3): `layout | PAFUSE_SPLIT_F16X2` makes the image of that layout
- * for it - the weight scaled by a power of two 2^k (the tensor's largest |W 2^k| in [2^14, 2^15)) as three fp16 slices
- * w0 = f16(Ws), w1 = f16(Ws - w0), w2 = f16(w0 2^-11) in the geometry of the bf16x3 image, 2^-k in the image's tail; the
- * kernels split an activation a into hi = f16(a), lo = f16((a - hi) 2^11) and keep hi w0 + hi w1 + lo w2 - THREE products
- * per k on the fp16 matrix cores, fp32 accumulate, the accumulator multiplied by 2^-k in the epilogue.  fp32-equivalent
- * (same bounds as bf16x3 against exact arithmetic, tests/test_hip_parity.py); activations must stay below 65504 in
- * magnitude (beyond it the row's outputs are inf / NaN, never silently wrong).  pafuse_linear_split on such an image: add
- * PAFUSE_LINEAR_F16X2_IMAGE to `act`.  Every image is pafuse_split_weights_bytes(N, K) = 6*N*K + 256 bytes (the tail). */
-#define PAFUSE_SPLIT_F16X2 4
-#define PAFUSE_LINEAR_F16X2_IMAGE 4
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K);
 int pafuse_split_weights(const float *W, int32_t N, int32_t K, int32_t layout, void *out, void *stream);
 int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, float *out, int64_t M, int32_t N,
                         int32_t K, int32_t act, void *stream);
+
+/* Second split-precision scheme, "f16x2" (operand_bf16 == 3, round 4): THREE fp16 MFMA products per fp32-equivalent product.
+ * Both GEMM operands are "H images": rows of 4 K bytes, per sub-block of 8 k the 16 bytes of the first fp16 slice, then the
+ * 16 of the second - [rows][K/8][hi 8 x f16 | lo 8 x f16]:
+ *   activation a   hi = f16(a), lo = f16((a - hi) * 2^11); written in this form by the kernel that PRODUCES the tensor
+ *                  (whole-row epilogues, attention, the fc1 epilogue, the embedding) - same bytes as fp32, split once;
+ *   weight W       pafuse_split_weights(W, N, K, PAFUSE_SPLIT_F16X2, out, stream): the image of Ws = 2^k W (the tensor's
+ *                  largest |Ws| in [2^14, 2^15)): w0 = f16(Ws), w1 = f16(Ws - w0); 4 N K bytes + a 256-byte tail whose
+ *                  first float is 2^-k (a buffer of pafuse_split_weights_bytes(N, K) bytes is large enough); every layer
+ *                  uses this one geometry, whatever the value of the layout bits.
+ * Kept per product: hi w0 + hi w1 + lo (w0 2^-11), fp32 accumulate, the accumulator times 2^-k in the epilogue; dropped
+ * terms and slice roundings ~ 2^-22 relative.  fp32-equivalent: the same bounds against exact arithmetic as bf16x3 hold
+ * (tests/test_hip_parity.py).  Activations must stay below 65504 in magnitude (beyond it hi is inf and the affected outputs
+ * are inf / NaN, never silently wrong).  Inference only; channel widths 224 / 256 / 384, plain-layer widths that are
+ * multiples of 128 or 224.
+ * pafuse_hsplit_rows: X [R,K] fp32 -> its activation H image (4 R K bytes).  pafuse_linear_h: nn.Linear on H images
+ * (act: 0 none, 1 GELU): fp32 `out` [M,N], or - when out_h is given - the H image of the output instead (either may be
+ * NULL, not both).  N a multiple of 128 or 224, K of 32.  Replaces the same nn.Linear call sites (common/mixste.py:38-42,65,80). */
+#define PAFUSE_SPLIT_F16X2 4
+int pafuse_hsplit_rows(const float *X, int64_t R, int32_t K, void *out, void *stream);
+int pafuse_linear_h(const void *Ah, const void *Wh, const float *bias, float *out, void *out_h, int64_t M, int32_t N, int32_t K,
+                    int32_t act, void *stream);
 
 /* out[M,C] = LayerNorm(x[M,C]) * w + b  (biased variance, eps inside the sqrt). */
 int pafuse_layernorm(const float *x, const float *w, const float *b, float *out, int64_t M, int32_t C, float eps,

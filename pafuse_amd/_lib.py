@@ -43,7 +43,8 @@ class D3DPConfig(C.Structure):
                 ("scale", C.c_double),
                 ("part", MixSTE2Weights * MAX_PARTS),
                 ("part_joints", C.c_void_p * MAX_PARTS),
-                ("joint_part", C.c_void_p), ("joint_local", C.c_void_p), ("flip_perm", C.c_void_p)]
+                ("joint_part", C.c_void_p), ("joint_local", C.c_void_p), ("flip_perm", C.c_void_p),
+                ("part_by_part_launches", C.c_int32)]
 
 
 class DDIMStep(C.Structure):
@@ -56,13 +57,15 @@ class DDIMStep(C.Structure):
 SIGNATURES = {
     "pafuse_version": (C.c_char_p, []),
     "pafuse_last_error": (C.c_char_p, []),
-    "pafuse_set_grouped_launches": (C.c_int, [C.c_int32]),
     "pafuse_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "pafuse_split_weights_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "pafuse_split_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pafuse_linear_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]),
+    "pafuse_hsplit_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pafuse_linear_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
     "pafuse_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "pafuse_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
@@ -102,7 +105,7 @@ SIGNATURES = {
 
 _lib = None
 
-KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
+KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/hgemm.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
                   "pafuse_amd/csrc/train_host.inc", "include/pafuse_hip.h")
 
 

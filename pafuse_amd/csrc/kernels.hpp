@@ -102,22 +102,22 @@ struct SplitPair {
     }
 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// ---- split precision, second scheme ("f16x2", round 4): fp16 has 11 significand bits, so two slices carry 22-23 bits of
-// an fp32 value and THREE matrix products replace bf16x3's six (ceiling 2500 / 3 = 833 TFLOP/s of fp32-equivalent work).
+// ---- split precision, second scheme ("f16x2", round 4; the kernels are in hgemm.hpp): fp16 has 11 significand bits, so two
+// slices carry 22-23 bits of an fp32 value and THREE matrix products replace bf16x3's six (ceiling 2500 / 3 = 833 TFLOP/s of
+// fp32-equivalent work).
 //   activation  a = hi + 2^-11 lo,   hi = f16(a),  lo = f16((a - hi) 2^11)      (the subtraction and the scaling are exact;
 //               the scaled lo stays a normal fp16 number for every |a| down to 2^-25, no per-tensor scale is needed;
 //               |a| must stay below 65504 - beyond it hi is inf and the output row shows it)
-//   weight      Ws = 2^k W with the tensor's largest |Ws| in [2^14, 2^15) (k chosen when the image is made), as three fp16
-//               slices  w0 = f16(Ws),  w1 = f16(Ws - w0)  (unscaled: at this magnitude it is normal or exactly representable
-//               far below anything that matters),  w2 = f16(w0 2^-11)
+//   weight      Ws = 2^k W with the tensor's largest |Ws| in [2^14, 2^15) (k chosen when the image is made), as fp16 slices
+//               w0 = f16(Ws),  w1 = f16(Ws - w0)  (unscaled: at this magnitude it is normal, or a subnormal whose rounding
+//               is 2^-39 of the tensor's largest weight),  and  w2 = f16(w0 2^-11), formed in registers
 //   product     a Ws ~ hi w0 + hi w1 + lo w2:  three MFMAs into ONE accumulator, nothing rescaled inside the K loop; the
 //               epilogue multiplies the accumulator by 2^-k (exact).  Dropped: lo (Ws - w0) 2^-11 ~ 2^-22 |a Ws|; the slices
 //               represent a to 2^-23 |a| and Ws likewise.  Each kept product is exact in the fp32 accumulator (22 bits).
 // Against exact arithmetic the scheme is as close as bf16x3 and closer than the fp32 FMA chain (one rounding per MFMA
-// instead of one per k; tools/f16x2_emulation.py, tests/test_hip_parity.py::test_linear_split).  The weight image keeps
-// bf16x3's geometry - three 16-byte slices per sub-block of 8 k - so every staging path, LDS layout and rotation of the
-// bf16x3 kernels serves both schemes; the image is followed by a 256-byte tail whose first float is 2^-k.
+// instead of one per k; tools/f16x2_emulation.py, tests/test_hip_parity.py::test_linear_split).
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 struct f16x8x2 {
@@ -134,30 +134,30 @@ __device__ __forceinline__ f16x8x2 split2h(const f32x4 lo4, const f32x4 hi4) {
     }
     return o;
 }
-// the same split of two values into packed pairs (low half = the first value), for the hand-placed pipelines
-struct SplitPairH {
-    float x0, x1;
-    uint32_t hi = 0, lo = 0;
-    __device__ __forceinline__ static uint32_t pack(float a, float b) {
-        const f16x2_t v = {(_Float16)a, (_Float16)b};  // one v_cvt_pk_f16_f32 (RNE)
-        return __builtin_bit_cast(uint32_t, v);
-    }
-    __device__ __forceinline__ void split() {
-        hi = pack(x0, x1);
-        const f16x2_t h = __builtin_bit_cast(f16x2_t, hi);
-        lo = pack((x0 - (float)h[0]) * 2048.0f, (x1 - (float)h[1]) * 2048.0f);
-    }
-};
+// "H image" of a matrix [rows][K]: rows of 4 K bytes, per sub-block of 8 k the 16 bytes of the first slice, then the 16 of the
+// second - [rows][K/8][hi 8 x f16 | lo 8 x f16] (weights: [w0 | w1]).  Producers that own four consecutive values of a row
+// store their halves of a sub-block: 8 bytes of hi, 8 bytes of lo.
+__device__ __forceinline__ void hsplit_store4(uint8_t* sub_block_base, int first /* 0 or 4: position inside the sub-block */,
+                                              const f32x4 v) {
+    f16x2_t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};   // v_cvt_pk_f16_f32 (RNE)
+    f16x2_t l0 = {(_Float16)((v[0] - (float)h0[0]) * 2048.0f), (_Float16)((v[1] - (float)h0[1]) * 2048.0f)};
+    f16x2_t l1 = {(_Float16)((v[2] - (float)h1[0]) * 2048.0f), (_Float16)((v[3] - (float)h1[1]) * 2048.0f)};
+    *reinterpret_cast<u32x2*>(sub_block_base + 2 * first) = u32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)};
+    *reinterpret_cast<u32x2*>(sub_block_base + 16 + 2 * first) = u32x2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)};
+}
+constexpr int HSPLIT_TAIL_BYTES = 256;   // behind a WEIGHT H image: [0] float 2^-k (what the epilogue multiplies by), [1] scratch
+__host__ __device__ inline size_t hsplit_bytes(int64_t R, int64_t K) { return (size_t)R * (size_t)K * 4 + HSPLIT_TAIL_BYTES; }
 __device__ __forceinline__ f32x16 mfma_f16_k16(const f16x8 a, const f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 mfma16_f16_k32(const f16x8 a, const f16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-constexpr int WSPLIT_TAIL_BYTES = 256;   // behind every image: [0] float 2^-k (f16x2 images; 1.0 for bf16x3), [1] scratch
-// 2^-k of the image at `img` (N x K weights): what an epilogue multiplies the accumulator by
-__device__ __forceinline__ float wsplit_acc_scale(const uint8_t* img, int N, int K) {
-    return *reinterpret_cast<const float*>(img + (size_t)N * (size_t)K * 6);
+// the largest |W| of a tensor as fp32 bits (monotonic for non-negative values) into *out (zeroed by the caller)
+__global__ void __launch_bounds__(256) absmax_kernel(const float* W, int64_t n, uint32_t* out) {
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = max(m, __builtin_bit_cast(uint32_t, W[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 // Pre-split weight image W' of a [N,K] fp32 matrix, in chunks of BKC = 32 or 16 along K:
@@ -172,7 +172,7 @@ __device__ __forceinline__ float wsplit_acc_scale(const uint8_t* img, int N, int
 // Third layout (M16 = 1, BKC = 32): the qkv layer runs on v_mfma_f32_16x16x32_bf16 (gemm16_tile), whose fragment read takes
 // 16 rows x 4 sub-blocks per wave instruction; that pattern is conflict-free with sub-block sb at (sb + (n >> 1)) & 3.
 constexpr int WSPLIT_ROW_BYTES = 192;  // BKC = 32
-__host__ __device__ inline size_t wsplit_bytes(int64_t N, int64_t K) { return (size_t)N * (size_t)K * 6 + 256; }  // + WSPLIT_TAIL_BYTES
+__host__ __device__ inline size_t wsplit_bytes(int64_t N, int64_t K) { return (size_t)N * (size_t)K * 6; }
 template <int BKC = 32, int M16 = 0>
 __device__ __forceinline__ int wsplit_sub_offset(int n, int sb) {
     static_assert(BKC == 32 || (BKC == 16 && !M16), "chunk depth");
@@ -194,49 +194,6 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint
     *reinterpret_cast<bf16x8*>(dst) = s.s0;
     *reinterpret_cast<bf16x8*>(dst + 16) = s.s1;
     *reinterpret_cast<bf16x8*>(dst + 32) = s.s2;
-    if (idx == 0) *reinterpret_cast<float*>(out + (size_t)N * K * 6) = 1.0f;   // the tail's accumulator scale
-}
-
-// f16x2 images.  Pass 1: the largest |W| of the tensor (as fp32 bits: monotonic for non-negative values) into the tail's
-// scratch word (zeroed by the caller).  Pass 2: the image of Ws = 2^k W in the geometry of split_weights_kernel<BKC, M16>,
-// k = 14 - floor(log2(max |W|)); thread 0 leaves 2^-k in the tail's first float.
-__global__ void __launch_bounds__(256) absmax_kernel(const float* W, int64_t n, uint32_t* out) {
-    uint32_t m = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        m = max(m, __builtin_bit_cast(uint32_t, W[i]) & 0x7fffffffu);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
-}
-
-template <int BKC, int M16 = 0>
-__global__ void __launch_bounds__(256) split_weights_f16_kernel(const float* W, uint8_t* out, int N, int K) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one (n, group of 8 k) per thread
-    const int groups = K / 8;
-    if (idx >= (int64_t)N * groups) return;
-    uint8_t* const tail = out + (size_t)N * K * 6;
-    const uint32_t mbits = reinterpret_cast<const uint32_t*>(tail)[1];
-    int e = (int)(mbits >> 23) - 127;            // floor(log2(max |W|)) for a normal maximum
-    e = e < -100 ? -100 : (e > 100 ? 100 : e);   // all-zero / denormal / non-finite tensors: any finite scale will do
-    const float mult = __builtin_bit_cast(float, (uint32_t)(127 + 14 - e) << 23);   // 2^k
-    if (idx == 0) *reinterpret_cast<float*>(tail) = __builtin_bit_cast(float, (uint32_t)(127 - 14 + e) << 23);   // 2^-k
-    constexpr int SUBS = BKC / 8, ROW = 6 * BKC;
-    const int n = (int)(idx / groups), g8 = (int)(idx % groups);
-    const int chunk = g8 / SUBS, sb = g8 % SUBS;
-    const float* src = W + (int64_t)n * K + g8 * 8;
-    f16x8 w0, w1, w2;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float x = src[i] * mult;   // exact (power of two; products stay far inside the fp32 range)
-        const _Float16 h = (_Float16)x;
-        w0[i] = h;
-        w1[i] = (_Float16)(x - (float)h);
-        w2[i] = (_Float16)((float)h * 0.00048828125f);   // 2^-11: exact unless it falls into the fp16 subnormals (then RNE)
-    }
-    uint8_t* dst = out + ((int64_t)chunk * N + n) * ROW + wsplit_sub_offset<BKC, M16>(n, sb);
-    *reinterpret_cast<f16x8*>(dst) = w0;
-    *reinterpret_cast<f16x8*>(dst + 16) = w1;
-    *reinterpret_cast<f16x8*>(dst + 32) = w2;
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -320,6 +277,12 @@ struct GemmParams {
     float* ln_stats;
     const float* ln_in;
     const float* ln_s;
+    // f16x2 "H" pipeline (hgemm.hpp): operands and outputs as H images (see hsplit_store4)
+    const uint8_t* Ah;   // A [M,K] split by its producer (hi = f16(a), lo = f16((a - hi) 2^11)); row stride 4 K bytes
+    const uint8_t* Wh;   // W [N,K] as the H image of 2^k W (w0 = f16(Ws), w1 = f16(Ws - w0)), 2^-k in the tail behind it
+    uint8_t* out_h;      // EPI_BIAS: the output as an H image [M,N] instead of fp32 `out` (its consumer is another hgemm)
+    uint8_t* out_xh;     // EPI_ROWLN: the H image of out_x, written beside it (A operand of the next qkv / fc1, LayerNorm folded)
+    uint8_t* out_nh;     // EPI_ROWLN: the H image of the next LayerNorm's output instead of fp32 out_n (LayerNorm not folded)
     const float* rowscale;  // [nseq] DropPath factor of the row's sequence, or null (= 1)
     int rs_temporal, rs_J, rs_FJ;  // seq(m) = rs_temporal ? (m / rs_FJ) * rs_J + m % rs_J : m / rs_J
     float* out_pre;
@@ -530,6 +493,9 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
                     *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
+                    // the same values as the H image the next qkv / fc1 reads: columns nb + 32 nt + 8 q .. + 3 are the half
+                    // 4 h of the sub-block that starts at column (nb - 4 h) + 32 nt + 8 q
+                    if (p.out_xh) hsplit_store4(p.out_xh + 4 * (mo + (nb - 4 * h) + 32 * nt + 8 * q), 4 * h, v);
                 }
         }
         if (p.next_w && p.ln_stats) {
@@ -556,6 +522,17 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
             }
         } else if (p.next_w) {
             layer_norm(p.next_w, p.next_b, p.next_eps, 2, 3);
+            if (p.out_nh && live) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
+                        hsplit_store4(p.out_nh + 4 * (mo + (nb - 4 * h) + 32 * nt + 8 * q), 4 * h, v);
+                    }
+            }
             if (p.out_n && live) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -612,7 +589,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
     using T = GemmTile<WM, WN, NT>;
     constexpr int NTHR = T::NTHR, BM = T::BM, BN = T::BN;
     constexpr int A_LD = (BM * 8 + NTHR - 1) / NTHR, W_LD = (BN * 8 + NTHR - 1) / NTHR;  // float4 per thread per chunk
-    constexpr bool SPLIT = BF16 >= 2, F16 = BF16 == 3;   // 2: bf16x3, 3: f16x2 (same image geometry, three products)
+    constexpr bool SPLIT = BF16 == 2;
     constexpr int W_ROW = SPLIT ? T::W_ROW_SPLIT : LDK;  // floats per W row of a stage
     float* As = smem;
     float* Ws = smem + NSTAGE * BM * LDK;
@@ -718,30 +695,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
         const float* Ac = As + cur * BM * LDK + a_frag;
         const float* Wc = Ws + cur * BN * W_ROW + w_frag;
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (F16) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const f16x8x2 a = split2h(*reinterpret_cast<const f32x4*>(Ac + 16 * s2),
-                                          *reinterpret_cast<const f32x4*>(Ac + 16 * s2 + 4));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float* wp = Wc + nt * 32 * W_ROW + ws_sub[s2];
-                    const f16x8 w0 = *reinterpret_cast<const f16x8*>(wp);
-                    const f16x8 w1 = *reinterpret_cast<const f16x8*>(wp + 4);
-                    const f16x8 w2 = *reinterpret_cast<const f16x8*>(wp + 8);
-                    // small terms first, the leading product last
-                    if constexpr (TR) {
-                        acc[nt] = mfma_f16_k16(w2, a.lo, acc[nt]);
-                        acc[nt] = mfma_f16_k16(w1, a.hi, acc[nt]);
-                        acc[nt] = mfma_f16_k16(w0, a.hi, acc[nt]);
-                    } else {
-                        acc[nt] = mfma_f16_k16(a.lo, w2, acc[nt]);
-                        acc[nt] = mfma_f16_k16(a.hi, w1, acc[nt]);
-                        acc[nt] = mfma_f16_k16(a.hi, w0, acc[nt]);
-                    }
-                }
-            }
-        } else if constexpr (SPLIT) {
+        if constexpr (SPLIT) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8x3 a = split3(*reinterpret_cast<const f32x4*>(Ac + 16 * s2),
@@ -808,10 +762,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
     }
 
     PAFUSE_STAMP(1);
-    float ws = 1.0f;   // accumulator scale of an f16x2 image (2^-k, exact)
-    if constexpr (F16) ws = wsplit_acc_scale(p.Wsplit, p.N, p.K);
     if constexpr (TR) {
-        epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem, ws);
+        epilogue_row_per_lane<WN, NT, BM, EPI>(acc, p, m0, n0, wm, wn, r, h, smem);
         return;
     }
     // accumulator element (nt, reg) of this lane is  row = (reg&3) + 8*(reg>>2) + 4*h,  col = 32*nt + r  of the strip
@@ -834,7 +786,6 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
             const float mean = p.ln_in[2 * mm];
             st_a = p.ln_in[2 * mm + 1];
             st_b = -mean * st_a;
-            st_a *= ws;   // (exact)
         }
 #pragma unroll
         for (int nt0 = 0; nt0 < NT; nt0 += NTH) {
@@ -859,7 +810,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
                         const float bv = p.bias[n0 + (wn * NT + nt0 + q) * 32 + r];
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
-                            float v = fmaf(acc[nt0 + q][reg], ws, bv);   // ws = 1: acc + bias, same bits
+                            float v = acc[nt0 + q][reg] + bv;
                             if (p.act) v = gelu_erf(v);
                             slab[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST + q * 32 + r] = v;
                         }
@@ -933,7 +884,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16_k32(const bf16x8 a, const bf16x8 b,
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int NB, int F16 = 0>   // F16 = 1: the f16x2 scheme (three products on v_mfma_f32_16x16x32_f16), same image geometry
+template <int NB>
 __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, const int nb, float* smem) {
     using T = Tile16<NB>;
     constexpr int BM = T::BM, BN = T::BN, A_LD = T::A_LD, W_LD = T::W_LD, NTHR = T::NTHR;
@@ -1002,25 +953,6 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
         const bool more = kc + 1 < nk;
         if (more) load_chunk(kc + 1);
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (F16) {
-            f16x8x2 a[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-                a[g] = split2h(*reinterpret_cast<const f32x4*>(a_frag + g * 2048), *reinterpret_cast<const f32x4*>(a_frag + g * 2048 + 1024));
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const uint8_t* wp = w_frag + n * 16 * WSPLIT_ROW_BYTES;
-                const f16x8 w0 = *reinterpret_cast<const f16x8*>(wp);
-                const f16x8 w1 = *reinterpret_cast<const f16x8*>(wp + 16);
-                const f16x8 w2 = *reinterpret_cast<const f16x8*>(wp + 32);
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {   // small terms first, the leading product last
-                    acc[g][n] = mfma16_f16_k32(w2, a[g].lo, acc[g][n]);
-                    acc[g][n] = mfma16_f16_k32(w1, a[g].hi, acc[g][n]);
-                    acc[g][n] = mfma16_f16_k32(w0, a[g].hi, acc[g][n]);
-                }
-            }
-        } else {
         bf16x8x3 a[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -1041,14 +973,11 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
                 acc[g][n] = mfma16_bf16_k32(w0, a[g].s0, acc[g][n]);
             }
         }
-        }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // everyone done reading before the single buffer is refilled
         if (more) store_chunk();
         __syncthreads();
     }
-    float ws = 1.0f;   // accumulator scale of an f16x2 image (2^-k, exact)
-    if constexpr (F16) ws = wsplit_acc_scale(p.Wsplit, p.N, p.K);
     // ---- epilogue: lane (c, qd) owns token 32 wave + 16 g + c, columns n0 + 16 n + 4 qd + {0,1,2,3}
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -1060,7 +989,6 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
             rstd = p.ln_in[2 * m + 1];
             nmr = -mean * rstd;
         }
-        rstd *= ws;
         float* const orow = p.out + m * p.N + n0 + 4 * qd;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -1072,7 +1000,7 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[g][n][e], ws, b4[e]);   // ws = 1: acc + b, same bits
+                for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -1082,11 +1010,11 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
     }
 }
 
-template <int NB, int MINW, int F16 = 0>
+template <int NB, int MINW>
 __global__ void __launch_bounds__(256, MINW) gemm16_kernel(const GemmParams p) {
     PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm16_tile<NB, F16>(p, blockIdx.x, gridDim.x, smem);
+    gemm16_tile<NB>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1148,11 +1076,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // One tile of the kernel as a device function: `b` of `nb` is the workgroup's index in its launch (or in its slot of a
 // grouped launch, see grouped_rowln_kernel); nb may exceed the tile count (slots are padded to multiples of 8 so that
 // b & 7 stays the XCD of the workgroup): surplus workgroups return at once.
-// F16 = 1: the f16x2 scheme on the same image geometry and ring (three MFMAs per group instead of six; 16-deep chunks, two stages)
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int ABL = 0, int BKC = 32, int F16 = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int ABL = 0, int BKC = 32>
 __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, const int nb, float* smem) {
     using T = DmaTile<WM, WN, NT, BKC>;
-    static_assert(!F16 || (BKC == 16 && NSTAGE == 2 && ABL == 0), "the f16x2 scheme has the production (16-deep, two-stage) form only");
     constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW;
     constexpr int NS2 = BKC / 16;                 // 16-deep MFMA steps per chunk
     constexpr int RPI = 1024 / T::A_ROW;          // A rows per DMA instruction (8 at BKC = 32, 16 at BKC = 16)
@@ -1413,46 +1339,6 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
             }
             SplitPair sp[4];
             u32x4 cur[3], nxt[3];
-            if constexpr (F16) {
-                // f16x2: the whole fragment is split here (32 VALU instructions, exposed once per chunk as the bf16x3 split of
-                // step 0 is - the other workgroup of the CU multiplies meanwhile); cur[0] = hi, cur[1] = lo
-    #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    SplitPairH sh;
-                    sh.x0 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q] : a_hi[2 * q - 4]);
-                    sh.x1 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q + 1] : a_hi[2 * q - 3]);
-                    sh.split();
-                    cur[0][q] = sh.hi, cur[1][q] = sh.lo;
-                }
-                static_for<NG>([&](auto G) {
-                    constexpr int g = decltype(G)::value;
-                    if constexpr (g + 1 < NG) {
-                        load_w(std::integral_constant<int, g + 1>{});  // in flight during this group's MFMAs
-                        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]), "+v"(wf[g & 1][2]));
-                    }
-                    const u32x4(&w)[3] = wf[g & 1];
-                    auto mm = [&](int wi, int ai) {
-                        PAFUSE_PIN_ACC(acc[g]);
-                        acc[g] = mfma_f16_k16(__builtin_bit_cast(f16x8, w[wi]), __builtin_bit_cast(f16x8, cur[ai]), acc[g]);
-                    };
-                    mm(2, 1);   // lo w2: small terms first, the leading product last
-                    {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
-                        constexpr int PER = (CNT + NG - 1) / NG, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
-                        if constexpr (j0 < j1) {
-                            asm volatile("" ::: "memory");
-                            if (refill) {
-    #pragma unroll
-                                for (int j = j0; j < j1; ++j) issue_piece(kn, stn, j);
-                            }
-                            asm volatile("" ::: "memory");
-                        }
-                    }
-                    mm(1, 0);   // hi w1
-                    mm(0, 0);   // hi w0
-                });
-            } else {
     #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 sp[q].x0 = __builtin_bit_cast(float, q < 2 ? a_lo[2 * q] : a_hi[2 * q - 4]);
@@ -1541,7 +1427,6 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
                         cur[0][q] = cur[2][q] = __builtin_bit_cast(uint32_t, sp[q].x0), cur[1][q] = __builtin_bit_cast(uint32_t, sp[q].x1);
                 }
             });
-            }   // !F16
     #undef PAFUSE_PIN_ACC
     #undef PAFUSE_PIN_PAIR
             __builtin_amdgcn_s_setprio(0);
@@ -1569,16 +1454,14 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
         if (sacc == 123.456f) p.out[0] = sacc;  // keeps the accumulators alive, stores nothing
         return;
     }
-    float ws = 1.0f;   // accumulator scale of an f16x2 image (2^-k, exact)
-    if constexpr (F16) ws = wsplit_acc_scale(p.Wsplit, p.N, p.K);
-    epilogue_row_per_lane<WN, NT, BM, EPI, VEC>(acc, p, m0, n0, wm, wn, r, h, smem, ws);
+    epilogue_row_per_lane<WN, NT, BM, EPI, VEC>(acc, p, m0, n0, wm, wn, r, h, smem);
 }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32, int F16 = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) gemm_dma_kernel(const GemmParams p) {
     PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    gemm_dma_tile<WM, WN, NT, EPI, NSTAGE, ABL, BKC, F16>(p, blockIdx.x, gridDim.x, smem);
+    gemm_dma_tile<WM, WN, NT, EPI, NSTAGE, ABL, BKC>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1599,7 +1482,7 @@ struct GroupedGemmParams {
     int n;
 };
 
-template <int EPI, int F16 = 0>
+template <int EPI>
 __global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemmParams g) {
     PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1611,16 +1494,16 @@ __global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemm
     const GemmParams& p = g.p[s];
     const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
     switch (p.N) {  // workgroup-uniform
-        case 384: gemm_dma_tile<2, 2, 6, EPI, 2, 0, 16, F16>(p, lb, nb, smem); break;
-        case 256: gemm_dma_tile<2, 2, 4, EPI, 2, 0, 16, F16>(p, lb, nb, smem); break;
-        case 224: gemm_dma_tile<4, 1, 7, EPI, 2, 0, 16, F16>(p, lb, nb, smem); break;
+        case 384: gemm_dma_tile<2, 2, 6, EPI, 2, 0, 16>(p, lb, nb, smem); break;
+        case 256: gemm_dma_tile<2, 2, 4, EPI, 2, 0, 16>(p, lb, nb, smem); break;
+        case 224: gemm_dma_tile<4, 1, 7, EPI, 2, 0, 16>(p, lb, nb, smem); break;
         default: break;
     }
 }
 
 // The plain layers (qkv, fc1 + GELU) of the parts in one grid, same slot scheme: split-precision register-staged tiles,
 // 128 x 128 where N allows, else 128 x 64, else 128 x 96 (row-per-lane epilogue); three workgroups per CU.
-template <int EPI, int MODE = 2>   // MODE: 2 bf16x3, 3 f16x2
+template <int EPI>
 __global__ void __launch_bounds__(256, 3) grouped_bias_kernel(const GroupedGemmParams g) {
     PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1632,11 +1515,11 @@ __global__ void __launch_bounds__(256, 3) grouped_bias_kernel(const GroupedGemmP
     const GemmParams& p = g.p[s];
     const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
     if (p.N % 128 == 0)  // (the order of the per-part dispatch, gemm_bias in pafuse_hip.hip)
-        gemm_tile<4, 1, 4, EPI, 1, 0, MODE>(p, lb, nb, smem);
+        gemm_tile<4, 1, 4, EPI, 1, 0, 2>(p, lb, nb, smem);
     else if (p.N % 64 == 0)
-        gemm_tile<4, 1, 2, EPI, 1, 0, MODE>(p, lb, nb, smem);
+        gemm_tile<4, 1, 2, EPI, 1, 0, 2>(p, lb, nb, smem);
     else
-        gemm_tile<4, 1, 3, EPI, 1, 1, MODE>(p, lb, nb, smem);
+        gemm_tile<4, 1, 3, EPI, 1, 1, 2>(p, lb, nb, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1648,6 +1531,7 @@ __global__ void __launch_bounds__(256, 3) grouped_bias_kernel(const GroupedGemmP
 struct AttnParams {
     const float* qkv;  // [M, 3C]
     float* o;          // [M, C]
+    uint8_t* o_h;      // or (f16x2 H pipeline): the output as an H image [M, C] (A operand of the proj hgemm); then o is unused
     int64_t nseq;
     int L, C, heads, d;
     int64_t group, group_stride, seq_stride, tok_stride;
@@ -1796,6 +1680,16 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
     // oc[ct][reg] = O[query 16*qt + l15][channel 16*ct + 4*g + reg]
     const int q = qt * 16 + l15;
     if (q < p.L) {
+        if (p.o_h) {   // channel c = head d + 16 ct + 4 g (a multiple of 4): sub-block c / 8, its second half when c & 4
+            uint8_t* const hrow = p.o_h + (base + q * p.tok_stride) * p.C * 4;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (ct * 16 + 4 * g < p.d) {
+                    const int c = head * p.d + ct * 16 + 4 * g;
+                    hsplit_store4(hrow + (c >> 3) * 32, c & 4, oc[ct]);
+                }
+            return;
+        }
         float* orow = p.o + (base + q * p.tok_stride) * p.C + head * p.d + 4 * g;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -1836,7 +1730,7 @@ struct FqaTile {
     static constexpr int LDS_BYTES = STAGE_BYTES > QKV_BYTES ? STAGE_BYTES : QKV_BYTES;
 };
 
-template <int LP, int DP, int F16 = 0>   // F16 = 1: the f16x2 scheme in the projection phase
+template <int LP, int DP>
 __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
     PAFUSE_XQ_GUARD();
     using FT = FqaTile<LP, DP>;
@@ -1911,25 +1805,6 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
         const bool more = kc + 1 < nk;
         if (more) load_chunk(kc + 1);
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (F16) {
-            f16x8x2 a[2];
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-                a[g] = split2h(*reinterpret_cast<const f32x4*>(a_frag + g * 2048), *reinterpret_cast<const f32x4*>(a_frag + g * 2048 + 1024));
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const uint8_t* wp = w_frag + n * 16 * WSPLIT_ROW_BYTES;
-                const f16x8 w0 = *reinterpret_cast<const f16x8*>(wp);
-                const f16x8 w1 = *reinterpret_cast<const f16x8*>(wp + 16);
-                const f16x8 w2 = *reinterpret_cast<const f16x8*>(wp + 32);
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    acc[g][n] = mfma16_f16_k32(w2, a[g].lo, acc[g][n]);
-                    acc[g][n] = mfma16_f16_k32(w1, a[g].hi, acc[g][n]);
-                    acc[g][n] = mfma16_f16_k32(w0, a[g].hi, acc[g][n]);
-                }
-            }
-        } else {
         bf16x8x3 a[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -1950,7 +1825,6 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
                 acc[g][n] = mfma16_bf16_k32(w0, a[g].s0, acc[g][n]);
             }
         }
-        }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // everyone done reading before the single buffer is refilled (after the last chunk: before phase 2)
         if (more) store_chunk();
@@ -1961,8 +1835,6 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
     float* const Qs = smem;                    // [ROWS][LDV] each
     float* const Ks = Qs + ROWS * LDV;
     float* const Vs = Ks + ROWS * LDV;
-    float ws = 1.0f;   // accumulator scale of an f16x2 image (2^-k, exact)
-    if constexpr (F16) ws = wsplit_acc_scale(p.Wsplit, p.N, p.K);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int r = 32 * wave + 16 * g + c;
@@ -1973,7 +1845,6 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
             rstd = p.ln_in[2 * m + 1];
             nmr = -mean * rstd;
         }
-        rstd *= ws;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
@@ -1985,7 +1856,7 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[g][n][e], ws, b4[e]);   // ws = 1: acc + b, same bits
+                for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
             }
             const int part = (16 * n) / DP, cc = col - part * DP;
             *reinterpret_cast<f32x4*>(Qs + part * ROWS * LDV + r * LDV + cc) = v;
@@ -2182,6 +2053,8 @@ struct EmbedParams {
     const float *n_w, *n_b;             // next LayerNorm
     float n_eps;
     float *x, *xn;  // [M,C]
+    uint8_t* xh;    // f16x2 H pipeline: the H image [M,C] the first qkv hgemm reads - of x when `stats` is set (LayerNorm
+    //                 folded), else of the normalised row (then xn is not written)
     float* stats;   // folded LayerNorm (GemmParams::ln_in of the first qkv GEMM): (mean, rstd) of row row0 + i at stats[2 i]
     //                 instead of xn; null = write xn
     int B, P, F, J, J3, C, nflip;
@@ -2248,6 +2121,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
                 s += a;
             }
             if (live) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
+            if (live && p.xh && p.stats) hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), v[i]);
         }
     }
     const float invC = 1.0f / (float)p.C;
@@ -2279,7 +2153,8 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-            if (live) *reinterpret_cast<f32x4*>(p.xn + row * p.C + 4 * c4) = o;
+            if (live && p.xh) hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), o);
+            else if (live) *reinterpret_cast<f32x4*>(p.xn + row * p.C + 4 * c4) = o;
         }
     }
 }

@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -13,6 +12,7 @@
 #include <cstring>
 
 #include "kernels.hpp"
+#include "hgemm.hpp"
 #include "train_kernels.hpp"
 
 using namespace pafuse;
@@ -75,15 +75,15 @@ struct StreamDevice {
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW = 1, int TR = 0, int BF16 = 0>
 int launch_gemm(const GemmParams& p, hipStream_t s) {
     using T = GemmTile<WM, WN, NT>;
-    constexpr size_t stage_bytes = (size_t)NSTAGE * (BF16 >= 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * sizeof(float);
-    if (BF16 >= 2 && !p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
+    constexpr size_t stage_bytes = (size_t)NSTAGE * (BF16 == 2 ? T::STAGE_FLOATS_SPLIT : T::STAGE_FLOATS) * sizeof(float);
+    if (BF16 == 2 && !p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     static_assert(EPI == EPI_BIAS || 7 * T::BM * WN <= NSTAGE * T::STAGE_FLOATS, "cross-wave reduction scratch must fit");
     static_assert(stage_bytes <= 160 * 1024, "LDS budget");
     size_t lds = stage_bytes;
     auto k = gemm_kernel<WM, WN, NT, EPI, NSTAGE, MINW, TR, BF16>;
 #ifdef PAFUSE_DIAG
     static const int dbg_pad = [] { const char* e = getenv("PAFUSE_DEBUG_LDS_PAD"); return e ? atoi(e) : 0; }();
-    if (dbg_pad && BF16 >= 2 && EPI == EPI_BIAS) {  // diagnostic: keep other kernels off this workgroup's CU
+    if (dbg_pad && BF16 == 2 && EPI == EPI_BIAS) {  // diagnostic: keep other kernels off this workgroup's CU
         lds = std::max(lds, (size_t)dbg_pad);
         hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     } else
@@ -100,11 +100,11 @@ int launch_gemm(const GemmParams& p, hipStream_t s) {
 }
 
 // qkv projection + attention of one head per workgroup (kernels.hpp fqa_kernel)
-template <int LP, int DP, int F16 = 0>
+template <int LP, int DP>
 int launch_fqa(const FqaParams& f, hipStream_t s) {
     using FT = FqaTile<LP, DP>;
     static_assert(FT::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-    auto k = fqa_kernel<LP, DP, F16>;
+    auto k = fqa_kernel<LP, DP>;
     if (FT::LDS_BYTES > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
@@ -124,13 +124,32 @@ static bool fqa_has(int L, int d) {   // (48, 48) would need 80.4 KB of LDS: one
     return lp && dp && !(lp == 48 && dp == 48);
 }
 
+// the same decomposition in the f16x2 H pipeline (hgemm.hpp hfqa_kernel): A and the head-major weight as H images, o as H image
+template <int LP, int DP>
+int launch_hfqa(const FqaParams& f, hipStream_t s) {
+    using FT = HfqaTile<LP, DP>;
+    static_assert(FT::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    auto k = hfqa_kernel<LP, DP>;
+    if (FT::LDS_BYTES > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
+    }
+    if (!f.g.Ah || !f.g.Wh) return fail(PAFUSE_E_ARG, "fused qkv-attention (f16x2) without the H images of its operands");
+    const int64_t ntiles = (f.nseq + f.nseq_tile - 1) / f.nseq_tile;
+    const int64_t blocks = (ntiles + 7) / 8 * 8 * f.heads;
+    if (blocks <= 0 || blocks > 0x7fffffff) return fail(PAFUSE_E_ARG, "fused qkv-attention grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), FT::LDS_BYTES, s, f);
+    return check_launch("hfqa_kernel");
+}
+
 int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
     if (f.nseq <= 0) return PAFUSE_OK;
     const int lp = fqa_lp(f.L), dp = fqa_dp(f.d);
-    if (f.g.bf16 == 3) {   // f16x2 products in the projection phase
-        if (lp == 32 && dp == 48) return launch_fqa<32, 48, 1>(f, s);
-        if (lp == 32 && dp == 32) return launch_fqa<32, 32, 1>(f, s);
-        if (lp == 48 && dp == 32) return launch_fqa<48, 32, 1>(f, s);
+    if (f.g.bf16 == 3) {
+        if (lp == 32 && dp == 48) return launch_hfqa<32, 48>(f, s);
+        if (lp == 32 && dp == 32) return launch_hfqa<32, 32>(f, s);
+        if (lp == 48 && dp == 32) return launch_hfqa<48, 32>(f, s);
+        return fail(PAFUSE_E_SHAPE, "fused qkv-attention: no kernel for L=%d, d=%d", f.L, f.d);
     }
     if (lp == 32 && dp == 48) return launch_fqa<32, 48>(f, s);
     if (lp == 32 && dp == 32) return launch_fqa<32, 32>(f, s);
@@ -139,14 +158,14 @@ int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
 }
 
 // the qkv layers' kernel on v_mfma_f32_16x16x32_bf16 (kernels.hpp gemm16_tile); the image must be in the M16 layout
-template <int NB, int MINW, int F16 = 0>
+template <int NB, int MINW>
 int launch_gemm16(const GemmParams& p, hipStream_t s) {
     using T = Tile16<NB>;
     static_assert(T::STAGE_BYTES <= 64 * 1024, "LDS budget without the attribute");
     if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     const int64_t tiles = ((p.M + T::BM - 1) / T::BM) * (p.N / T::BN);
     if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
-    hipLaunchKernelGGL((gemm16_kernel<NB, MINW, F16>), dim3((unsigned)tiles), dim3(T::NTHR), T::STAGE_BYTES, s, p);
+    hipLaunchKernelGGL((gemm16_kernel<NB, MINW>), dim3((unsigned)tiles), dim3(T::NTHR), T::STAGE_BYTES, s, p);
     return check_launch("gemm16_kernel");
 }
 
@@ -156,7 +175,7 @@ int launch_gemm16(const GemmParams& p, hipStream_t s) {
 // and 224 run on the LDS-DMA kernel with 16-deep chunks, everything else on 32-deep chunks.
 int wsplit_chunk(int N, bool whole_row) { return (whole_row && (N == 384 || N == 288 || N == 256 || N == 224)) ? 16 : 32; }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32, int F16 = 0>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int BKC = 32>
 int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     using T = DmaTile<WM, WN, NT, BKC>;
     constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
@@ -164,7 +183,7 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
     if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
     if (p.K % BKC) return fail(PAFUSE_E_SHAPE, "split GEMM: K=%d is not a multiple of %d", p.K, BKC);
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, 0, BKC, F16>;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI, NSTAGE, MINW, 0, BKC>;
     if (lds > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -173,6 +192,50 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
     if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, s, p);
     return check_launch("gemm_dma_kernel");
+}
+
+// ---- f16x2 "H pipeline" (hgemm.hpp): both operands arrive as H images; one workgroup of WM x WN waves per CU
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW>
+int launch_hgemm(const GemmParams& p, hipStream_t s) {
+    using T = HTile<WM, WN, NT, BKC>;
+    constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
+    if (!p.Ah || !p.Wh) return fail(PAFUSE_E_ARG, "f16x2 GEMM without the H images of its operands");
+    if (p.K % BKC || p.K <= 0 || p.N % T::BN) return fail(PAFUSE_E_SHAPE, "f16x2 GEMM: N=%d, K=%d do not fit the %d-column tile", p.N, p.K, T::BN);
+    auto k = hgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW>;
+    if (lds > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, s, p);
+    return check_launch("hgemm_kernel");
+}
+
+// widths the f16x2 kernels serve: the PAFUSE parts' (whole-row layers), and every plain-layer width that tiles by 128 or 224
+bool hgemm_width(int C) { return C == 384 || C == 256 || C == 224; }
+bool hgemm_plain_n(int N) { return N > 0 && (N % 128 == 0 || N % 224 == 0); }
+
+// tile choice per shape: tools/hgemm_bench.hip (profiles/r04_hgemm_bench_*.log).  With three products per k these layers sit
+// between the matrix, the L2 -> LDS and the HBM bound (a whole-row launch moves 4 M C floats for 6 M C K MFMA-flops), so the
+// winners are the tiles that keep MORE workgroups per CU in different phases, not the tallest ones.
+int hgemm_bias(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return PAFUSE_OK;
+    if (p.N % 128 == 0) return launch_hgemm<4, 2, 2, EPI_BIAS, 3, 16, 2>(p, s);   // 128 x 128, eight waves, three per CU
+    if (p.N % 224 == 0) return launch_hgemm<4, 1, 7, EPI_BIAS, 3, 16, 2>(p, s);   // 128 x 224 (the face: 672 = 3 x 224, 448 = 2 x 224)
+    return fail(PAFUSE_E_SHAPE, "f16x2 linear: N=%d must be a multiple of 128 or 224", p.N);
+}
+
+int hgemm_rowln(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return PAFUSE_OK;
+    switch (p.N) {
+        case 384: return launch_hgemm<4, 2, 6, EPI_ROWLN, 2, 32, 1>(p, s);   // 128 rows, eight waves, 128 KB ring: one per CU
+        case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2>(p, s);   // 64 rows, four waves, three per CU
+        case 224: return launch_hgemm<4, 1, 7, EPI_ROWLN, 3, 16, 2>(p, s);   // 128 rows, four waves (7 column blocks do not split), two per CU
+        default: return fail(PAFUSE_E_SHAPE, "no f16x2 whole-row kernel for channel width %d (have 224, 256, 384)", p.N);
+    }
 }
 
 // diagnostic switch, compiled only into -DPAFUSE_DIAG builds (tools/): environment PAFUSE_DEBUG_F32_MASK, read once -
@@ -192,7 +255,6 @@ constexpr int debug_f32_mask() { return 0; }
 
 int gemm_bias(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
-    if (p.bf16 < 0 || p.bf16 > 3) return fail(PAFUSE_E_ARG, "linear: matrix-product mode %d", p.bf16);
     if (p.bf16 == 2 && (debug_f32_mask() & 1)) p.bf16 = 0;
     if (p.bf16 == 2 && (debug_f32_mask() & 4) && !p.act) p.bf16 = 0;   // qkv only
     if (p.bf16 == 2 && (debug_f32_mask() & 8) && p.act) p.bf16 = 0;    // fc1 only
@@ -202,6 +264,7 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
+    if (p.bf16 == 3) return hgemm_bias(p, s);   // f16x2: the H pipeline
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
@@ -213,18 +276,6 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
         if (p.N % 96 == 0) return launch_gemm16<6, 3>(p, s);     // face 672, single-model 864: 128 x 96
         if (p.N % 64 == 0) return launch_gemm16<4, 4>(p, s);
         return launch_gemm16<2, 4>(p, s);
-    }
-    if (p.bf16 == 3 && p.wlayout == 2) {  // f16x2, the qkv layers: the same tiles, three products on v_mfma_f32_16x16x32_f16
-        if (p.N % 128 == 0) return launch_gemm16<8, 3, 1>(p, s);
-        if (p.N % 96 == 0) return launch_gemm16<6, 3, 1>(p, s);
-        if (p.N % 64 == 0) return launch_gemm16<4, 4, 1>(p, s);
-        return launch_gemm16<2, 4, 1>(p, s);
-    }
-    if (p.bf16 == 3) {  // f16x2: the tiles of the bf16x3 dispatch below, three products per k instead of six
-        if (p.N % 128 == 0 && p.M >= 4096) return launch_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 3>(p, s);
-        if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 3>(p, s);
-        if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 3>(p, s);
-        return launch_gemm<4, 1, 1, EPI_BIAS, 1, 1, 0, 3>(p, s);
     }
     if (p.bf16 == 2) {  // split precision (bf16x3): fp32-equivalent products on the bf16 matrix cores
         // measured per shape with tools/gemm_bench.hip (profiles/r02_gemm_bench_split_v1.log): 128x128 tiles at two
@@ -250,7 +301,10 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
     if (p.bf16 == 2 && (debug_f32_mask() & 2)) p.bf16 = 0;
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
-    if (p.bf16 < 0 || p.bf16 > 3 || (EPI == EPI_ROWLN_TRAIN && p.bf16 == 3)) return fail(PAFUSE_E_ARG, "rowln: matrix-product mode %d", p.bf16);
+    if (p.bf16 == 3) {   // f16x2: the H pipeline (inference only)
+        if constexpr (EPI == EPI_ROWLN) return hgemm_rowln(p, s);
+        else return fail(PAFUSE_E_ARG, "training has no f16x2 kernels");
+    }
     if constexpr (EPI == EPI_ROWLN_TRAIN) {   // training forward with split products: the three PAFUSE widths (train_host.inc)
         if (p.bf16 == 2) {
             switch (p.N) {
@@ -263,18 +317,6 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
         }
     }
     if constexpr (EPI == EPI_ROWLN) {
-        if (p.bf16 == 3) {   // f16x2: the bf16x3 tiles below with three products per k
-            switch (p.N) {
-                case 384: return launch_gemm_dma<2, 2, 6, EPI, 2, 2, 16, 1>(p, s);
-                case 288: return launch_gemm_dma<2, 3, 3, EPI, 2, 2, 16, 1>(p, s);
-                case 256: return launch_gemm_dma<2, 2, 4, EPI, 2, 2, 16, 1>(p, s);
-                case 224:
-                    return p.M >= 4096 ? launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16, 1>(p, s) : launch_gemm_dma<2, 1, 7, EPI, 2, 2, 16, 1>(p, s);
-                case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 3>(p, s);
-                case 64: return launch_gemm<1, 2, 1, EPI, 1, 1, 1, 3>(p, s);
-                default: return fail(PAFUSE_E_SHAPE, "no f16x2 whole-row kernel for channel width %d", p.N);
-            }
-        }
         if (p.bf16 == 2) {
             switch (p.N) {
                 // picked per width with tools/gemm_bench.hip (profiles/r02_gemm_bench_*.log): the LDS-DMA kernel on 16-deep
@@ -323,23 +365,19 @@ int gemm_rowln_train(const GemmParams& p, hipStream_t s) { return gemm_rowln_as<
 // Only the split-precision mode has them (the fp32 mode overlaps parts on streams instead); anything a grouped kernel
 // has no variant for goes part by part through the dispatch above - same tiles, same arithmetic, same results.
 bool group_ok_rowln(const GemmParams& p) {
-    return (p.bf16 == 2 || p.bf16 == 3) && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 &&
-           p.K > 0 && !(debug_f32_mask() & 2);
+    return p.bf16 == 2 && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 && p.K > 0 &&
+           !(debug_f32_mask() & 2);
 }
 bool group_ok_bias(const GemmParams& p) {
-    return (p.bf16 == 2 || p.bf16 == 3) && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 &&
-           !(debug_f32_mask() & 29);
+    return p.bf16 == 2 && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 && !(debug_f32_mask() & 29);
 }
-// process-wide schedule option (pafuse_set_grouped_launches): the same layer of the parts in shared grids (default) or
-// part by part - same tiles, same arithmetic, same bits either way
-std::atomic<int> g_grouped{1};
-bool grouping_enabled() { return g_grouped.load(std::memory_order_relaxed) != 0; }
+// (whether the parts of a configuration share grids is the caller's choice per call: pafuse_d3dp_config.part_by_part_launches -
+// same tiles, same arithmetic, same bits either way; there is no process-wide schedule state)
 
 template <bool ROWLN>
-int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
-    bool ok = grouping_enabled() && n >= 2 && n <= GROUP_MAX;
-    for (int i = 0; i < n && ok; ++i)   // (one product scheme per grid)
-        ok = ps[i].M > 0 && ps[i].bf16 == ps[0].bf16 && (ROWLN ? group_ok_rowln(ps[i]) : group_ok_bias(ps[i]));
+int gemm_group(const GemmParams* ps, int n, hipStream_t s, bool shared_grids) {
+    bool ok = shared_grids && n >= 2 && n <= GROUP_MAX;
+    for (int i = 0; i < n && ok; ++i) ok = ps[i].M > 0 && (ROWLN ? group_ok_rowln(ps[i]) : group_ok_bias(ps[i]));
     if (!ok) {
         for (int i = 0; i < n; ++i) {
             const int rc = ROWLN ? gemm_rowln(ps[i], s) : gemm_bias(ps[i], s);
@@ -375,13 +413,6 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
     if (ROWLN) {
         constexpr size_t lds = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES;  // the widest variant's ring
         static_assert(lds >= 2 * DmaTile<2, 2, 4, 16>::STAGE_BYTES && lds >= 2 * DmaTile<4, 1, 7, 16>::STAGE_BYTES && lds <= 80 * 1024, "LDS");
-        if (ps[0].bf16 == 3) {
-            auto k = grouped_rowln_kernel<EPI_ROWLN, 1>;
-            static DeviceOnce once;
-            if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(k, dim3((unsigned)first), dim3(256), lds, s, g);
-            return check_launch("grouped_rowln_kernel");
-        }
         auto k = grouped_rowln_kernel<EPI_ROWLN>;
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -390,10 +421,7 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s) {
     } else {
         constexpr size_t lds = GemmTile<4, 1, 4>::STAGE_FLOATS_SPLIT * sizeof(float);
         static_assert(lds <= 64 * 1024, "LDS");
-        if (ps[0].bf16 == 3)
-            hipLaunchKernelGGL((grouped_bias_kernel<EPI_BIAS, 3>), dim3((unsigned)first), dim3(256), lds, s, g);
-        else
-            hipLaunchKernelGGL((grouped_bias_kernel<EPI_BIAS, 2>), dim3((unsigned)first), dim3(256), lds, s, g);
+        hipLaunchKernelGGL(grouped_bias_kernel<EPI_BIAS>, dim3((unsigned)first), dim3(256), lds, s, g);
         return check_launch("grouped_bias_kernel");
     }
 }
@@ -436,13 +464,15 @@ int attention(const AttnParams& p, hipStream_t s) {
 // --------------------------------------------------------------------------------------- per-part activations
 struct PartBuffers {
     float *x, *xn, *o, *wide;  // [M,C], [M,C], [M,C], [M,3C] (qkv, then the MLP hidden [M,2C])
+    //                            f16x2 mode: xn, o and (as the hidden) wide hold H images of those tensors - same bytes
     float* temb;               // [B,C]
     float* pred;               // [M,3]
+    float* stats;              // [M,2] (mean, rstd) of a row when the LayerNorm is folded into the consumer GEMM
 };
 
 size_t part_buffer_bytes(int64_t M, int C, int B) {
     return 3 * align_up((size_t)M * C * 4) + align_up((size_t)M * 3 * C * 4) + align_up((size_t)B * C * 4) +
-           align_up((size_t)M * 3 * 4);
+           align_up((size_t)M * 3 * 4) + align_up((size_t)M * 2 * 4);
 }
 
 char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb) {
@@ -458,6 +488,8 @@ char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb) {
     base += align_up((size_t)B * C * 4);
     pb.pred = (float*)base;
     base += align_up((size_t)M * 3 * 4);
+    pb.stats = (float*)base;
+    base += align_up((size_t)M * 2 * 4);
     return base;
 }
 
@@ -467,6 +499,7 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
     PartBuffers o = pb;
     o.x = pb.x + row0 * C, o.xn = pb.xn + row0 * C, o.o = pb.o + row0 * C, o.wide = pb.wide + row0 * 3 * C;
     o.pred = pb.pred + row0 * 3;
+    o.stats = pb.stats + row0 * 2;
     return o;
 }
 
@@ -485,6 +518,12 @@ int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
     if (w->joints < 1 || w->joints > 144 || w->frames < 1 || w->frames > 144)
         return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..144", w->joints, w->frames);
     if (w->operand_bf16 < 0 || w->operand_bf16 > 3) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
+    if (w->operand_bf16 == 3) {   // f16x2: the PAFUSE part widths; plain layers that tile by 128 or 224 columns
+        const int hidden = w->mlp_hidden > 0 ? w->mlp_hidden : 2 * w->channels;
+        if (!hgemm_width(w->channels) || !hgemm_plain_n(3 * w->channels) || !hgemm_plain_n(hidden) || hidden % 32)
+            return fail(PAFUSE_E_SHAPE, "f16x2 products serve the widths 224 / 256 / 384 with an MLP hidden width that is a multiple "
+                                        "of 128 or 224 (got C = %d, hidden = %d): use 'bf16x3'", w->channels, hidden);
+    }
     if (w->mlp_hidden < 0 || (w->mlp_hidden > 0 && (w->mlp_hidden % 32 || w->mlp_hidden > 3 * w->channels)))
         return fail(PAFUSE_E_SHAPE, "mlp hidden width %d must be a multiple of 32 and at most 3C = %d", w->mlp_hidden, 3 * w->channels);
     if (!(w->qk_scale >= 0.f)) return fail(PAFUSE_E_ARG, "qk_scale must be positive (0 = head_dim^-0.5)");
@@ -533,18 +572,24 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
                        int bf16, int hidden = 0, float qk_scale = 0.f, bool fold = false) {
     if (hidden <= 0) hidden = 2 * C;  // mlp_ratio = 2, the PAFUSE configuration
     BlockLaunch b{};
-    // fold: the LayerNorm in front of qkv / fc1 is applied inside those GEMMs (GemmParams::ln_in); the statistics of a
-    // row live where xn would (2 floats per row at the start of the part's xn buffer - offset_rows keeps groups apart)
-    float* const stats = pb.xn;
+    // fold: the LayerNorm in front of qkv / fc1 is applied inside those GEMMs (GemmParams::ln_in); the producer of a row
+    // leaves its (mean, rstd) in the part's stats buffer
+    float* const stats = pb.stats;
+    // f16x2 (bf16 == 3): every GEMM operand is an H image - xn (of x with the fold, else of LN(x)), o, and the MLP hidden in
+    // `wide` are written in that form by their producers (hgemm.hpp); the *_ws pointers are the weights' H images
+    const bool hp = bf16 == 3;
+    uint8_t* const xn_h = reinterpret_cast<uint8_t*>(pb.xn);
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     GemmParams& g = b.qkv;
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
     g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws, g.wlayout = 2;   // qkv images are in the M16 layout (include/pafuse_hip.h)
     if (fold) g.A = pb.x, g.ln_in = stats, g.ln_s = bw.qkv_ls, g.bias = bw.qkv_lt;
+    if (hp) g.Ah = xn_h, g.Wh = (const uint8_t*)bw.qkv_ws;
     AttnParams& a = b.attn;
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
     a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
     a.scale = qk_scale != 0.f ? qk_scale : 1.0f / sqrtf((float)(C / heads));  // qk_scale or head_dim ** -0.5  mixste.py:52
+    if (hp) a.o_h = reinterpret_cast<uint8_t*>(pb.o);
     // the two in one kernel where a head-major image was supplied and the shape has a fused form
     b.fused = false;
     if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads) && (!fold || bw.qkv_hl)) {
@@ -552,6 +597,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
         FqaParams& f = b.fqa;
         f.g = g;
         f.g.Wsplit = (const uint8_t*)bw.qkv_hs, f.g.bias = bw.qkv_hb, f.g.ln_s = fold ? bw.qkv_hl : nullptr;
+        if (hp) f.g.Wh = (const uint8_t*)bw.qkv_hs;   // (Ah is the qkv launch's; o is written as the H image the proj hgemm reads)
         f.g.N = heads * 3 * dp;
         f.o = pb.o, f.nseq = nseq, f.L = L, f.C = C, f.heads = heads, f.d = C / heads;
         f.nseq_tile = (rows - lp) / L + 1;    // whole sequences per 128-row tile, the last one's LP-row key tile inside the buffer
@@ -566,11 +612,17 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     pj.next_w = bw.norm2_w, pj.next_b = bw.norm2_b, pj.next_eps = 1e-6f;
     pj.bf16 = bf16, pj.Wsplit = (const uint8_t*)bw.proj_ws;
     if (fold) pj.out_n = nullptr, pj.ln_stats = stats;
+    if (hp) {
+        pj.Ah = reinterpret_cast<const uint8_t*>(pb.o), pj.Wh = (const uint8_t*)bw.proj_ws;
+        if (fold) pj.out_xh = xn_h;
+        else pj.out_n = nullptr, pj.out_nh = xn_h;
+    }
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
     GemmParams& f1 = b.fc1;
     f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = hidden, f1.K = C, f1.act = 1;
     f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
     if (fold) f1.A = pb.x, f1.ln_in = stats, f1.ln_s = bw.fc1_ls, f1.bias = bw.fc1_lt;
+    if (hp) f1.Ah = xn_h, f1.Wh = (const uint8_t*)bw.fc1_ws, f1.out_h = reinterpret_cast<uint8_t*>(pb.wide);
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
     GemmParams& f2 = b.fc2;
     f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = hidden;
@@ -582,6 +634,11 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     if (!tail.next_w) f2.out_n = nullptr;
     if (fold && tail.next_w && !tail.out_head) f2.out_n = nullptr, f2.ln_stats = stats;   // the head keeps its own LayerNorm
     f2.bf16 = bf16, f2.Wsplit = (const uint8_t*)bw.fc2_ws;
+    if (hp) {
+        f2.Ah = reinterpret_cast<const uint8_t*>(pb.wide), f2.Wh = (const uint8_t*)bw.fc2_ws;
+        if (f2.ln_stats) f2.out_xh = xn_h;                       // folded: the next block's qkv reads the H image of x
+        else if (f2.out_n) f2.out_n = nullptr, f2.out_nh = xn_h;  // not folded: the H image of the next LayerNorm's output
+    }
     return b;
 }
 
@@ -612,7 +669,7 @@ void trace(const void* buf, size_t bytes, hipStream_t s) {
 // one block of n independent parts: the same layer of every part in one grid where the grouped kernels apply
 // (n == 1: the plain per-part launches)
 int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = false, double* flops = nullptr,
-               int* launches = nullptr, int layer_mask = 15) {
+               int* launches = nullptr, int layer_mask = 15, bool shared_grids = true) {
     int rc;
     GemmParams g[GROUP_MAX];
     auto count = [&](int layers) {
@@ -620,7 +677,7 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
         for (int i = 0; i < n; ++i) *flops += 2.0 * g[i].M * g[i].N * g[i].K;
         *launches += layers;
     };
-    const bool grouped = grouping_enabled() && n >= 2;
+    const bool grouped = shared_grids && n >= 2;
     auto layer = [&](GemmParams BlockLaunch::*which, bool rowln, int bit) -> int {
         if (!(layer_mask & bit)) return PAFUSE_OK;
         bool all = grouped;
@@ -628,7 +685,7 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
             g[i] = bl[i].*which;
             all = all && g[i].M > 0 && (rowln ? group_ok_rowln(g[i]) : group_ok_bias(g[i]));
         }
-        const int r = rowln ? gemm_group<true>(g, n, s) : gemm_group<false>(g, n, s);
+        const int r = rowln ? gemm_group<true>(g, n, s, shared_grids) : gemm_group<false>(g, n, s, shared_grids);
         count(all ? 1 : n);
         for (int i = 0; i < n; ++i) {
             if (rowln) {
@@ -672,7 +729,7 @@ int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, 
 // pb[i].xn; results in pb[i].pred [M_i,3].  Block k of every part is issued together (run_blocks).
 int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffers* pbs, const int64_t* Rs, int n,
                         hipStream_t s, bool gemms_only = false, double* flops = nullptr, int* launches = nullptr,
-                        int layer_mask = 15) {
+                        int layer_mask = 15, bool shared_grids = true) {
     if (n < 1 || n > GROUP_MAX) return fail(PAFUSE_E_ARG, "run_mixste_layers_n: %d parts", n);
     for (int i = 1; i < n; ++i)
         if (ws[i]->depth != ws[0]->depth) return fail(PAFUSE_E_ARG, "run_mixste_layers_n: parts of unequal depth");
@@ -691,7 +748,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16,
                                w->mlp_hidden, w->qk_scale, ln_folded(w));
         }
-        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask))) return rc;
+        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask, shared_grids))) return rc;
         for (int k = 0; k < n; ++k) {
             const pafuse_mixste2_weights* w = ws[k];
             const int F = w->frames, J = w->joints, C = w->channels;
@@ -708,7 +765,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             bl[k] = make_block(w->tte[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * J, F, J, (int64_t)F * J, 1, J, t,
                                w->operand_bf16, w->mlp_hidden, w->qk_scale, ln_folded(w));
         }
-        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask))) return rc;
+        if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask, shared_grids))) return rc;
     }
     return PAFUSE_OK;
 }
@@ -720,11 +777,9 @@ int run_mixste_layers(const pafuse_mixste2_weights* w, const PartBuffers& pb, in
 
 // parts of one configuration may share grids when they all run split-precision products and have the same depth
 bool parts_groupable(const pafuse_d3dp_config* cfg) {
-    if (!grouping_enabled() || cfg->num_parts < 2 || cfg->num_parts > GROUP_MAX) return false;
+    if (cfg->part_by_part_launches || cfg->num_parts < 2 || cfg->num_parts > GROUP_MAX) return false;
     for (int i = 0; i < cfg->num_parts; ++i)
-        if (cfg->part[i].operand_bf16 < 2 || cfg->part[i].operand_bf16 != cfg->part[0].operand_bf16 ||
-            cfg->part[i].depth != cfg->part[0].depth)
-            return false;
+        if (cfg->part[i].operand_bf16 != 2 || cfg->part[i].depth != cfg->part[0].depth) return false;
     return true;
 }
 
@@ -760,8 +815,6 @@ const char* pafuse_version(void) {
 #endif
 }
 const char* pafuse_last_error(void) { return g_err; }
-
-int pafuse_set_grouped_launches(int32_t on) { return g_grouped.exchange(on ? 1 : 0); }
 
 #ifdef PAFUSE_DIAG
 /* diagnostic builds only (not declared in include/pafuse_hip.h): hash every intermediate of the following passes of this
@@ -807,26 +860,19 @@ int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t layout, v
     StreamDevice on_stream_device(stream);
     if (!W || !out) return fail(PAFUSE_E_ARG, "split_weights: null pointer");
     if (N <= 0 || K <= 0 || K % BK) return fail(PAFUSE_E_SHAPE, "split_weights: N=%d, K=%d (K must be a positive multiple of 32)", N, K);
-    const bool f16 = (layout & PAFUSE_SPLIT_F16X2) != 0;
-    layout &= ~PAFUSE_SPLIT_F16X2;
-    if (layout < 0 || layout > 2) return fail(PAFUSE_E_ARG, "split_weights: layout %d (0 plain, 1 whole-row, 2 qkv; + PAFUSE_SPLIT_F16X2)", layout);
     const int64_t n = (int64_t)N * (K / 8);
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (f16) {   // the f16x2 image: the tensor's largest |W| first (into the tail's scratch word), then the scaled slices
+    if (layout & PAFUSE_SPLIT_F16X2) {   // the f16x2 H image (one geometry for every layer): largest |W| first, then the slices
         hipStream_t st = (hipStream_t)stream;
-        uint8_t* const tail = (uint8_t*)out + (size_t)N * K * 6;
-        if (hipMemsetAsync(tail, 0, WSPLIT_TAIL_BYTES, st) != hipSuccess) return fail(PAFUSE_E_HIP, "split_weights: memset failed");
+        uint8_t* const tail = (uint8_t*)out + (size_t)N * K * 4;
+        if (hipMemsetAsync(tail, 0, HSPLIT_TAIL_BYTES, st) != hipSuccess) return fail(PAFUSE_E_HIP, "split_weights: memset failed");
         const int64_t elems = (int64_t)N * K;
         hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<int64_t>((elems + 255) / 256, 1024)), dim3(256), 0, st, W, elems,
                            reinterpret_cast<uint32_t*>(tail) + 1);
-        if (layout == 2)
-            hipLaunchKernelGGL((split_weights_f16_kernel<32, 1>), grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
-        else if (wsplit_chunk(N, layout == 1) == 16)
-            hipLaunchKernelGGL(split_weights_f16_kernel<16>, grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
-        else
-            hipLaunchKernelGGL(split_weights_f16_kernel<32>, grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
-        return check_launch("split_weights_f16_kernel");
+        hipLaunchKernelGGL(hsplit_weights_kernel, grid, dim3(256), 0, st, W, (uint8_t*)out, N, K);
+        return check_launch("hsplit_weights_kernel");
     }
+    if (layout < 0 || layout > 2) return fail(PAFUSE_E_ARG, "split_weights: layout %d (0 plain, 1 whole-row, 2 qkv; or PAFUSE_SPLIT_F16X2)", layout);
 #ifdef PAFUSE_QKV_32X32
     if (layout == 2) layout = 0;
 #endif
@@ -845,7 +891,28 @@ int pafuse_linear_split(const float* A, const void* Wsplit, const float* bias, f
     if (!A || !Wsplit || !bias || !out || M < 0) return fail(PAFUSE_E_ARG, "linear_split: null pointer or negative M");
     GemmParams g{};
     g.A = A, g.Wsplit = (const uint8_t*)Wsplit, g.bias = bias, g.out = out, g.M = M, g.N = N, g.K = K, g.act = act & 1;
-    g.bf16 = (act & PAFUSE_LINEAR_F16X2_IMAGE) ? 3 : 2, g.wlayout = (act & PAFUSE_LINEAR_QKV_IMAGE) ? 2 : 0;
+    g.bf16 = 2, g.wlayout = (act & 2) ? 2 : 0;
+    return gemm_bias(g, (hipStream_t)stream);
+}
+
+int pafuse_hsplit_rows(const float* X, int64_t R, int32_t K, void* out, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!X || !out || R < 0) return fail(PAFUSE_E_ARG, "hsplit_rows: null pointer or negative row count");
+    if (K <= 0 || K % 8) return fail(PAFUSE_E_SHAPE, "hsplit_rows: K=%d must be a positive multiple of 8", K);
+    if (R == 0) return PAFUSE_OK;
+    const int64_t n = R * (K / 8);
+    if ((n + 255) / 256 > 0x7fffffff) return fail(PAFUSE_E_ARG, "hsplit_rows: grid out of range");
+    hipLaunchKernelGGL(hsplit_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, (uint8_t*)out, R, K);
+    return check_launch("hsplit_rows_kernel");
+}
+
+int pafuse_linear_h(const void* Ah, const void* Wh, const float* bias, float* out, void* out_h, int64_t M, int32_t N, int32_t K,
+                    int32_t act, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!Ah || !Wh || !bias || (!out && !out_h) || M < 0) return fail(PAFUSE_E_ARG, "linear_h: null pointer or negative M");
+    GemmParams g{};
+    g.Ah = (const uint8_t*)Ah, g.Wh = (const uint8_t*)Wh, g.bias = bias, g.out = out, g.out_h = (uint8_t*)out_h;
+    g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = 3;
     return gemm_bias(g, (hipStream_t)stream);
 }
 
@@ -879,6 +946,7 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
     StreamDevice on_stream_device(stream);
     if (!w || !x || !workspace || S < 0) return fail(PAFUSE_E_ARG, "block_forward: bad argument");
     if (operand_bf16 < 0 || operand_bf16 > 3) return fail(PAFUSE_E_ARG, "block_forward: matrix-product mode %d", operand_bf16);
+    if (operand_bf16 == 3 && !hgemm_width(C)) return fail(PAFUSE_E_SHAPE, "block_forward: f16x2 products serve the widths 224 / 256 / 384");
     if (operand_bf16 >= 2 && (!w->qkv_ws || !w->proj_ws || !w->fc1_ws || !w->fc2_ws))
         return fail(PAFUSE_E_ARG, "block_forward: split-precision mode needs the pre-split image of every linear weight");
     if (!width_supported(C)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", C);
@@ -891,8 +959,10 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
     PartBuffers pb;
     carve_part((char*)workspace, M, C, 1, pb);
     pb.x = x;
-    int rc = pafuse_layernorm(x, w->norm1_w, w->norm1_b, pb.xn, M, C, 1e-6f, stream);
+    // f16x2: the qkv GEMM reads the H image of LN1(x) - the fp32 rows pass through `wide` (free until qkv writes it)
+    int rc = pafuse_layernorm(x, w->norm1_w, w->norm1_b, operand_bf16 == 3 ? pb.wide : pb.xn, M, C, 1e-6f, stream);
     if (rc) return rc;
+    if (operand_bf16 == 3 && (rc = pafuse_hsplit_rows(pb.wide, M, C, pb.xn, stream))) return rc;
     BlockTail t{};  // plain Block.forward: no post norm, nothing after
     return run_block(*w, pb, M, C, heads, S, L, 1, L, 0, 1, t, s, false, nullptr, nullptr, operand_bf16);
 }
@@ -931,7 +1001,8 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.x3d = x3d, e.x2d = x2d, e.x2d_flip = nullptr, e.joints = nullptr, e.perm = nullptr;
     e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb.temb;
     e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
-    e.x = pb.x, e.xn = pb.xn, e.stats = ln_folded(w) ? pb.xn : nullptr;
+    e.x = pb.x, e.xn = pb.xn, e.stats = ln_folded(w) ? pb.stats : nullptr;
+    e.xh = w->operand_bf16 == 3 ? reinterpret_cast<uint8_t*>(pb.xn) : nullptr;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
@@ -1088,7 +1159,8 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb[i].temb;
             e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
             e.x = pb[i].x, e.xn = pb[i].xn;
-            e.stats = ln_folded(w) ? pb[i].xn + row0 * w->channels : nullptr;   // where offset_rows puts this group's xn
+            e.stats = ln_folded(w) ? pb[i].stats + row0 * 2 : nullptr;   // where offset_rows puts this group's statistics
+            e.xh = w->operand_bf16 == 3 ? reinterpret_cast<uint8_t*>(pb[i].xn) : nullptr;   // (indexed by the absolute row)
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
             e.do_clamp = 1, e.scale = (float)cfg->scale, e.lim = (float)(1.1 * cfg->scale), e.row0 = row0, e.nrows = nrows;
             hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)),

@@ -116,16 +116,24 @@ class D3DP(nn.Module):
         self.n_aux_streams = 2         # streams per device made on first use (0: everything on the current stream,
         #                                the parts' layers in grouped launches); 2 = the three parts side by side
         self._aux_by_device = {}       # shared by DataParallel replicas, keyed by device index
-        self.use_graph = False         # replay the whole loop as one hipGraph (captured per input shape)
+        self.part_by_part_launches = False   # single-stream bf16x3 schedule: every layer part by part instead of in shared grids
+        #                                      (same bits; pafuse_d3dp_config.part_by_part_launches - tests and A/B timing)
+        self.use_graph = False         # replay the whole loop as one hipGraph (captured per input shape).  Measured in round 4
+        #                                (profiles/r04_sweep.json): not faster at any P, so off
         self.max_rows_per_launch = 640  # nflip*B*P hypothesis passes per library call: larger batches are cut along
         #                                 the clip axis (clips are independent, results are bit-identical); bounds the
         #                                 workspace (0.9 GB per 40 rows) and keeps activations cache-resident
         self._graphs = {}
-        # matrix-product mode: the split-precision products (fp32-equivalent: the same parity bounds as the fp32 matrix
-        # cores hold - tests/test_hip_parity.py for the loop, tests/test_hip_train.py for the gradients).  In training
-        # they serve the plain GEMMs (qkv, fc1, every dX: +13 % on the step); 'f32' stays selectable
+        # matrix-product mode: the split-precision products (fp32-equivalent: as close to an fp64 evaluation as the
+        # reference's own fp32 arithmetic - tests/test_hip_parity.py, tests/test_hip_fullsize.py for the loop,
+        # tests/test_hip_train.py for the gradients).  Inference of the part-based model: 'f16x2' (three fp16 MFMA products,
+        # the H pipeline of csrc/hgemm.hpp; widths 224 / 256 / 384); the single-model variant (width 288) and training:
+        # 'bf16x3' - training under torch.distributed with more than one rank: 'f32' (see _training_precision);
+        # 'f32' stays selectable everywhere
+        default = "bf16x3" if (is_train or not self.part_based) else "f16x2"
         for m in self.denoisers().values():
-            m.operand_bf16 = self.PRECISIONS["bf16x3"]
+            m.operand_bf16 = self.PRECISIONS[default]
+        self.allow_split_products_under_ddp = False
 
     PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
 
@@ -192,6 +200,7 @@ class D3DP(nn.Module):
             cfg.part_joints[i] = getattr(self, f"_joints_{part}").data_ptr()
         cfg.joint_part, cfg.joint_local = self._joint_part.data_ptr(), self._joint_local.data_ptr()
         cfg.flip_perm = self._flip_perm.data_ptr()
+        cfg.part_by_part_launches = int(bool(self.part_by_part_launches))
         return cfg
 
     # ------------------------------------------------------------------------------------------- sampling
@@ -278,12 +287,12 @@ class D3DP(nn.Module):
             # a captured graph holds raw pointers to the parameters AND to every split image: key on the parameter
             # storage and on the image generation of every denoiser (bumped whenever a weight version changes), and drop
             # the graphs of dead generations - their images are freed and their static buffers would only pile up
-            shape_key = (B, P, len(steps), bool(flip), dev)
+            shape_key = (B, P, len(steps), bool(flip), dev, bool(self.part_by_part_launches))
             weights_key = (tuple(cfg.part[i].patch_w for i in range(cfg.num_parts)),
                            tuple((cfg.part[i].operand_bf16, m.split_generation.get(dev.index, 0))
                                  for i, m in enumerate(self.denoisers().values())))
             key = shape_key + weights_key
-            for k in [k for k in self._graphs if k[:5] == shape_key and k != key]:
+            for k in [k for k in self._graphs if k[:6] == shape_key and k != key]:
                 del self._graphs[k]
             g = self._graphs.get(key)
             if g is None:
@@ -319,10 +328,27 @@ class D3DP(nn.Module):
         target, [B,F,J,3], differentiable w.r.t. the parameters (:346-356)."""
         if not self.is_train:
             return self.ddim_sample(input_2d, input_3d, input_2d_flip=input_2d_flip, flip=self.flip)
+        self._training_precision()
         x_poses, _noises, t = self.prepare_targets(input_3d)
         return self.pred_parts(input_2d, x_poses, t.squeeze(-1))
 
     # ------------------------------------------------------------------------------------------------ training
+    def _training_precision(self):
+        """Training beside a collective: a step in 'bf16x3' issues v_mfma_f32_32x32x16_bf16 (whole-row forward tiles, dX, dW),
+        the instruction beside which a packed-fp32 VALU instruction of ANOTHER queue's kernel returns wrong lanes on MI355X
+        (profiles/r03_bf16_mfma_concurrency.md).  This library is compiled without such instructions; RCCL's reduction
+        kernels, which DistributedDataParallel overlaps with the backward on its own stream, are not ours.  Until a
+        multi-GPU soak shows bit-equal gradients, a process group of more than one rank trains on the fp32 matrix cores
+        ('f32'; set allow_split_products_under_ddp to keep 'bf16x3' at your own risk)."""
+        if self.allow_split_products_under_ddp or self.precision != "bf16x3":
+            return
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            import warnings
+            warnings.warn("pafuse_amd.D3DP: training under torch.distributed with world size > 1 runs 'f32' products (the "
+                          "bf16 matrix instruction of 'bf16x3' is not proven safe beside RCCL's kernels on MI355X)")
+            self.precision = "f32"
+
     def prepare_targets(self, targets):
         """common/diffusionpose.py:358-388: per sample one timestep and one noise draw (in that order, on the
         device), then q_sample + clamp in the fp64 of the schedule buffers (pafuse_d3dp_qsample), cast to fp32."""

@@ -111,10 +111,10 @@ class MixSTE2(nn.Module):
         #                                (pafuse_block_weights.qkv_ls ...: g-scaled weight images + two vectors per layer);
         #                                False = the whole-row kernels write the normalised rows (same function, one more
         #                                [M,C] store and normalise pass per whole-row launch)
-        self.fuse_qkv_attention = False  # split-precision inference, opt-in: qkv projection + attention of a block in ONE kernel
-        #                                where the sequence length has a fused form (include/pafuse_hip.h pafuse_block_weights.qkv_hs):
-        #                                q, k, v never reach memory.  Measured equal to the two kernels in time,
-        #                                so the default keeps the two kernels, whose GEMM is the better-utilised one
+        self.fuse_qkv_attention = None   # split-precision inference: qkv projection + attention of a block in ONE kernel where the
+        #                                sequence length has a fused form (include/pafuse_hip.h pafuse_block_weights.qkv_hs): q, k, v
+        #                                never reach memory.  None = on in 'f16x2' (that pipeline is bound by the bytes it moves:
+        #                                +7 % on the loop), off in 'bf16x3' (matrix-bound: equal in time)
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -146,7 +146,7 @@ class MixSTE2(nn.Module):
         fold = split and bool(self.fold_layernorm)
         if split:           # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
-        fuse = split and bool(self.fuse_qkv_attention)
+        fuse = split and (mode == 3 if self.fuse_qkv_attention is None else bool(self.fuse_qkv_attention))
         if fold or fuse:    # ... and so are the folded / head-major images and vectors: they also hold LayerNorm and bias values
             key += ("fold", fold, fuse) + tuple(get(n)._version for n in self._param_names if n.endswith(FOLD_SUFFIXES))
         dev = self._freqs.device

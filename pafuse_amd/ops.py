@@ -181,10 +181,24 @@ def ddim_finalize(preds, joint_part, joint_local, img, step_scalars, noise=None,
     return out, img
 
 
+def hsplit_rows(x):
+    """The activation H image of a contiguous fp32 [R,K] tensor (pafuse_hsplit_rows): per sub-block of 8 k the fp16 slices
+    hi = f16(a) and lo = f16((a - hi) 2^11), 4 R K bytes.  In the loop every producer writes this form itself; the unit tests
+    and pafuse_block_forward's first LayerNorm use this pass."""
+    lib = _lib.load()
+    _need(x.dim() == 2 and x.shape[1] % 8 == 0, "hsplit_rows: x must be [R, K] with K % 8 == 0")
+    R, K = x.shape
+    out = torch.empty(R * K * 4, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_hsplit_rows(_ptr(x, "x"), R, K, out.data_ptr(), _stream(x)))
+    return out
+
+
 def split_weights(weight, layout=0, scheme="bf16x3"):
     """Pre-split image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights);
     layout 0: the 32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers;
-    scheme 'bf16x3' (three bf16 slices) or 'f16x2' (three fp16 slices of the power-of-two-scaled weight)."""
+    scheme 'bf16x3' (three bf16 slices) or 'f16x2' (the H image: two fp16 slices of the power-of-two-scaled weight, one
+    geometry for every layer)."""
     lib = _lib.load()
     _need(weight.dim() == 2 and weight.shape[1] % 32 == 0, "split_weights: weight must be [N, K] with K % 32 == 0")
     _need(layout in (0, 2), "split_weights: layout 0 (fc1 kernel) or 2 (qkv kernel)")
@@ -210,9 +224,15 @@ def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3
     _need(img.numel() == lib.pafuse_split_weights_bytes(N, K), "linear_split: image size does not match the weight")
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+    if scheme == "f16x2":      # both operands as H images (pafuse_linear_h)
+        _need(N % 128 == 0 or N % 224 == 0, "linear_split: f16x2 serves N that is a multiple of 128 or 224")
+        ah = hsplit_rows(x2)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pafuse_linear_h(ah.data_ptr(), img.data_ptr(), _ptr(bias, "bias"), out.data_ptr(), None, x2.shape[0], N, K,
+                                           1 if act == "gelu" else 0, _stream(x)))
+        return out.view(*x.shape[:-1], N)
     with torch.cuda.device(x.device):
         _lib.check(lib.pafuse_linear_split(_ptr(x2, "x"), img.data_ptr(), _ptr(bias, "bias"), out.data_ptr(),
                                            x2.shape[0], N, K,
-                                           (1 if act == "gelu" else 0) + (2 if layout == 2 else 0) + (4 if scheme == "f16x2" else 0),
-                                           _stream(x)))
+                                           (1 if act == "gelu" else 0) + (2 if layout == 2 else 0), _stream(x)))
     return out.view(*x.shape[:-1], N)

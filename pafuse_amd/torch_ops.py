@@ -10,7 +10,8 @@ there is no fallback), with fake-tensor shape functions so the ops trace under `
   pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads, precision)  MixSTE2.forward, eval  common/mixste.py:278-298
   pafuse::ddim_loop(..., precision)                        D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
 
-``precision`` ('bf16x3' default, 'f16x2', 'f32', 'bf16') is the matrix-product mode of the linear
+``precision`` ('f16x2' = the part-based modules' inference default for the model-level ops, 'bf16x3' for pafuse::block, which
+serves every width; 'f32', 'bf16') is the matrix-product mode of the linear
 layers; in the split modes the ops build and cache the pre-split weight images themselves (cached_split_image).
 
 ``weights`` lists are in ``named_parameters()`` order of the corresponding module (= the reference's state-dict
@@ -24,8 +25,8 @@ from typing import List
 import torch
 
 from . import _lib
-from .mixste2 import (FOLDED_LINEAR, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear, image_layout,
-                      sinusoid_frequencies, split_image)
+from .mixste2 import (FOLDED_LINEAR, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear, head_major_qkv,
+                      image_layout, sinusoid_frequencies, split_image)
 
 BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
@@ -104,6 +105,20 @@ def cached_folded_linear(table, name, f16=False):
     return hit[0]
 
 
+def cached_head_major_qkv(table, name, heads, f16=False):
+    """(image, hb, hl) of a qkv layer for the fused qkv + attention kernel (mixste2.head_major_qkv, LayerNorm folded), made once
+    per version of the four tensors it is built from; the entry pins them (see cached_split_image)."""
+    block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
+    parts = (table[name], table[f"{block}.{norm}.weight"], table[f"{block}.{norm}.bias"], table[name[:-len("weight")] + "bias"])
+    key = ("head-major", bool(f16), int(heads)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
+    hit = _image_cache.get(key)
+    if hit is None:
+        while len(_image_cache) >= _IMAGE_CACHE_MAX:
+            _image_cache.pop(next(iter(_image_cache)))
+        hit = _image_cache[key] = (head_major_qkv(table.__getitem__, name, heads, True, f16), parts)
+    return hit[0]
+
+
 def _mode(precision):
     if precision not in PRECISIONS:
         raise _lib.PafuseError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
@@ -131,6 +146,9 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
                 images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, mode == 3)
             elif n.endswith(SPLIT_SUFFIXES):
                 images[n] = cached_split_image(t, image_layout(n), mode == 3)
+            if mode == 3 and n.endswith("attn.qkv.weight"):     # the modules' default in 'f16x2': qkv + attention in one kernel
+                stem = n[:-len("weight")]
+                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = cached_head_major_qkv(table, n, heads, True)
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
     return w, (table, fr, images)
 
@@ -231,7 +249,7 @@ def _(x, weights, heads, precision="bf16x3"):
 # ------------------------------------------------------------------------------------------- model-level ops
 @torch.library.custom_op("pafuse::mixste_eval", mutates_args=(), device_types="cuda")
 def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: List[torch.Tensor], depth: int,
-                heads: int, precision: str = "bf16x3") -> torch.Tensor:
+                heads: int, precision: str = "f16x2") -> torch.Tensor:
     lib = _lib.load()
     _need(x3d.dim() == 5 and x3d.shape[-1] == 3, "mixste_eval: x3d must be [B,P,F,J,3]")
     B, P, F, J, _ = x3d.shape
@@ -247,14 +265,14 @@ def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: 
 
 
 @mixste_eval.register_fake
-def _(x2d, x3d, t, weights, depth, heads, precision="bf16x3"):
+def _(x2d, x3d, t, weights, depth, heads, precision="f16x2"):
     return torch.empty_like(x3d)
 
 
 @torch.library.custom_op("pafuse::ddim_loop", mutates_args=(), device_types="cuda")
 def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, weights: List[torch.Tensor],
               part_joints: List[torch.Tensor], flip_perm: torch.Tensor, depth: int, heads: int, times: List[int],
-              sched: List[float], flip: bool, scale: float, precision: str = "bf16x3") -> torch.Tensor:
+              sched: List[float], flip: bool, scale: float, precision: str = "f16x2") -> torch.Tensor:
     """The whole sampler.  noise [n_draws,B,P,F,J,3] in the reference's draw order; weights = the per-part
     parameter lists concatenated in part order; part_joints[i] int32 joint indices of part i; flip_perm int32 [J];
     times[k] the k-th timestep (the last one is the step whose time_next < 0); sched 5 doubles per step:
@@ -313,7 +331,7 @@ def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, we
 
 
 @ddim_loop.register_fake
-def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale, precision="bf16x3"):
+def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale, precision="f16x2"):
     n_draws, B, P, F, J, _ = noise.shape
     return noise.new_empty(B, len(times), P, F, J, 3)
 

@@ -3,7 +3,7 @@
 of the four protocols (J-Best / P-Best / P-Agg / J-Agg, main_h3wb.py:327-348) at every DDIM step.
 
 Run on the GPU box:
-    python tests/reports/parity_report.py --out profiles/r03_parity_report.json [--no-fullsize] [extra P,T,B,precision ...]
+    python tests/reports/parity_report.py --out profiles/r04_parity_report.json [--no-fullsize] [extra P,T,B,precision ...]
 It runs exactly the case functions the GPU tests run (tests/test_hip_parity.py::loop_case for LOOP_CASES x {f32, bf16x3},
 tests/test_hip_fullsize.py::fullsize_case) plus the metric's own P=20, T=10 loop in both fp32-grade modes and the opt-in
 bf16 mode at P=5, T=5; every case is recorded under its name together with the SHA-256 of the oracle's output.  The tests
@@ -53,7 +53,7 @@ def main(argv):
         out_path, argv = argv[1], argv[2:]
     if argv and argv[0] == "--no-fullsize":
         fullsize, argv = False, argv[1:]
-    extra = [(1, 20, 10, "bf16x3"), (1, 20, 10, "f32"), (1, 5, 5, "bf16")]
+    extra = [(1, 20, 10, "bf16x3"), (1, 20, 10, "f32"), (1, 20, 10, "f16x2"), (1, 5, 5, "bf16")]
     for spec in argv:
         f = spec.split(",")
         extra.append((int(f[2]) if len(f) > 2 else 1, int(f[0]), int(f[1]), f[3] if len(f) > 3 else "bf16x3"))
@@ -69,7 +69,7 @@ def main(argv):
 
     done = set()
     for (B, P, T) in LOOP_CASES:
-        for prec in ("f32", "bf16x3"):
+        for prec in ("f32", "bf16x3", "f16x2"):
             t0 = time.time()
             name, out, ref, target, x2d = loop_case(B, P, T, prec)
             emit(measure(name, out, ref, target, x2d, prec, time.time() - t0))
@@ -92,7 +92,7 @@ def main(argv):
             emit(measure(name, out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, fs["x2d"], "bf16x3", time.time() - t0))
         # the metric's own configuration against the REFERENCE's run of it (golden G19): all 20 hypotheses, every step
         z = load_golden("g19_metric_config.npz")
-        for prec in ("bf16x3", "f32"):
+        for prec in ("bf16x3", "f32", "f16x2"):
             if prec == "bf16x3":
                 out20 = fs["out"][:, :, :20].cpu()
             else:
@@ -101,6 +101,8 @@ def main(argv):
                 noises = [n[:, :20].contiguous() for n in fs["noises"]]
                 model.noise_fn = lambda k, shape, device: noises[k]
                 out20 = model(fs["x2d"].cuda(), None, input_2d_flip=fs["x2f"].cuda()).cpu()
+            if prec == "f16x2":     # and against the oracle on this box, all 20 hypotheses (tests: test_full_size_f16x2_vs_oracle)
+                emit(measure("fullsize_20of20_T10_f16x2", out20, fs["ref"][:, :, :20].contiguous(), target, fs["x2d"], "f16x2"))
             pt, diffs, d, frac, worst = g19_compare(out20, z, fs["x2d"])
             emit({"name": f"g19_P20_T10_{prec}", "B": 1, "P": 20, "T": T_FULL, "precision": prec,
                   "against": "tests/golden/g19_metric_config.npz (the reference's own run of BASELINE configs[2])",

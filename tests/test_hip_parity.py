@@ -45,7 +45,7 @@ BLANKET_TOL_MM = 5e-4
 UNRECORDED_HOST_TOL_MM = 2e-3
 BOUND_FACTOR = 1.25
 BOUND_FLOOR_MM = 2e-5          # below this a measured value says nothing about the next weight seed's rounding
-PARITY_REPORT = "profiles/r03_parity_report.json"
+PARITY_REPORT = "profiles/r04_parity_report.json"
 PROTOCOLS = ("J-Best", "P-Best", "P-Agg", "J-Agg")
 PARITY_LINES = []              # one line per asserted case, printed in the terminal summary (tests/conftest.py)
 
@@ -66,6 +66,10 @@ def parity_bounds(case, ref):
     if e is None:
         pytest.fail(f"{PARITY_REPORT} has no case '{case}': regenerate it with tests/reports/parity_report.py on the GPU box")
     if ref is not None and e["oracle_sha256"] != tensor_sha256(ref):
+        import warnings
+        warnings.warn(f"{case}: the CPU oracle's output on this host is not the recorded one (another BLAS / libm code path): the "
+                      f"per-case MPJPE bounds do not apply; the fp64 criterion (assert_not_further_from_fp64) is asserted instead "
+                      f"where the case is small enough, else only the host-spread bound {UNRECORDED_HOST_TOL_MM} mm")
         return {k: UNRECORDED_HOST_TOL_MM for k in PROTOCOLS}, False
     m = dict(e["mpjpe_mm_abs_diff_max"])
     m["J-Agg"] = e["j_agg_same_picks_mm_abs_diff_max"]
@@ -136,6 +140,8 @@ def test_linear_split(M, N, K, act, layout, scheme):
     layout 0: the 32x32x16-MFMA tiles (mlp.fc1); layout 2: the 16x16x32-MFMA tiles of the qkv layers."""
     from pafuse_amd import ops
     from functools import partial
+    if scheme == "f16x2" and (layout != 0 or not (N % 128 == 0 or N % 224 == 0)):
+        pytest.skip("f16x2: one image geometry, column tiles of 128 or 224")
     ops = type("ops", (), {"linear": staticmethod(ops.linear),
                            "linear_split": staticmethod(partial(ops.linear_split, layout=layout, scheme=scheme))})
     x, w, b = _seeded((M, K), 1), _seeded((N, K), 2, K ** -0.5), _seeded((N,), 3, 0.1)
@@ -179,16 +185,15 @@ def test_linear_split_exact_integers_and_slices(layout, M, N, K):
     assert torch.equal(out, (w[:, km] * 0.5).t())
 
 
-@pytest.mark.parametrize("layout,M,N,K", [(0, 96, 224, 64), (2, 96, 224, 64), (2, 200, 1152, 384), (2, 131, 672, 224),
-                                          (2, 70, 768, 256), (2, 300, 96, 64), (0, 200, 768, 384)])
-def test_linear_f16x2_exact_integers_and_slices(layout, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(96, 224, 64), (200, 1152, 384), (131, 672, 224), (70, 768, 256), (300, 128, 64), (513, 448, 224)])
+def test_linear_f16x2_exact_integers_and_slices(M, N, K):
     """the f16x2 scheme on exact data: small integers (row / col / k-permutation and sub-block rotation slips show exactly);
     22-bit operands that need both activation slices (hi and the 2^11-scaled lo) resp. both weight slices; activations so
     small that hi is an fp16 SUBNORMAL (the matrix cores must not flush them); weights spanning 2^-20 .. 1 inside one tensor
     (one power-of-two scale per tensor: the small ones live in fp16 subnormals of w1 / w2 and still come out exact)."""
     from pafuse_amd import ops
     from functools import partial
-    lin = partial(ops.linear_split, layout=layout, scheme="f16x2")
+    lin = partial(ops.linear_split, scheme="f16x2")
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (M, K), generator=g).float()
     w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
@@ -218,9 +223,9 @@ def test_linear_f16x2_exact_integers_and_slices(layout, M, N, K):
 def test_linear_f16x2_overflow_is_loud():
     """|activation| >= 65504 does not fit the fp16 hi slice: the affected outputs are inf / NaN, never a finite wrong number."""
     from pafuse_amd import ops
-    x = torch.ones(64, 64)
+    x = torch.ones(64, 128)
     x[3, 5] = 1e5
-    w, b = torch.eye(64), torch.zeros(64)
+    w, b = torch.eye(128), torch.zeros(128)
     out = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), scheme="f16x2").cpu()
     assert not torch.isfinite(out[3, 5]) and torch.isfinite(out[:3]).all() and torch.isfinite(out[4:]).all()
 
@@ -338,12 +343,13 @@ def test_g5_flip_loop_golden(g5, precision):
     assert torch.allclose(out, z["flip_out"], rtol=0, atol=1e-5), (out - z["flip_out"]).abs().max()
 
 
-def test_split_images_follow_in_place_weight_updates():
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_split_images_follow_in_place_weight_updates(precision):
     """the pre-split weight images are a cache: an in-place change of a weight (optimizer step, load_state_dict) must
-    remake them - the bf16x3 result after the change equals a freshly built model's, bit for bit."""
+    remake them - the split-precision result after the change equals a freshly built model's, bit for bit."""
     from __graft_entry__ import make_model
     model, _ = make_model(1, 1, seed=51)
-    model.precision = "bf16x3"
+    model.precision = precision
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     n1 = gu.synthetic_noises(B=1, P=1, n=1, seed=2)
     model.noise_fn = lambda k, shape, device: n1[k]
@@ -351,13 +357,14 @@ def test_split_images_follow_in_place_weight_updates():
     other, sd2 = make_model(1, 1, seed=52)
     model.load_state_dict(sd2)                                   # in place: same storages, new values
     after = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
-    other.precision = "bf16x3"
+    other.precision = precision
     other.noise_fn = model.noise_fn
     assert not torch.equal(before, after)
     assert torch.equal(after, other(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)))
 
 
-def test_folded_layernorm_is_the_same_function():
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_folded_layernorm_is_the_same_function(precision):
     """Split-precision default: norm1 / norm2 are applied INSIDE the qkv / fc1 GEMMs (weight image of W (.) g, two vectors
     per layer, row statistics from the producing whole-row kernel; include/pafuse_hip.h pafuse_block_weights.qkv_ls).
     Against the same model with the fold off (the whole-row kernels write the normalised rows): the same function, i.e.
@@ -368,7 +375,7 @@ def test_folded_layernorm_is_the_same_function():
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=3, n=2, seed=4)
     model.noise_fn = lambda k, shape, device: noises[k]
-    assert model.precision == "bf16x3"
+    model.precision = precision
     parts = list(model.denoisers().values())
     assert all(m.fold_layernorm for m in parts)
     folded = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
@@ -393,8 +400,9 @@ def test_folded_layernorm_is_the_same_function():
     assert float((changed - ref2).abs().max()) <= 1e-5, float((changed - ref2).abs().max())
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("fold", [True, False])
-def test_fused_qkv_attention_kernel_is_the_same_function(fold):
+def test_fused_qkv_attention_kernel_is_the_same_function(fold, precision):
     """The opt-in fused kernel (fqa_kernel: qkv projection + attention of one head per workgroup, q / k / v never written;
     MixSTE2.fuse_qkv_attention) against the default two kernels, with and without the folded LayerNorm: same products
     (six bf16 MFMA terms per pair), same attention arithmetic - rounding-level differences (the K sum rounds per 32 k in
@@ -402,13 +410,14 @@ def test_fused_qkv_attention_kernel_is_the_same_function(fold):
     blocks (68 tokens) have no fused form and keep the two kernels - B = 2 and P = 3 give ragged last tiles."""
     from __graft_entry__ import make_model
     model, sd = make_model(3, 2, seed=57)
+    model.precision = precision
     x2d, x2f = gu.synthetic_inputs_2d(B=2)
     noises = gu.synthetic_noises(B=2, P=3, n=2, seed=6)
     model.noise_fn = lambda k, shape, device: noises[k]
     parts = list(model.denoisers().values())
     for m in parts:
         m.fold_layernorm = fold
-    assert not any(m.fuse_qkv_attention for m in parts)
+        m.fuse_qkv_attention = False
     two = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     import ctypes
     from pafuse_amd import _lib
@@ -481,9 +490,13 @@ def _j_agg_compare(out, ref, target, x2d):
     return d, flipped.double().mean().item(), worst
 
 
-def _assert_mpjpe_parity(out, ref, target, x2d, case):
+def _assert_mpjpe_parity(out, ref, target, x2d, case, truth_fn=None):
+    """truth_fn: () -> the fp64 evaluation of the same loop; asserted INSTEAD of the recorded per-case bounds when the oracle's
+    arithmetic on this host is not the recorded one (the reference-independent criterion, assert_not_further_from_fp64)."""
     got, want = _mpjpe_report(out, target, x2d), _mpjpe_report(ref, target, x2d)
     bounds, per_case = parity_bounds(case, ref)
+    if not per_case and truth_fn is not None:
+        assert_not_further_from_fp64(case, out, ref, truth_fn(), target, x2d)
     diffs = {k: (got[k] - want[k]).abs() for k in ("J-Best", "P-Best", "P-Agg")}
     d, frac, worst = _j_agg_compare(out, ref, target, x2d)
     met = sum(int((v <= 1e-4).sum()) for v in diffs.values())
@@ -519,17 +532,79 @@ LOOP_CASES = [(1, 5, 5), (2, 3, 2)]
 _LOOP_ORACLE = {}
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("B,P,T", LOOP_CASES)
 def test_loop_vs_oracle_mpjpe(B, P, T, precision):
     """BASELINE configs[1] shape (P=5, T=5) and a B>1 case: pointwise and MPJPE parity, for the fp32 matrix cores and
     for the split-precision (bf16x3) products alike, each against its own committed measurement."""
     case, out, ref, target, x2d = loop_case(B, P, T, precision)
     assert torch.allclose(out, ref, rtol=0, atol=1e-5), (out - ref).abs().max()
-    _assert_mpjpe_parity(out, ref, target, x2d, case)
+    _assert_mpjpe_parity(out, ref, target, x2d, case, truth_fn=lambda: loop_truth(B, P, T))
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+FP64_FACTOR = 1.1           # the HIP path may be this much further from exact arithmetic than the reference's own fp32 is
+FP64_FLOOR_MM = 2e-5
+_LOOP_TRUTH = {}
+
+
+def fp64_truth(sd, x2d, x2f, noises, T):
+    """The oracle evaluated in fp64 on the same fp32 weights, inputs and noise: the host-independent yardstick (its own
+    rounding is 1e-16; libm differences between hosts vanish at that level)."""
+    sd64 = {k: v.double() for k, v in sd.items()}
+    return orc.ddim_sample(sd64, x2d.double(), [n.double() for n in noises], T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT,
+                           inputs_2d_flip=x2f.double())
+
+
+def loop_truth(B, P, T):
+    """fp64 evaluation of loop_case(B, P, T)'s loop (cached)"""
+    if (B, P, T) not in _LOOP_TRUTH:
+        from __graft_entry__ import make_model
+        _, sd = make_model(P, T, seed=77, device="cpu")
+        x2d, x2f = gu.synthetic_inputs_2d(B=B, seed=1234)
+        _LOOP_TRUTH[(B, P, T)] = fp64_truth(sd, x2d, x2f, gu.synthetic_noises(B=B, P=P, n=T, seed=3), T)
+    return _LOOP_TRUTH[(B, P, T)]
+
+
+FP64_MAX_FACTOR = 1.5       # ... and on the largest single step (the maximum of T noisy values: a looser guard)
+
+
+def assert_not_further_from_fp64(case, out, ref32, truth, target, x2d):
+    """The reference-independent tolerance: through the whole DDIM loop, on every protocol, the HIP
+    path is at most FP64_FACTOR x as far from the exact (fp64) evaluation as the reference's fp32 arithmetic (the oracle) is,
+    + a 2e-5 mm floor.  Asserted on the MEAN over the steps of |MPJPE - MPJPE_fp64| per protocol and on the pointwise mean
+    distance of the predictions; a single step's deviation of either run is one draw of rounding noise (it can be near zero
+    by chance, and the larger of ten draws of two equally accurate runs differs by tens of percent), so the per-step maximum
+    is held to the looser FP64_MAX_FACTOR.  Every protocol's columns go to the terminal summary next to the north star's 1e-4 mm."""
+    got, o32, t64 = (_mpjpe_report(v, target, x2d) for v in (out, ref32, truth.float()))
+    lines = []
+    for k in ("J-Best", "P-Best", "P-Agg"):
+        dh, do = (got[k] - t64[k]).abs(), (o32[k] - t64[k]).abs()
+        lines.append(f"{k} hip mean {float(dh.mean()):.2e} max {float(dh.max()):.2e} / oracle32 mean {float(do.mean()):.2e} max {float(do.max()):.2e}")
+        assert float(dh.mean()) <= FP64_FACTOR * float(do.mean()) + FP64_FLOOR_MM, (case, k, dh.tolist(), do.tolist())
+        assert float(dh.max()) <= FP64_MAX_FACTOR * float(do.max()) + FP64_FLOOR_MM, (case, k, dh.tolist(), do.tolist())
+    dj_h, fr_h, _ = _j_agg_compare(out, truth.float(), target, x2d)
+    dj_o, fr_o, _ = _j_agg_compare(ref32, truth.float(), target, x2d)
+    lines.append(f"J-Agg (same picks, max) hip {dj_h:.2e} / oracle32 {dj_o:.2e}")
+    assert dj_h <= FP64_MAX_FACTOR * dj_o + FP64_FLOOR_MM and fr_h <= max(2e-3, 2 * fr_o), (case, dj_h, dj_o, fr_h, fr_o)
+    pw_h, pw_o = (out.double() - truth).abs().mean().item(), (ref32.double() - truth).abs().mean().item()
+    # (the 'f32' mode's k-ordered FMA chain - what v_mfma_f32_32x32x2_f32 computes - accumulates more rounding than the
+    # blocked sums of the reference's CPU BLAS: measured 1.16 x pointwise; the split-precision modes, one rounding per 16 / 32
+    # k, are CLOSER to exact arithmetic than the reference and are held to FP64_FACTOR)
+    assert pw_h <= (1.25 if case.endswith("_f32") else FP64_FACTOR) * pw_o, (case, pw_h, pw_o)
+    PARITY_LINES.append(f"{case} vs fp64 truth, |MPJPE - MPJPE_fp64| mm over the steps: " + "; ".join(lines) +
+                        f"; pointwise mean |d| m: hip {pw_h:.2e} / oracle32 {pw_o:.2e}")
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
+def test_loop_vs_fp64_truth(precision):
+    """BASELINE configs[1]'s shape (P=5, T=5, flip-TTA) through all five steps against an fp64 evaluation of the same
+    loop: the tolerance that does not depend on which host ran the fp32 reference (profiles/r03_host_variation.json)."""
+    B, P, T = 1, 5, 5
+    case, out, ref32, target, x2d = loop_case(B, P, T, precision)
+    assert_not_further_from_fp64(case, out, ref32, loop_truth(B, P, T), target, x2d)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_accuracy_equivalent_to_reference_fp32(precision):
     """Against an fp64 evaluation of the same function (same fp32 weights and inputs), the HIP denoiser is at most
     1.5x as far as the reference's fp32 CPU arithmetic (the oracle, bit-identical to the reference here) - in both
@@ -768,9 +843,9 @@ def test_torch_custom_ops_equal_the_modules():
     i2d, i2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=3, n=2, seed=12)
     model.noise_fn = lambda k, shape, device: noises[k]
-    assert model.precision == "bf16x3"          # the ops' default precision is the modules' inference default
+    assert model.precision == "f16x2"           # the model-level ops' default precision is the modules' inference default
     assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads), body(x2d, x3d, t))
-    for precision in ("bf16x3", "f32"):         # the default split-precision path and the fp32 matrix cores
+    for precision in ("f16x2", "bf16x3", "f32"):   # both split-precision schemes and the fp32 matrix cores
         model.precision = precision
         assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads, precision),
                            body(x2d, x3d, t)), precision

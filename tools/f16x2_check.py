@@ -28,45 +28,45 @@ def seeded(shape, seed, scale=1.0):
 
 
 g = torch.Generator().manual_seed(5)
-for layout in (0, 2):
-    M, N, K = 131, 672 if layout == 2 else 224, 224 if layout == 2 else 64
-    x = torch.randint(-3, 4, (M, K), generator=g).float()
-    w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
-    b = torch.arange(N).float()
-    out = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), layout=layout, scheme="f16x2").cpu()
-    emit(test="small integers", layout=layout, exact=bool(torch.equal(out, x @ w.t() + b)), maxdiff=float((out - (x @ w.t() + b)).abs().max()))
-    # 22-bit activations against one-hot powers of two: hi and lo both in play
-    x = torch.randint(2 ** 21, 2 ** 22, (M, K), generator=g).float() * (torch.randint(0, 2, (M, K), generator=g) * 2 - 1) * 2.0 ** -8   # |x| < 65504
-    kn = torch.randint(0, K, (N,), generator=g)
-    w = torch.zeros(N, K)
-    w[torch.arange(N), kn] = 2.0 ** torch.randint(-3, 4, (N,), generator=g).float()
-    out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
-    ref = x[:, kn] * w[torch.arange(N), kn]
-    emit(test="22-bit activations", layout=layout, exact=bool(torch.equal(out, ref)), max_rel=float(((out - ref) / ref).abs().max()))
-    # 22-bit weights against one-hot 0.5 activations
-    w = torch.randint(2 ** 21, 2 ** 22, (N, K), generator=g).float()
-    x = torch.zeros(M, K)
-    km = torch.randint(0, K, (M,), generator=g)
-    x[torch.arange(M), km] = 0.5
-    out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
-    ref = (w[:, km] * 0.5).t()
-    emit(test="22-bit weights", layout=layout, exact=bool(torch.equal(out, ref)), max_rel=float(((out - ref) / ref).abs().max()))
-    # tiny activations (fp16 subnormal hi): x = j * 2^-24 .. and 2^-20 scale, weights one-hot 1.0
-    x = torch.randint(1, 2 ** 10, (M, K), generator=g).float() * 2.0 ** -26
-    w = torch.zeros(N, K)
-    w[torch.arange(N), kn] = 1.0
-    out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
-    ref = x[:, kn]
-    emit(test="tiny activations (hi subnormal in fp16)", layout=layout, exact=bool(torch.equal(out, ref)),
-         max_rel=float(((out - ref) / ref).abs().max()))
-    # wide dynamic range inside one weight tensor: small weights next to a large one
-    w = torch.zeros(N, K)
-    w[torch.arange(N), kn] = 2.0 ** torch.randint(-20, 1, (N,), generator=g).float()
-    x = torch.randint(2 ** 21, 2 ** 22, (M, K), generator=g).float() * 2.0 ** -22
-    out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
-    ref = x[:, kn] * w[torch.arange(N), kn]
-    emit(test="weights spanning 2^-20..1 in one tensor", layout=layout, exact=bool(torch.equal(out, ref)),
-         max_rel=float(((out - ref) / ref).abs().max()))
+for layout in (0,):
+  for (M, N, K) in ((131, 672, 224), (96, 224, 64), (300, 1152, 384), (513, 128, 32)):
+      x = torch.randint(-3, 4, (M, K), generator=g).float()
+      w = torch.randint(-3, 4, (N, K), generator=g).float() + torch.arange(N)[:, None].float() % 5
+      b = torch.arange(N).float()
+      out = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), layout=layout, scheme="f16x2").cpu()
+      emit(test="small integers", layout=layout, exact=bool(torch.equal(out, x @ w.t() + b)), maxdiff=float((out - (x @ w.t() + b)).abs().max()))
+      # 22-bit activations against one-hot powers of two: hi and lo both in play
+      x = torch.randint(2 ** 21, 2 ** 22, (M, K), generator=g).float() * (torch.randint(0, 2, (M, K), generator=g) * 2 - 1) * 2.0 ** -8   # |x| < 65504
+      kn = torch.randint(0, K, (N,), generator=g)
+      w = torch.zeros(N, K)
+      w[torch.arange(N), kn] = 2.0 ** torch.randint(-3, 4, (N,), generator=g).float()
+      out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
+      ref = x[:, kn] * w[torch.arange(N), kn]
+      emit(test="22-bit activations", layout=layout, exact=bool(torch.equal(out, ref)), max_rel=float(((out - ref) / ref).abs().max()))
+      # 22-bit weights against one-hot 0.5 activations
+      w = torch.randint(2 ** 21, 2 ** 22, (N, K), generator=g).float()
+      x = torch.zeros(M, K)
+      km = torch.randint(0, K, (M,), generator=g)
+      x[torch.arange(M), km] = 0.5
+      out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
+      ref = (w[:, km] * 0.5).t()
+      emit(test="22-bit weights", layout=layout, exact=bool(torch.equal(out, ref)), max_rel=float(((out - ref) / ref).abs().max()))
+      # tiny activations (fp16 subnormal hi): x = j * 2^-24 .. and 2^-20 scale, weights one-hot 1.0
+      x = torch.randint(1, 2 ** 10, (M, K), generator=g).float() * 2.0 ** -26
+      w = torch.zeros(N, K)
+      w[torch.arange(N), kn] = 1.0
+      out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
+      ref = x[:, kn]
+      emit(test="tiny activations (hi subnormal in fp16)", layout=layout, exact=bool(torch.equal(out, ref)),
+           max_rel=float(((out - ref) / ref).abs().max()))
+      # wide dynamic range inside one weight tensor: small weights next to a large one
+      w = torch.zeros(N, K)
+      w[torch.arange(N), kn] = 2.0 ** torch.randint(-20, 1, (N,), generator=g).float()
+      x = torch.randint(2 ** 21, 2 ** 22, (M, K), generator=g).float() * 2.0 ** -22
+      out = ops.linear_split(x.to(DEV), w.to(DEV), torch.zeros(N, device=DEV), layout=layout, scheme="f16x2").cpu()
+      ref = x[:, kn] * w[torch.arange(N), kn]
+      emit(test="weights spanning 2^-20..1 in one tensor", layout=layout, exact=bool(torch.equal(out, ref)),
+           max_rel=float(((out - ref) / ref).abs().max()))
 
 # error against fp64, per scheme
 for (M, N, K) in [(200, 1152, 384), (300, 672, 224), (77, 384, 768), (64, 768, 256), (129, 448, 224)]:
@@ -75,9 +75,12 @@ for (M, N, K) in [(200, 1152, 384), (300, 672, 224), (77, 384, 768), (64, 768, 2
     row = {"test": "fp64 error", "shape": [M, N, K], "bound": 2.5e-7 * K ** 0.5 + 1e-6}
     row["fma32"] = float((ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu().double() - ref).abs().mean())
     for scheme in ("bf16x3", "f16x2"):
-        for layout in (0, 2):
+        for layout in ((0, 2) if scheme == "bf16x3" else (0,)):
             o = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), layout=layout, scheme=scheme).cpu().double()
             row[f"{scheme}/{layout}"] = {"mean": float((o - ref).abs().mean()), "max": float((o - ref).abs().max())}
+    if scheme == "f16x2":
+        og = ops.linear_split(x.to(DEV), w.to(DEV), b.to(DEV), act="gelu", scheme=scheme).cpu().double()
+        row["f16x2 gelu max"] = float((og - torch.nn.functional.gelu(ref)).abs().max())
     emit(**row)
 
 # G4 block goldens through pafuse_block_forward (whole-row kernels + attention)

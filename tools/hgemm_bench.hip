@@ -1,0 +1,152 @@
+// hgemm_bench.hip - the f16x2 H-pipeline tiles (pafuse_amd/csrc/hgemm.hpp) at the hot path's layer shapes, several tile
+// configurations per shape in one process: us per launch (HIP events), TFLOP/s of fp32-equivalent work, and the per-wave
+// lifetime split by in-kernel stamps (prologue = until the first chunk is visible, K loop, epilogue), in shader cycles.
+//   hipcc <library flags> -DPAFUSE_STAMPS tools/hgemm_bench.hip -o tools/bin/hgemm_bench ;  HB_FILTER=<substring> ./hgemm_bench
+#define PAFUSE_STAMPS 1
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../pafuse_amd/csrc/hgemm.hpp"
+using namespace pafuse;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+static const char* g_filter = nullptr;
+static int g_reps = 20;
+
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW>
+void run(const char* shape, GemmParams p) {
+    using T = HTile<WM, WN, NT, BKC>;
+    char tag[160];
+    snprintf(tag, sizeof tag, "%s <%d,%d,%d> %dx%d st%d bkc%d minw%d", shape, WM, WN, NT, T::BM, T::BN, NSTAGE, BKC, MINW);
+    if (g_filter && !strstr(tag, g_filter)) return;
+    if (p.N % T::BN) { printf("%s: N %% BN != 0, skipped\n", tag); return; }
+    const size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    auto k = hgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    const size_t nw = tiles * (T::NTHR / 64);
+    unsigned long long* st; CK(hipMalloc(&st, nw * 32)); CK(hipMemset(st, 0, nw * 32));
+    p.stamps = st;
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T::NTHR, lds));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < g_reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(nw * 4);
+    CK(hipMemcpy(h.data(), st, nw * 32, hipMemcpyDeviceToHost));
+    double pro = 0, loop = 0, epi = 0; size_t n = 0;
+    for (size_t w = 0; w < nw; ++w) {
+        if (!h[w * 4] || !h[w * 4 + 2]) continue;
+        pro += h[w * 4 + 3] - h[w * 4]; loop += h[w * 4 + 1] - h[w * 4 + 3]; epi += h[w * 4 + 2] - h[w * 4 + 1]; ++n;
+    }
+    const double us = ms * 1e3 / g_reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    const double mfma = (double)(p.K / 16) * 3 * NT * 32;   // this wave's own MFMA issue cycles
+    printf("%-58s tiles %5ld (%.2f rounds at %d/CU) %7.2f us %6.1f TF (%.3f of 833) | per wave: prologue %5.0f  K loop %6.0f (MFMA %5.0f)  epilogue %6.0f\n",
+           tag, (long)tiles, (double)tiles / (256.0 * occ), occ, us, tf, tf / 833.3, n ? pro / n : 0, n ? loop / n : 0, mfma, n ? epi / n : 0);
+    fflush(stdout);
+    CK(hipFree(st));
+}
+
+int main() {
+    g_filter = getenv("HB_FILTER");
+    if (getenv("HB_REPS")) g_reps = atoi(getenv("HB_REPS"));
+    const int64_t Mmax = 73440;
+    float *X, *W, *vec, *out, *x, *stats;
+    uint8_t *Ah, *Wh, *outh, *xh;
+    CK(hipMalloc(&X, Mmax * 768 * 4)); CK(hipMalloc(&W, 1152 * 768 * 4)); CK(hipMalloc(&vec, 4096 * 4));
+    CK(hipMalloc(&out, Mmax * 1152 * 4)); CK(hipMalloc(&x, Mmax * 384 * 4)); CK(hipMalloc(&stats, Mmax * 8));
+    CK(hipMalloc(&Ah, Mmax * 768 * 4)); CK(hipMalloc(&Wh, 1152 * 768 * 4 + 256)); CK(hipMalloc(&outh, Mmax * 1152 * 4)); CK(hipMalloc(&xh, Mmax * 384 * 4));
+    std::vector<float> h(Mmax * 768);
+    for (auto& v : h) v = (float)(rand() % 2001 - 1000) * 1e-3f;
+    CK(hipMemcpy(X, h.data(), Mmax * 768 * 4, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < 1152 * 768; ++i) h[i] *= 0.05f;
+    CK(hipMemcpy(W, h.data(), 1152 * 768 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(vec, h.data() + 999, 4096 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(x, h.data() + 5, Mmax * 384 * 4, hipMemcpyHostToDevice));
+    std::vector<float> sth(Mmax * 2);
+    for (int64_t i = 0; i < Mmax; ++i) sth[2 * i] = 0.01f, sth[2 * i + 1] = 1.3f;
+    CK(hipMemcpy(stats, sth.data(), Mmax * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(hsplit_rows_kernel, dim3((unsigned)((Mmax * 96 + 255) / 256)), dim3(256), 0, 0, X, Ah, Mmax, 768);   // (row stride 4 K: re-made per K below)
+
+    struct Part { const char* name; int64_t M; int C; };
+    const Part parts[3] = {{"body", 25920, 384}, {"face", 73440, 224}, {"hands", 45360, 256}};
+    for (const Part& pt : parts) {
+        const int C = pt.C;
+        auto images = [&](int N, int K) {   // A [M,K] and W [N,K] as H images
+            hipLaunchKernelGGL(hsplit_rows_kernel, dim3((unsigned)((pt.M * (K / 8) + 255) / 256)), dim3(256), 0, 0, X, Ah, pt.M, K);
+            CK(hipMemset(Wh + (size_t)N * K * 4, 0, 256));
+            hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, 0, W, (int64_t)N * K, reinterpret_cast<uint32_t*>(Wh + (size_t)N * K * 4) + 1);
+            hipLaunchKernelGGL(hsplit_weights_kernel, dim3((unsigned)(((int64_t)N * (K / 8) + 255) / 256)), dim3(256), 0, 0, W, Wh, N, K);
+        };
+        char shape[64];
+        // ---- plain layers
+        for (int layer = 0; layer < 2; ++layer) {
+            const int N = layer == 0 ? 3 * C : 2 * C;
+            images(N, C);
+            GemmParams p{};
+            p.Ah = Ah, p.Wh = Wh, p.bias = vec, p.ln_in = stats, p.ln_s = vec + 1500, p.M = pt.M, p.N = N, p.K = C, p.bf16 = 3;
+            if (layer == 0) p.out = out; else p.out_h = outh, p.act = 1;
+            snprintf(shape, sizeof shape, "%s %s", pt.name, layer == 0 ? "qkv" : "fc1");
+            if (C != 224) {
+                run<8, 1, 4, EPI_BIAS, 3, 32, 1>(shape, p);
+                run<8, 1, 4, EPI_BIAS, 2, 32, 1>(shape, p);
+                run<4, 1, 4, EPI_BIAS, 2, 32, 2>(shape, p);
+                run<4, 1, 4, EPI_BIAS, 3, 16, 2>(shape, p);
+                run<4, 1, 4, EPI_BIAS, 2, 16, 3>(shape, p);
+                run<4, 2, 2, EPI_BIAS, 2, 32, 1>(shape, p);
+                run<4, 2, 2, EPI_BIAS, 3, 16, 2>(shape, p);
+                run<8, 1, 2, EPI_BIAS, 2, 32, 2>(shape, p);
+            } else {
+                run<8, 1, 7, EPI_BIAS, 2, 32, 1>(shape, p);
+                run<4, 1, 7, EPI_BIAS, 2, 32, 1>(shape, p);
+                run<4, 1, 7, EPI_BIAS, 3, 16, 2>(shape, p);
+                run<4, 1, 7, EPI_BIAS, 2, 16, 2>(shape, p);
+                run<8, 1, 7, EPI_BIAS, 3, 16, 1>(shape, p);
+            }
+        }
+        // ---- whole-row layers
+        for (int layer = 0; layer < 2; ++layer) {
+            const int K = layer == 0 ? C : 2 * C;
+            images(C, K);
+            GemmParams q{};
+            q.Ah = Ah, q.Wh = Wh, q.bias = vec, q.resid = x, q.out_x = x, q.out_xh = xh, q.ln_stats = stats;
+            q.post_w = layer ? vec + 400 : nullptr, q.post_b = vec + 800, q.post_eps = 1e-6f, q.next_w = vec + 1200, q.next_b = vec + 1600, q.next_eps = 1e-6f;
+            q.M = pt.M, q.N = C, q.K = K, q.bf16 = 3;
+            snprintf(shape, sizeof shape, "%s %s", pt.name, layer == 0 ? "proj" : "fc2");
+            if (C == 384 && getenv("HB_ABLATE")) {   // where the whole-row epilogue's cycles go (results wrong by design)
+                char sh2[96];
+                { GemmParams a = q; a.out_xh = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no H image", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
+                { GemmParams a = q; a.out_xh = nullptr; a.out_x = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no stores", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
+                { GemmParams a = q; a.out_xh = nullptr; a.out_x = nullptr; a.next_w = nullptr; a.post_w = nullptr; snprintf(sh2, sizeof sh2, "%s ABL resid only", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
+                { GemmParams a = q; a.next_w = nullptr; a.post_w = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no LN / stats", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
+            }
+            if (C == 384) {
+                run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(shape, q);
+                run<4, 2, 6, EPI_ROWLN, 3, 16, 1>(shape, q);
+                run<2, 2, 6, EPI_ROWLN, 2, 16, 2>(shape, q);
+                run<2, 2, 6, EPI_ROWLN, 2, 32, 1>(shape, q);
+                run<3, 2, 6, EPI_ROWLN, 2, 16, 1>(shape, q);
+            } else if (C == 256) {
+                run<4, 2, 4, EPI_ROWLN, 3, 32, 1>(shape, q);
+                run<4, 2, 4, EPI_ROWLN, 2, 16, 2>(shape, q);
+                run<2, 2, 4, EPI_ROWLN, 2, 16, 2>(shape, q);
+                run<2, 2, 4, EPI_ROWLN, 3, 16, 3>(shape, q);
+                run<2, 2, 4, EPI_ROWLN, 2, 32, 2>(shape, q);
+            } else {
+                run<4, 1, 7, EPI_ROWLN, 3, 16, 2>(shape, q);
+                run<4, 1, 7, EPI_ROWLN, 2, 16, 2>(shape, q);
+                run<2, 1, 7, EPI_ROWLN, 2, 16, 2>(shape, q);
+                run<2, 1, 7, EPI_ROWLN, 3, 16, 3>(shape, q);
+                run<4, 1, 7, EPI_ROWLN, 2, 32, 1>(shape, q);
+            }
+        }
+    }
+    return 0;
+}
