@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--fuse-qkv-attention", choices=("auto", "on", "off"), default="auto",
                     help="A/B: the fused qkv + attention kernel (pafuse_amd.MixSTE2.fuse_qkv_attention) where it exists; auto = "
                          "the modules' default: on in f16x2, off in bf16x3")
+    ap.add_argument("--f32-residual", action="store_true",
+                    help="A/B (f16x2): keep the residual stream between the blocks as fp32 rows beside its H image "
+                         "(pafuse_amd.MixSTE2.keep_f32_residual)")
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
@@ -125,6 +128,7 @@ def main():
         if args.no_ln_fold:
             m.fold_layernorm = False
         m.fuse_qkv_attention = {"auto": None, "on": True, "off": False}[args.fuse_qkv_attention]
+        m.keep_f32_residual = bool(args.f32_residual)
     sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)
     x2d, x2f = x2d.to(dev), x2f.to(dev)
@@ -210,6 +214,8 @@ def main():
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
         "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype in SPLIT_DTYPES and not args.no_ln_fold),
+        "residual_stream_in_memory": ("H image only (two fp16 slices, 22-23 significant bits)" if args.dtype == "f16x2" and not args.no_ln_fold
+                                      and not args.f32_residual else "fp32"),
         "qkv_attention_fused_blocks": {name: _lib.check(_lib.load().pafuse_mixste2_fused_blocks(C.byref(m.weights_struct())))
                                        for name, m in model.denoisers().items()} if args.dtype in SPLIT_DTYPES else None,
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],

@@ -30,7 +30,7 @@ class BlockWeights(C.Structure):
 
 class MixSTE2Weights(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("frames", "joints", "channels", "depth", "heads", "in_chans",
-                                         "operand_bf16", "mlp_hidden")] + [("qk_scale", C.c_float)] +
+                                         "operand_bf16", "mlp_hidden")] + [("qk_scale", C.c_float), ("keep_f32_residual", C.c_int32)] +
                 [(n, C.c_void_p) for n in ("patch_w", "patch_b", "pos_spatial", "pos_temporal",
                                            "tm1_w", "tm1_b", "tm3_w", "tm3_b", "freqs",
                                            "snorm_w", "snorm_b", "tnorm_w", "tnorm_b",

@@ -135,6 +135,9 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
     constexpr int LD = 32 * 8 * NTH / 64;        // float4 per lane per (full) pass
     constexpr int NBUF = NT * 16 + 8 * LD <= 160 ? 2 : 1;   // the next pass in flight only where the registers allow it
     f32x4 rin[NBUF][LD];
+    // (the residual is either fp32 rows or - p.resid_h - the H image of x: the same 4 bytes per element, so the same
+    // row-segment loads; what differs is how a lane picks its four values out of the slab)
+    const float* const resid_rows = p.resid_h ? reinterpret_cast<const float*>(p.resid_h) : p.resid;
     auto load_resid = [&](int ps, f32x4 (&dst)[LD]) {
         const int nth = pass_cols(ps), qpr = 8 * nth;
         const int ncol0 = n0 + (wn * NT + ps * NTH) * 32;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
         for (int it = 0; it < LD; ++it) {
             const int idx = it * 64 + lane, row = idx / qpr, c4 = idx % qpr;
             const int64_t mr = mw + row < p.M ? mw + row : p.M - 1;
-            if (idx < 32 * qpr) dst[it] = *reinterpret_cast<const f32x4*>(p.resid + mr * p.N + ncol0 + 4 * c4);
+            if (idx < 32 * qpr) dst[it] = *reinterpret_cast<const f32x4*>(resid_rows + mr * p.N + ncol0 + 4 * c4);
         }
     };
     load_resid(0, rin[0]);
@@ -164,7 +167,16 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                 for (int q = 0; q < 4; ++q) {
                     const int nt = ps * NTH + j;
                     const f32x4 b4 = vec4(0, nb + 32 * nt + 8 * q);
-                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(slab + r * ST + 32 * j + 8 * q + 4 * h);
+                    f32x4 r4;
+                    if (p.resid_h) {   // sub-block (32 j + 8 q) / 8 of the slab row: hi at + 0, lo at + 16 bytes; this lane's half 4 h
+                        const uint8_t* sbk = reinterpret_cast<const uint8_t*>(slab + r * ST + 32 * j + 8 * q);
+                        typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+                        const f16x4_t hi = *reinterpret_cast<const f16x4_t*>(sbk + 8 * h), lo = *reinterpret_cast<const f16x4_t*>(sbk + 16 + 8 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r4[e] = fmaf((float)lo[e], 0.00048828125f, (float)hi[e]);   // hi + 2^-11 lo: exact
+                    } else {
+                        r4 = *reinterpret_cast<const f32x4*>(slab + r * ST + 32 * j + 8 * q + 4 * h);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] = fmaf(acc[nt][4 * q + e], ws, b4[e]) + r4[e];
                 }
@@ -223,7 +235,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
             __builtin_amdgcn_wave_barrier();
         }
     };
-    if (p.out_x) store_rows(p.out_x, p.out_xh);
+    if (p.out_x || p.out_xh) store_rows(p.out_x, p.out_xh);
     if (p.next_w && p.ln_stats) {
         // the next LayerNorm is folded into the GEMM that consumes it: the row's statistics only
         float s = 0.f;

@@ -283,6 +283,8 @@ struct GemmParams {
     uint8_t* out_h;      // EPI_BIAS: the output as an H image [M,N] instead of fp32 `out` (its consumer is another hgemm)
     uint8_t* out_xh;     // EPI_ROWLN: the H image of out_x, written beside it (A operand of the next qkv / fc1, LayerNorm folded)
     uint8_t* out_nh;     // EPI_ROWLN: the H image of the next LayerNorm's output instead of fp32 out_n (LayerNorm not folded)
+    const uint8_t* resid_h;  // EPI_ROWLN: the residual as the H image of x (then `resid` is unused): with the LayerNorm folded the
+    //                          residual stream lives in memory in this form ONLY (hi + 2^-11 lo, 22-23 significant bits; out_x null)
     const float* rowscale;  // [nseq] DropPath factor of the row's sequence, or null (= 1)
     int rs_temporal, rs_J, rs_FJ;  // seq(m) = rs_temporal ? (m / rs_FJ) * rs_J + m % rs_J : m / rs_J
     float* out_pre;
@@ -2052,7 +2054,7 @@ struct EmbedParams {
     const float *pw, *pb, *pos, *temb;  // [C,5], [C], [J,C], [B,C]
     const float *n_w, *n_b;             // next LayerNorm
     float n_eps;
-    float *x, *xn;  // [M,C]
+    float *x, *xn;  // [M,C]  (x may be null when only the H image of x is wanted)
     uint8_t* xh;    // f16x2 H pipeline: the H image [M,C] the first qkv hgemm reads - of x when `stats` is set (LayerNorm
     //                 folded), else of the normalised row (then xn is not written)
     float* stats;   // folded LayerNorm (GemmParams::ln_in of the first qkv GEMM): (mean, rstd) of row row0 + i at stats[2 i]
@@ -2120,7 +2122,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
                 v[i][e] = a;
                 s += a;
             }
-            if (live) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
+            if (live && p.x) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
             if (live && p.xh && p.stats) hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), v[i]);
         }
     }

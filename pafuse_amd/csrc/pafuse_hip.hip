@@ -504,6 +504,8 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
 }
 
 static bool ln_folded(const pafuse_mixste2_weights* w) { return w->ste[0].qkv_ls != nullptr; }
+// f16x2 with the LayerNorm folded: the residual stream between the blocks lives in memory as its H image only
+static bool h_residual_only(const pafuse_mixste2_weights* w) { return w->operand_bf16 == 3 && ln_folded(w) && !w->keep_f32_residual; }
 
 // `training`: the training entry points make the images of the weights they multiply themselves (weights change every step)
 int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
@@ -569,7 +571,7 @@ struct BlockLaunch {
 
 BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
                        int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, const BlockTail& tail,
-                       int bf16, int hidden = 0, float qk_scale = 0.f, bool fold = false) {
+                       int bf16, int hidden = 0, float qk_scale = 0.f, bool fold = false, bool keep_f32_residual = false) {
     if (hidden <= 0) hidden = 2 * C;  // mlp_ratio = 2, the PAFUSE configuration
     BlockLaunch b{};
     // fold: the LayerNorm in front of qkv / fc1 is applied inside those GEMMs (GemmParams::ln_in); the producer of a row
@@ -579,6 +581,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     // `wide` are written in that form by their producers (hgemm.hpp); the *_ws pointers are the weights' H images
     const bool hp = bf16 == 3;
     uint8_t* const xn_h = reinterpret_cast<uint8_t*>(pb.xn);
+    const bool h_residual = hp && fold && !keep_f32_residual;
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
     GemmParams& g = b.qkv;
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
@@ -614,7 +617,10 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     if (fold) pj.out_n = nullptr, pj.ln_stats = stats;
     if (hp) {
         pj.Ah = reinterpret_cast<const uint8_t*>(pb.o), pj.Wh = (const uint8_t*)bw.proj_ws;
-        if (fold) pj.out_xh = xn_h;
+        // folded: the residual stream lives in memory as the H image of x ONLY - read as the residual, written back in place
+        // (a workgroup owns its rows), and it IS the next GEMM's operand; no fp32 x is read or written inside the denoiser
+        if (fold && h_residual) pj.out_xh = xn_h, pj.resid_h = xn_h, pj.resid = nullptr, pj.out_x = nullptr;
+        else if (fold) pj.out_xh = xn_h;
         else pj.out_n = nullptr, pj.out_nh = xn_h;
     }
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
@@ -638,6 +644,10 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
         f2.Ah = reinterpret_cast<const uint8_t*>(pb.wide), f2.Wh = (const uint8_t*)bw.fc2_ws;
         if (f2.ln_stats) f2.out_xh = xn_h;                       // folded: the next block's qkv reads the H image of x
         else if (f2.out_n) f2.out_n = nullptr, f2.out_nh = xn_h;  // not folded: the H image of the next LayerNorm's output
+        if (fold && h_residual) {
+            f2.resid_h = xn_h, f2.resid = nullptr;
+            if (f2.out_xh) f2.out_x = nullptr;                    // (the head's block writes neither)
+        }
     }
     return b;
 }
@@ -746,7 +756,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
             if (i == 0) t.pos = w->pos_temporal, t.posJ = J, t.posF = F;
             t.next_w = w->tte[i].norm1_w, t.next_b = w->tte[i].norm1_b, t.next_eps = 1e-6f;
             bl[k] = make_block(w->ste[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * F, J, 1, J, 0, 1, t, w->operand_bf16,
-                               w->mlp_hidden, w->qk_scale, ln_folded(w));
+                               w->mlp_hidden, w->qk_scale, ln_folded(w), w->keep_f32_residual != 0);
         }
         if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask, shared_grids))) return rc;
         for (int k = 0; k < n; ++k) {
@@ -763,7 +773,7 @@ int run_mixste_layers_n(const pafuse_mixste2_weights* const* ws, const PartBuffe
                 t.head_w = w->head_w, t.head_b = w->head_b, t.out_head = pbs[k].pred;
             }
             bl[k] = make_block(w->tte[i], pbs[k], Rs[k] * F * J, C, w->heads, Rs[k] * J, F, J, (int64_t)F * J, 1, J, t,
-                               w->operand_bf16, w->mlp_hidden, w->qk_scale, ln_folded(w));
+                               w->operand_bf16, w->mlp_hidden, w->qk_scale, ln_folded(w), w->keep_f32_residual != 0);
         }
         if ((rc = run_blocks(bl, n, s, gemms_only, flops, launches, layer_mask, shared_grids))) return rc;
     }
@@ -1003,6 +1013,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
     e.x = pb.x, e.xn = pb.xn, e.stats = ln_folded(w) ? pb.stats : nullptr;
     e.xh = w->operand_bf16 == 3 ? reinterpret_cast<uint8_t*>(pb.xn) : nullptr;
+    if (h_residual_only(w)) e.x = nullptr;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((M + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)), dim3(256), 0, s, e);
@@ -1161,6 +1172,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.x = pb[i].x, e.xn = pb[i].xn;
             e.stats = ln_folded(w) ? pb[i].stats + row0 * 2 : nullptr;   // where offset_rows puts this group's statistics
             e.xh = w->operand_bf16 == 3 ? reinterpret_cast<uint8_t*>(pb[i].xn) : nullptr;   // (indexed by the absolute row)
+            if (h_residual_only(w)) e.x = nullptr;
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
             e.do_clamp = 1, e.scale = (float)cfg->scale, e.lim = (float)(1.1 * cfg->scale), e.row0 = row0, e.nrows = nrows;
             hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((nrows + EMBED_ROWS_PER_BLOCK - 1) / EMBED_ROWS_PER_BLOCK)),

@@ -115,6 +115,10 @@ class MixSTE2(nn.Module):
         #                                sequence length has a fused form (include/pafuse_hip.h pafuse_block_weights.qkv_hs): q, k, v
         #                                never reach memory.  None = on in 'f16x2' (that pipeline is bound by the bytes it moves:
         #                                +7 % on the loop), off in 'bf16x3' (matrix-bound: equal in time)
+        self.keep_f32_residual = False  # 'f16x2' with the LayerNorm folded: False keeps the residual stream between the blocks in memory
+        #                                only as the two-fp16-slice image the GEMMs read (22-23 significant bits; measured: the loop stays
+        #                                closer to an fp64 evaluation than the reference's fp32 arithmetic, tests/test_hip_parity.py);
+        #                                True also keeps the fp32 rows (include/pafuse_hip.h pafuse_mixste2_weights.keep_f32_residual)
         self.use_side_stream = False   # training backward: weight-gradient GEMMs on a second stream (identical
         #                                results; measured 3 % slower than one stream per part at B=37, so off)
         self._side_by_device = {}
@@ -130,7 +134,8 @@ class MixSTE2(nn.Module):
                 return self._zero_qkv_bias
             return attrgetter(name)(self)
         mode = int(self.operand_bf16)
-        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode, bool(images))
+        key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode, bool(images),
+                                                                     bool(self.keep_f32_residual))
         if not images:
             hit = self._wcache_by_device.get(("train", self._freqs.device.index))
             if hit is not None and hit[0] == key:
@@ -175,6 +180,7 @@ class MixSTE2(nn.Module):
                             self.block_depth, self.num_heads, self.in_chans, mode, images)
         w.mlp_hidden = self.mlp_hidden
         w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
+        w.keep_f32_residual = int(bool(self.keep_f32_residual))
         if replica:
             self._replica_keep = (w, images, event)      # alive as long as the replica (one forward)
         else:
