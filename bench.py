@@ -82,6 +82,8 @@ def main():
                          "compare them with a single-process run of the same seed")
     ap.add_argument("--train-dtype", choices=("f32", "bf16x3"), default="bf16x3",
                     help="--train: matrix products of the plain GEMMs (qkv, fc1, dX): split precision (default) or fp32 MFMA")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the `train` object of the inference line (a short B=37 training measurement, N = 1 only)")
     ap.add_argument("--train", action="store_true",
                     help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
                          "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
@@ -283,19 +285,19 @@ def main():
         # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
         # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
         traffic, traffic_info = None, {"traffic_source": None}
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
         if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10):
             tj = json.load(open(tpath))
             if tj.get("dtype", "bf16x3") != args.dtype:
-                traffic_info = {"traffic_source": f"profiles/r03_pmc_traffic.json was collected in {tj.get('dtype', 'bf16x3')} mode: not quoted"}
+                traffic_info = {"traffic_source": f"profiles/r04_pmc_traffic.json was collected in {tj.get('dtype', 'bf16x3')} mode: not quoted"}
             elif tj.get("kernel_source_sha256") == _lib.kernel_source_digest():
                 traffic = round(tj["traffic_bytes_per_launch"])
-                traffic_info = {"traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                traffic_info = {"traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                                   "FETCH doubled per the gfx950 correction)",
                                 "hbm_GBps_dominant_kernel": round(traffic / (ms * 1e-3 / n) / 1e9, 1),
                                 "hbm_GBps_by_kernel_family": tj.get("hbm_GBps_by_kernel_family")}
             else:
-                traffic_info = {"traffic_source": "profiles/r03_pmc_traffic.json is from other kernel sources "
+                traffic_info = {"traffic_source": "profiles/r04_pmc_traffic.json is from other kernel sources "
                                                   "(kernel_source_sha256 differs): not quoted"}
         # algorithmic bytes per launch, two ways: (i) this design's launch boundaries (every GEMM reads A and W and
         # writes its outputs; whole-row kernels also read the residual and write x and xn); (ii) SURVEY 8(d)'s fused
@@ -335,7 +337,7 @@ def main():
                             "frac_of_bf16_dense_peak": None if args.dtype == "f32" else round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
                             "mfma_pipe_frac": round(achieved * products / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
                             "mfma_pipe_note": "executed matrix FLOPs (useful x 6 products in bf16x3, x 3 in f16x2) / dense peak of the instruction; "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES of the same launches: profiles/r03_pmc_mfma_util.json",
+                                              "SQ_VALU_MFMA_BUSY_CYCLES of the same launches: profiles/r04_pmc_mfma_util.json",
                             "traffic": traffic,
                             "traffic_unit": "HBM bytes per launch",
                             "algorithmic_bytes_per_launch": {"this_design_unfused_between_gemms": round(alg_unfused),
@@ -383,11 +385,51 @@ def main():
                                           f"picked from a P=1,T=1 probe {{threads: s}} = "
                                           f"{ {k: round(v, 2) for k, v in probe.items()} } on a {hw}-thread host"}
 
+    # ---- BASELINE configs[4] beside the headline (N = 1): a short training measurement, so that the driver's record holds one
+    if world == 1 and not args.no_train_leg:
+        line["train"] = train_leg(dev, args.streams)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()      # ranks > 0 wait here while rank 0 runs the roofline and CPU-baseline legs
         dist.destroy_process_group()
+
+
+def train_leg(dev, streams, B=37, steps=3):
+    """The `train` object of the inference line: D3DP train step (fwd + bwd + AdamW) at B = 37 clips, one GPU, 'bf16x3' products
+    (the single-process default; `python bench.py --train` is the full training bench with its CPU baseline and DDP)."""
+    import torch
+    import __graft_entry__ as ge
+    from pafuse_amd import synthetic as gu
+    model, _ = ge.make_model(1, 1, seed=51, device=dev, is_train=True)
+    model.n_aux_streams = streams
+    x2d, _ = gu.synthetic_inputs_2d(B=B, seed=1234)
+    target = gu.synthetic_target_3d(B=B, seed=1235).to(dev)
+    x2d = x2d.to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=6e-5, weight_decay=0.1)
+    torch.manual_seed(4321)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = model(x2d, target)
+        loss = torch.mean(torch.norm(pred - target, dim=-1))
+        loss.backward()
+        opt.step()
+        return loss
+
+    step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    sec = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(loss.detach()))
+    tflops = B * 3 * GFLOP_PER_HYP_PASS / 1e3 / sec
+    return {"metric": "training clips/sec (H3WB 27x134 clips, fwd+bwd+AdamW), BASELINE configs[4] on one GPU", "value": round(B / sec, 2),
+            "unit": "clips/s", "ms_per_step": round(sec * 1e3, 2), "steps": steps, "B": B, "dtype": model.precision,
+            "achieved": round(tflops, 2), "unit_achieved": "TFLOP/s of fp32-equivalent work (B*3*69.3847 GFLOP / step)",
+            "frac_of_f32_peak": round(tflops / PEAK_F32_MFMA_TFLOPS, 4)}
 
 
 def train_bench(args, rank, local_rank, world, dev):

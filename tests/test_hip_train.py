@@ -89,15 +89,16 @@ def test_g13_d3dp_train_golden():
 
 @pytest.mark.parametrize("part,B,depth,rate,rel,precision",
                          [("body", 3, 2, 0.3, 2e-4, "f32"), ("face", 2, 2, 0.3, 2e-4, "f32"), ("hands", 2, 2, 0.3, 2e-4, "f32"),
-                          ("body", 37, 8, 0.1, 5e-4, "f32"),
+                          ("body", 37, 8, 0.1, 5e-4, "f32"), ("face", 37, 8, 0.1, 5e-4, "f32"), ("hands", 37, 8, 0.1, 5e-4, "f32"),
                           # split-precision products in the plain GEMMs of training (qkv, fc1, every dX): the same bounds
                           ("body", 3, 2, 0.3, 2e-4, "bf16x3"), ("face", 2, 2, 0.3, 2e-4, "bf16x3"),
-                          ("hands", 2, 2, 0.3, 2e-4, "bf16x3"), ("body", 37, 8, 0.1, 5e-4, "bf16x3")])
+                          ("hands", 2, 2, 0.3, 2e-4, "bf16x3"), ("body", 37, 8, 0.1, 5e-4, "bf16x3"),
+                          ("face", 37, 8, 0.1, 5e-4, "bf16x3"), ("hands", 37, 8, 0.1, 5e-4, "bf16x3")])
 def test_train_gradients_vs_oracle_real_widths(part, B, depth, rate, rel, precision):
     """one part at its real width, DropPath active with seeded factors, against torch autograd over the oracle on the
-    CPU: depth 2 at small batches for every part, and BASELINE configs[4]'s own size for the body denoiser - depth 8,
-    B = 37 clips (1024 // 27, main_h3wb.py:781), drop_path_rate 0.1 (diffusionpose.py:147): 23 976 tokens, every one of
-    the 208 parameter gradients (sums over up to 24 k rows: 5e-4 of the tensor's largest entry)."""
+    CPU: depth 2 at small batches for every part, and BASELINE configs[4]'s own size for EVERY part's denoiser - depth 8,
+    B = 37 clips (1024 // 27, main_h3wb.py:781), drop_path_rate 0.1 (diffusionpose.py:147): 23 976 / 67 932 / 41 958
+    tokens, every one of the 208 parameter gradients (sums over up to 68 k rows: 5e-4 of the tensor's largest entry)."""
     import pafuse_amd
     J, C = len(gu.PART_JOINTS[part]), gu.PART_WIDTH[part]
     m = pafuse_amd.MixSTE2(num_frame=27, num_joints=J, in_chans=5, embed_dim_ratio=C, depth=depth, num_heads=8,
@@ -126,6 +127,63 @@ def test_train_gradients_vs_oracle_real_widths(part, B, depth, rate, rel, precis
     assert len(leaves) == len(list(m.named_parameters())) == 16 + 24 * depth
     for n, p in m.named_parameters():
         _close(p.grad, leaves[n].grad, n, rel)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_d3dp_train_step_full_size_vs_oracle(precision):
+    """BASELINE configs[4]'s step at its own size: the three-part D3DP in train mode, depth 8, B = 37 clips, DropPath 0.1
+    with seeded factors, per-sample (t, noise) draws -> q_sample -> the parts' train-mode denoisers -> mpjpe loss -> backward
+    (common/diffusionpose.py:346-388, main_h3wb.py:781,850-871), against torch autograd over the oracle on the CPU: the noised
+    poses bit for bit, the prediction pointwise, the loss, and every one of the 624 parameter gradients.  (The oracle side
+    runs part by part - the parts meet only in the loss' mean over joints - so that its autograd graph stays in memory.)"""
+    from __graft_entry__ import make_model
+    B, depth, rate = 37, 8, 0.1
+    model, sd = make_model(1, 1, seed=132, is_train=True, depth=depth)
+    model.precision = precision
+    x2d, _ = gu.synthetic_inputs_2d(B=B)
+    target = gu.synthetic_target_3d(B=B)
+    g = torch.Generator().manual_seed(133)
+    draws = [(torch.randint(0, 1000, (1,), generator=g), torch.randn(27, 134, 3, generator=g)) for _ in range(B)]
+    model.train_draw_fn = lambda i: draws[i]
+    drops = {}
+    for part, m in model.pose_estimator.items():
+        J = m.num_joints
+        assert abs(m.drop_path_rate - rate) < 1e-12 and m.block_depth == depth
+        d = []
+        for r in orc.drop_path_rates(rate, depth):
+            for nseq in (B * 27, B * J):
+                d.append(tuple((torch.rand(nseq, generator=g) < 1 - r).float() / (1 - r) if r > 0 else None for _ in range(2)))
+        drops[part] = d
+        m.drop_fn = lambda block, branch, nseq, rate_, d=d: d[block][branch]
+    pred = model(x2d.to(DEV), target.to(DEV))
+    loss = orc.mpjpe(pred, target.to(DEV))
+    loss.backward()
+    # ---- the oracle
+    t = torch.stack([d[0] for d in draws]).squeeze(-1)
+    noise = torch.stack([d[1] for d in draws])
+    x_poses = orc.q_sample_targets(sd, target, t, noise)
+    x_hip, _, _ = model.prepare_targets(target.to(DEV))
+    assert torch.equal(x_hip.cpu(), x_poses)
+    with torch.no_grad():
+        ref = orc.train_forward(sd, x2d, x_poses, t, depth=depth, drops=[drops[p] for p in orc.PART_JOINTS])
+    assert torch.allclose(pred.detach().cpu(), ref, rtol=0, atol=1e-5), (pred.detach().cpu() - ref).abs().max()
+    ref_leaf = ref.clone().requires_grad_(True)
+    ref_loss = orc.mpjpe(ref_leaf, target)
+    assert torch.allclose(loss.detach().cpu(), ref_loss.detach(), rtol=1e-5, atol=0), (float(loss), float(ref_loss))
+    ref_loss.backward()
+    params = dict(model.named_parameters())
+    checked = 0
+    for part, idx in orc.PART_JOINTS.items():
+        pre = f"pose_estimator.{part}."
+        leaves = {k: (v.clone().requires_grad_(True) if k.startswith(pre) else v) for k, v in sd.items()}
+        out = orc.mixste2_train(leaves, pre, x2d[..., idx, :], x_poses[..., idx, :], t, depth, 8, drop=drops[part])
+        out.backward(ref_leaf.grad[..., idx, :])
+        for k, v in leaves.items():
+            if k.startswith(pre):
+                _close(params[k].grad, v.grad, k, 5e-4)
+                checked += 1
+        del leaves, out
+    assert checked == len(params) == 3 * (16 + 24 * depth)
 
 
 def test_train_backward_is_bit_reproducible():

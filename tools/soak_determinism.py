@@ -29,7 +29,7 @@ from pafuse_amd._lib import kernel_source_digest  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    precision = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+    precision = sys.argv[2] if len(sys.argv) > 2 else "f16x2"
     aux = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     model, _ = make_model(20, 10, seed=77)
     model.precision = precision
