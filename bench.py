@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--f32-residual", action="store_true",
                     help="A/B (f16x2): keep the residual stream between the blocks as fp32 rows beside its H image "
                          "(pafuse_amd.MixSTE2.keep_f32_residual)")
+    ap.add_argument("--ln-fold", action="store_true", help="A/B (bf16x3): fold norm1 / norm2 into the qkv / fc1 GEMMs (the default only in f16x2)")
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
@@ -127,8 +128,8 @@ def main():
     model.use_graph = args.graph
     model.precision = args.dtype
     for m in model.denoisers().values():
-        if args.no_ln_fold:
-            m.fold_layernorm = False
+        if args.no_ln_fold or args.ln_fold:
+            m.fold_layernorm = not args.no_ln_fold
         m.fuse_qkv_attention = {"auto": None, "on": True, "off": False}[args.fuse_qkv_attention]
         m.keep_f32_residual = bool(args.f32_residual)
     sampler = ShardedSampler(model)
@@ -215,9 +216,9 @@ def main():
                    "single_device_rehearsal": bool(args.single_device),
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
-        "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype in SPLIT_DTYPES and not args.no_ln_fold),
+        "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype in SPLIT_DTYPES and not args.no_ln_fold and (args.dtype == "f16x2" or args.ln_fold)),
         "residual_stream_in_memory": ("H image only (two fp16 slices, 22-23 significant bits)" if args.dtype == "f16x2" and not args.no_ln_fold
-                                      and not args.f32_residual else "fp32"),
+                                      and not args.f32_residual else "fp32 rows"),
         "qkv_attention_fused_blocks": {name: _lib.check(_lib.load().pafuse_mixste2_fused_blocks(C.byref(m.weights_struct())))
                                        for name, m in model.denoisers().items()} if args.dtype in SPLIT_DTYPES else None,
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
@@ -308,7 +309,7 @@ def main():
         # (i) per token and block: qkv reads C writes 3C; proj reads o, x writes x, xn; fc1 reads C writes 2C; fc2 reads
         #     2C, x writes x, xn = 16 C floats (14 with the LayerNorm folded into qkv / fc1: no xn, 8 B of statistics per
         #     row instead); 16 blocks per pass; + the 139.8 MB of weights once
-        per_token = 14 if (args.dtype in SPLIT_DTYPES and not args.no_ln_fold) else 16
+        per_token = 14 if (args.dtype in SPLIT_DTYPES and not args.no_ln_fold and (args.dtype == "f16x2" or args.ln_fold)) else 16
         alg_unfused = (mc * 4 * per_token * 16 + 139.8e6) / launches
         alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
         mfma = ("v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else

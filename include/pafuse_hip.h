@@ -102,9 +102,10 @@ typedef struct pafuse_mixste2_weights {
     float qk_scale;       /* MixSTE2(qk_scale=...): attention logit scale; 0 = head_dim^-0.5 (common/mixste.py:52).
                              Inference only.  (qkv_bias=False: point qkv_b at zeros.) */
     int32_t keep_f32_residual; /* operand_bf16 == 3 with the LayerNorm folded: 0 (default) keeps the residual stream between the
-                             blocks in memory ONLY as its H image (hi + 2^-11 lo: 22-23 significant bits; the whole-row kernels read
-                             it as the residual and write it back in place - a quarter of their HBM traffic less); 1 also keeps
-                             the fp32 rows and adds those (the residual stream then carries all 24 bits). */
+                             blocks in memory ONLY as its H image - of x - mean(row): every reader of the stream is a LayerNorm or
+                             the residual add that feeds one, so a row's mean never reaches the output and is not carried - as
+                             hi + 2^-11 lo (22-23 significant bits); the whole-row kernels read it as the residual and write it
+                             back in place (a quarter of their HBM traffic less); 1 also keeps the fp32 rows and adds those. */
     const float *patch_w, *patch_b;                           /* Spatial_patch_to_embedding [C,5], [C] */
     const float *pos_spatial;                                 /* Spatial_pos_embed [J,C] */
     const float *pos_temporal;                                /* Temporal_pos_embed [F,C] */

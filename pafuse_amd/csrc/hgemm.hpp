@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) hsplit_weights_kernel(const float* W, uin
 // cost 30 000 line transactions: 62 000 cycles of epilogue against 35 000 of K loop (tools/hgemm_bench.hip stamps).  Through
 // the slab a wave instruction moves 1 KiB in 8 lines (4 rows x 256 B).
 // LDS (the dead ring): [7 BM WN floats: cross-wave partial sums][5 BN floats: per-column vectors][NW slabs of 32 x (32 NTH + 4)].
-template <int WN, int NT, int BM, int NW, int NTH>
+template <int WN, int NT, int BM, int NW, int NTH, bool HRES>   // HRES: the residual is the centred H image of x (p.resid_h)
 __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0, const int wm,
                                                 const int wn, const int r, const int h, const int wave, const int lane, float* smem,
                                                 const float ws) {
@@ -137,7 +137,12 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
     f32x4 rin[NBUF][LD];
     // (the residual is either fp32 rows or - p.resid_h - the H image of x: the same 4 bytes per element, so the same
     // row-segment loads; what differs is how a lane picks its four values out of the slab)
-    const float* const resid_rows = p.resid_h ? reinterpret_cast<const float*>(p.resid_h) : p.resid;
+    const float* const resid_rows = HRES ? reinterpret_cast<const float*>(p.resid_h) : p.resid;
+    // The H image of x is CENTRED: it holds x - mean(row), so what the next GEMM multiplies has no common mode.  The mean
+    // itself is carried nowhere: every reader of the residual stream is a LayerNorm (norm1, norm2, the block's post-norm, the
+    // head's) or the residual add that feeds them, and LayerNorm does not see a row's mean - x and x - mean(x) give the same
+    // network output.  So the residual here is the image as it is, the sum is re-centred on its own mean before it is stored,
+    // and no number of the stream is ever rounded at the magnitude of an outlier mean (the fp32 reference rounds there).
     auto load_resid = [&](int ps, f32x4 (&dst)[LD]) {
         const int nth = pass_cols(ps), qpr = 8 * nth;
         const int ncol0 = n0 + (wn * NT + ps * NTH) * 32;
@@ -168,7 +173,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                     const int nt = ps * NTH + j;
                     const f32x4 b4 = vec4(0, nb + 32 * nt + 8 * q);
                     f32x4 r4;
-                    if (p.resid_h) {   // sub-block (32 j + 8 q) / 8 of the slab row: hi at + 0, lo at + 16 bytes; this lane's half 4 h
+                    if constexpr (HRES) {   // sub-block (32 j + 8 q) / 8 of the slab row: hi at + 0, lo at + 16 bytes; this lane's half 4 h
                         const uint8_t* sbk = reinterpret_cast<const uint8_t*>(slab + r * ST + 32 * j + 8 * q);
                         typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
                         const f16x4_t hi = *reinterpret_cast<const f16x4_t*>(sbk + 8 * h), lo = *reinterpret_cast<const f16x4_t*>(sbk + 16 + 8 * h);
@@ -197,7 +202,8 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
     }
     // a pass of the accumulators out through the slab: fp32 rows to `dst32` and / or their H image to `dsth` (whole sub-blocks
     // of 8 columns per lane: 32 contiguous bytes of either)
-    auto store_rows = [&](float* dst32, uint8_t* dsth) {
+    float* const rowmean = smem + 6 * BM * WN + wave * 32;     // (slot 6 of the reduction scratch is unused by the chain: per-wave row means)
+    auto store_rows = [&](float* dst32, uint8_t* dsth, bool centred) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int nth = pass_cols(ps), spr = 4 * nth;
@@ -226,7 +232,13 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                         *reinterpret_cast<f32x4*>(dst32 + at + 4) = hi4;
                     }
                     if (dsth) {
-                        const f16x8x2 sp = split2h(lo4, hi4);
+                        f32x4 c0 = lo4, c1 = hi4;
+                        if (centred) {
+                            const float mu = rowmean[row];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) c0[e] -= mu, c1[e] -= mu;
+                        }
+                        const f16x8x2 sp = split2h(c0, c1);
                         *reinterpret_cast<f16x8*>(dsth + at * 4) = sp.hi;
                         *reinterpret_cast<f16x8*>(dsth + at * 4 + 16) = sp.lo;
                     }
@@ -235,31 +247,49 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
             __builtin_amdgcn_wave_barrier();
         }
     };
-    if (p.out_x || p.out_xh) store_rows(p.out_x, p.out_xh);
-    if (p.next_w && p.ln_stats) {
-        // the next LayerNorm is folded into the GEMM that consumes it: the row's statistics only
-        float s = 0.f;
+    // Up to two row stores: (0) x (fp32 and / or its H image - centred on the row mean when the next LayerNorm is folded into
+    // its consumer, whose statistics are formed first), (1) without the fold, the next LayerNorm's output.  ONE copy of the
+    // store code (a loop the compiler may not unroll): three inlined copies cost 170 - 380 bytes of scratch per lane.
+    const bool folded = p.next_w && p.ln_stats;
+#pragma clang loop unroll(disable)
+    for (int ph = 0; ph < 2; ++ph) {
+        float* d32;
+        uint8_t* dh;
+        bool centred = false;
+        if (ph == 0) {
+            if (folded) {   // the row's statistics only (the same two fixed-order reductions layer_norm makes)
+                float s = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s += acc[nt][i];
-        const float mean = row_total(s, 2) * invC;
-        float qv = 0.f;
+                    for (int i = 0; i < 16; ++i) s += acc[nt][i];
+                const float mean = row_total(s, 2) * invC;
+                float qv = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float d = acc[nt][i] - mean;
-                qv += d * d;
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = acc[nt][i] - mean;
+                        qv += d * d;
+                    }
+                const float rstd = 1.0f / sqrtf(row_total(qv, 3) * invC + p.next_eps);
+                if (live && h == 0 && wn == 0) {
+                    p.ln_stats[2 * m] = mean;
+                    p.ln_stats[2 * m + 1] = rstd;
+                }
+                if (h == 0) rowmean[r] = mean;      // (every wave of the row knows the mean: its own copy, wave-local)
+                __builtin_amdgcn_wave_barrier();
+                centred = true;
             }
-        const float rstd = 1.0f / sqrtf(row_total(qv, 3) * invC + p.next_eps);
-        if (live && h == 0 && wn == 0) {
-            p.ln_stats[2 * m] = mean;
-            p.ln_stats[2 * m + 1] = rstd;
+            d32 = p.out_x, dh = p.out_xh;
+        } else {
+            if (!p.next_w || folded) break;
+            layer_norm(p.next_eps, 2, 3);
+            d32 = p.out_n, dh = p.out_nh;
         }
-    } else if (p.next_w) {
-        layer_norm(p.next_eps, 2, 3);
-        if (p.out_nh || p.out_n) store_rows(p.out_n, p.out_nh);
+        if (d32 || dh) store_rows(d32, dh, centred);
+    }
+    if (p.next_w && !folded) {
         if (p.out_head) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -296,7 +326,7 @@ struct HTile {
     static_assert(BKC == 16 || (NW % 2 == 0 && IA % 2 == 0), "instruction parity = wave parity");
 };
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, bool HRES = false>
 __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, const int nb, float* smem) {
     using T = HTile<WM, WN, NT, BKC>;
     constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW, ROWB = T::ROWB;
@@ -459,7 +489,7 @@ __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, con
                 for (int i = tid; i < BN / 4; i += T::NTHR)
                     *reinterpret_cast<f32x4*>(smem + VEC + v * BN + 4 * i) = *reinterpret_cast<const f32x4*>(src[v] + n0 + 4 * i);
         __syncthreads();
-        epilogue_rows_h<WN, NT, BM, NW, NTH>(acc, p, m0, n0, wm, wn, r, h, wave, lane, smem, ws);
+        epilogue_rows_h<WN, NT, BM, NW, NTH, HRES>(acc, p, m0, n0, wm, wn, r, h, wave, lane, smem, ws);
         return;
     } else {
         // ---- plain layers: out = act(ws acc + bias), or the folded LayerNorm  act(rstd (ws acc - mean ls) + lt); every wave
@@ -494,10 +524,13 @@ __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, con
                         const int n = ncol0 + 32 * j + 8 * q + 4 * h;
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
                         f32x4 v;
-                        if (p.ln_in) {
+                        if (p.ln_in && p.ln_s) {
                             const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[nt0 + j][4 * q + e], fmaf(nmr, s4[e], b4[e]));
+                        } else if (p.ln_in) {   // A is the CENTRED image (x - mean): LN(x) W^T + b = rstd acc + lt, no mean term
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[nt0 + j][4 * q + e], b4[e]);
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[nt0 + j][4 * q + e], ws, b4[e]);
@@ -544,11 +577,11 @@ __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, con
     }
 }
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW, bool HRES = false>
 __global__ void __launch_bounds__(WM* WN * 64, MINW) hgemm_kernel(const GemmParams p) {
     PAFUSE_XQ_GUARD();
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    hgemm_tile<WM, WN, NT, EPI, NSTAGE, BKC>(p, blockIdx.x, gridDim.x, smem);
+    hgemm_tile<WM, WN, NT, EPI, NSTAGE, BKC, HRES>(p, blockIdx.x, gridDim.x, smem);
 }
 
 
@@ -706,10 +739,13 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
             const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
             f32x4 v;
-            if (p.ln_in) {
+            if (p.ln_in && p.ln_s) {
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + col);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
+            } else if (p.ln_in) {   // centred A: no mean term
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[g][n][e], ws, b4[e]);

@@ -281,10 +281,12 @@ struct GemmParams {
     const uint8_t* Ah;   // A [M,K] split by its producer (hi = f16(a), lo = f16((a - hi) 2^11)); row stride 4 K bytes
     const uint8_t* Wh;   // W [N,K] as the H image of 2^k W (w0 = f16(Ws), w1 = f16(Ws - w0)), 2^-k in the tail behind it
     uint8_t* out_h;      // EPI_BIAS: the output as an H image [M,N] instead of fp32 `out` (its consumer is another hgemm)
-    uint8_t* out_xh;     // EPI_ROWLN: the H image of out_x, written beside it (A operand of the next qkv / fc1, LayerNorm folded)
+    uint8_t* out_xh;     // EPI_ROWLN: the H image of out_x - CENTRED: of out_x - mean(row), the mean being the one written to ln_stats -
+    //                      (A operand of the next qkv / fc1 with the LayerNorm folded, and the residual stream itself)
     uint8_t* out_nh;     // EPI_ROWLN: the H image of the next LayerNorm's output instead of fp32 out_n (LayerNorm not folded)
-    const uint8_t* resid_h;  // EPI_ROWLN: the residual as the H image of x (then `resid` is unused): with the LayerNorm folded the
-    //                          residual stream lives in memory in this form ONLY (hi + 2^-11 lo, 22-23 significant bits; out_x null)
+    const uint8_t* resid_h;  // EPI_ROWLN: the residual as the (centred) H image of x (then `resid` is unused): with the LayerNorm
+    //                          folded the residual stream lives in memory in this form ONLY - x - mean(row) as hi + 2^-11 lo, 22-23
+    //                          significant bits; the row mean is dropped, no reader of the stream sees it (hgemm.hpp); out_x null
     const float* rowscale;  // [nseq] DropPath factor of the row's sequence, or null (= 1)
     int rs_temporal, rs_J, rs_FJ;  // seq(m) = rs_temporal ? (m / rs_FJ) * rs_J + m % rs_J : m / rs_J
     float* out_pre;
@@ -2055,8 +2057,8 @@ struct EmbedParams {
     const float *n_w, *n_b;             // next LayerNorm
     float n_eps;
     float *x, *xn;  // [M,C]  (x may be null when only the H image of x is wanted)
-    uint8_t* xh;    // f16x2 H pipeline: the H image [M,C] the first qkv hgemm reads - of x when `stats` is set (LayerNorm
-    //                 folded), else of the normalised row (then xn is not written)
+    uint8_t* xh;    // f16x2 H pipeline: the H image [M,C] the first qkv hgemm reads - of x - mean(row) when `stats` is set
+    //                 (LayerNorm folded), else of the normalised row (then xn is not written)
     float* stats;   // folded LayerNorm (GemmParams::ln_in of the first qkv GEMM): (mean, rstd) of row row0 + i at stats[2 i]
     //                 instead of xn; null = write xn
     int B, P, F, J, J3, C, nflip;
@@ -2123,7 +2125,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
                 s += a;
             }
             if (live && p.x) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
-            if (live && p.xh && p.stats) hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), v[i]);
+
         }
     }
     const float invC = 1.0f / (float)p.C;
@@ -2143,6 +2145,18 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
         if (live && li == 0) {
             p.stats[2 * local] = mean;
             p.stats[2 * local + 1] = rstd;
+        }
+        if (p.xh && live) {   // f16x2: the H image of x, CENTRED on the row mean (hgemm.hpp epilogue_rows_h)
+#pragma unroll
+            for (int i = 0; i < EMBED_NV; ++i) {
+                const int c4 = li + 32 * i;
+                if (c4 < NQ) {
+                    f32x4 cv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cv[e] = v[i][e] - mean;
+                    hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), cv);
+                }
+            }
         }
         return;
     }

@@ -195,7 +195,7 @@ int launch_gemm_dma(const GemmParams& p, hipStream_t s) {
 }
 
 // ---- f16x2 "H pipeline" (hgemm.hpp): both operands arrive as H images; one workgroup of WM x WN waves per CU
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW, bool HRES = false>
 int launch_hgemm(const GemmParams& p, hipStream_t s) {
     using T = HTile<WM, WN, NT, BKC>;
     constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
@@ -203,7 +203,8 @@ int launch_hgemm(const GemmParams& p, hipStream_t s) {
     static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
     if (!p.Ah || !p.Wh) return fail(PAFUSE_E_ARG, "f16x2 GEMM without the H images of its operands");
     if (p.K % BKC || p.K <= 0 || p.N % T::BN) return fail(PAFUSE_E_SHAPE, "f16x2 GEMM: N=%d, K=%d do not fit the %d-column tile", p.N, p.K, T::BN);
-    auto k = hgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW>;
+    if (HRES && !p.resid_h) return fail(PAFUSE_E_ARG, "f16x2 whole-row GEMM: no H-image residual");
+    auto k = hgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW, HRES>;
     if (lds > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -230,6 +231,13 @@ int hgemm_bias(const GemmParams& p, hipStream_t s) {
 
 int hgemm_rowln(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
+    if (p.resid_h)   // the residual stream as its (centred) H image: the default of the folded-LayerNorm pipeline
+        switch (p.N) {
+            case 384: return launch_hgemm<4, 2, 6, EPI_ROWLN, 2, 32, 1, true>(p, s);
+            case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2, true>(p, s);
+            case 224: return launch_hgemm<4, 1, 7, EPI_ROWLN, 3, 16, 2, true>(p, s);
+            default: break;
+        }
     switch (p.N) {
         case 384: return launch_hgemm<4, 2, 6, EPI_ROWLN, 2, 32, 1>(p, s);   // 128 rows, eight waves, 128 KB ring: one per CU
         case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2>(p, s);   // 64 rows, four waves, three per CU
@@ -588,6 +596,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws, g.wlayout = 2;   // qkv images are in the M16 layout (include/pafuse_hip.h)
     if (fold) g.A = pb.x, g.ln_in = stats, g.ln_s = bw.qkv_ls, g.bias = bw.qkv_lt;
     if (hp) g.Ah = xn_h, g.Wh = (const uint8_t*)bw.qkv_ws;
+    if (hp && fold) g.ln_s = nullptr;   // the H image of x is centred on the row mean: rstd acc + lt, no mean term
     AttnParams& a = b.attn;
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
     a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
@@ -600,7 +609,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
         FqaParams& f = b.fqa;
         f.g = g;
         f.g.Wsplit = (const uint8_t*)bw.qkv_hs, f.g.bias = bw.qkv_hb, f.g.ln_s = fold ? bw.qkv_hl : nullptr;
-        if (hp) f.g.Wh = (const uint8_t*)bw.qkv_hs;   // (Ah is the qkv launch's; o is written as the H image the proj hgemm reads)
+        if (hp) f.g.Wh = (const uint8_t*)bw.qkv_hs, f.g.ln_s = nullptr;   // (Ah is the qkv launch's: centred; o is written as an H image)
         f.g.N = heads * 3 * dp;
         f.o = pb.o, f.nseq = nseq, f.L = L, f.C = C, f.heads = heads, f.d = C / heads;
         f.nseq_tile = (rows - lp) / L + 1;    // whole sequences per 128-row tile, the last one's LP-row key tile inside the buffer
@@ -629,6 +638,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
     if (fold) f1.A = pb.x, f1.ln_in = stats, f1.ln_s = bw.fc1_ls, f1.bias = bw.fc1_lt;
     if (hp) f1.Ah = xn_h, f1.Wh = (const uint8_t*)bw.fc1_ws, f1.out_h = reinterpret_cast<uint8_t*>(pb.wide);
+    if (hp && fold) f1.ln_s = nullptr;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
     GemmParams& f2 = b.fc2;
     f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = hidden;

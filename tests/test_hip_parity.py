@@ -377,7 +377,8 @@ def test_folded_layernorm_is_the_same_function(precision):
     model.noise_fn = lambda k, shape, device: noises[k]
     model.precision = precision
     parts = list(model.denoisers().values())
-    assert all(m.fold_layernorm for m in parts)
+    for m in parts:
+        m.fold_layernorm = True
     folded = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     for m in parts:
         m.fold_layernorm = False
@@ -879,6 +880,84 @@ def test_replicas_share_nothing_device_bound():
     assert torch.equal(dp(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV)), want)
     replica = torch.nn.parallel.replicate(model, [0])[0]
     assert torch.equal(replica(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV)), want)
+
+
+def test_replicas_follow_the_parent_weights():
+    """nn.DataParallel's replicas are fresh broadcast copies on EVERY forward: version 0, and the caching allocator hands out
+    the addresses of the previous forward's copies again - a weight-image cache keyed on (pointer, version) would hit with
+    the images of the OLD weights.  Replicas therefore never read the cache: forward, in-place weight update
+    (an optimiser step / load_state_dict of another checkpoint), forward again, through replicas on one device listed twice
+    (two worker threads, two replicas), must give what the updated parent gives."""
+    from __graft_entry__ import make_model
+    model, _ = make_model(2, 1, seed=93)
+    i2d, i2f = gu.synthetic_inputs_2d(B=2)
+    noises = gu.synthetic_noises(B=2, P=2, n=1, seed=13)
+    model.noise_fn = lambda k, shape, device: noises[k][:shape[0]] if shape[0] == 2 else noises[k][model._clip:model._clip + 1]
+    model._clip = 0
+
+    def replicas_forward():
+        outs = []
+        for b, rep in enumerate(torch.nn.parallel.replicate(model, [0, 0])):     # what DataParallel.forward does per call
+            assert getattr(rep, "_is_replica", False)
+            model._clip = b
+            outs.append(rep(i2d[b:b + 1].to(DEV), None, input_2d_flip=i2f[b:b + 1].to(DEV)))
+        return torch.cat(outs)
+
+    first = replicas_forward()
+    assert torch.equal(first, model(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV)))
+    _, sd2 = make_model(2, 1, seed=94)
+    model.load_state_dict(sd2)                                    # in place: same parameter storages, new values
+    second = replicas_forward()
+    assert not torch.equal(first, second)
+    assert torch.equal(second, model(i2d.to(DEV), None, input_2d_flip=i2f.to(DEV)))
+
+
+def test_image_caches_do_not_outlive_their_tensors():
+    """the torch ops' image cache pins the tensor an image was made from: a temporary weight freed and another allocated at
+    the same address (same shape, version 0) must not be served the first one's image."""
+    from pafuse_amd import torch_ops as to
+    x = _seeded((64, 256), 31).to(DEV)
+    outs = []
+    for seed in (32, 33):
+        w = _seeded((256, 256), seed, 0.05).to(DEV)               # a per-call temporary: freed at the end of the iteration
+        img = to.cached_split_image(w, 0)
+        from pafuse_amd import ops
+        outs.append((ops.linear_split(x, w, torch.zeros(256, device=DEV), image=img).cpu(), ops.linear_split(x, w, torch.zeros(256, device=DEV)).cpu()))
+        del w, img
+    for cached, fresh in outs:
+        assert torch.equal(cached, fresh)
+    assert not torch.equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("precision,fold,factor", [("f16x2", None, 1.5), ("bf16x3", None, 1.5), ("bf16x3", True, 3.0)])
+def test_folded_layernorm_with_large_row_means(precision, fold, factor):
+    """The folded LayerNorm multiplies un-normalised rows: with |mean| >> std (outlier channels of a trained residual
+    stream) a three-term form rstd (acc - mean ls) + lt cancels large numbers.  'f16x2' stores x - mean(row)
+    (the image is centred; the mean itself is dead information to a stack of LayerNorms and is dropped), so nothing
+    cancels, and the fold is its default; 'bf16x3' keeps the three-term form and therefore folds only on request (measured
+    2.1 x the reference's error here: the last case documents it, bounded at 3 x).  Against an fp64 evaluation of one denoiser pass whose post-norm biases (Spatial_norm, Temporal_norm: what every
+    block hands to the next) put every row of the residual stream at mean 10 with std ~ 1: not further from exact
+    arithmetic than 1.5 x the reference's own fp32 arithmetic (whose LayerNorms see the same rows)."""
+    from __graft_entry__ import make_model
+    model, sd = make_model(2, 2, seed=95)
+    for part in model.pose_estimator:
+        sd[f"pose_estimator.{part}.Spatial_norm.bias"] += 10.0
+        sd[f"pose_estimator.{part}.Temporal_norm.bias"] += 10.0
+    model.load_state_dict(sd)
+    model.precision = precision
+    for m in model.denoisers().values():
+        m.fold_layernorm = fold
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x2d, _ = gu.synthetic_inputs_2d(B=1)
+    x3d = _seeded((1, 2, 27, 134, 3), 53).clamp(-1.1, 1.1)
+    t = torch.tensor([499])
+    for part, idx in orc.PART_JOINTS.items():
+        pre = f"pose_estimator.{part}."
+        truth = orc.mixste2_eval(sd64, pre, x2d[..., idx, :].double(), x3d[..., idx, :].double(), t)
+        ref32 = orc.mixste2_eval(sd, pre, x2d[..., idx, :], x3d[..., idx, :], t)
+        hip = model.pose_estimator[part](x2d[..., idx, :].to(DEV), x3d[..., idx, :].to(DEV), t.to(DEV)).cpu()
+        e_ref, e_hip = (ref32.double() - truth).abs(), (hip.double() - truth).abs()
+        assert e_hip.mean() <= factor * e_ref.mean(), (precision, fold, part, float(e_hip.mean()), float(e_ref.mean()))
 
 
 def test_g11_scale_golden():
