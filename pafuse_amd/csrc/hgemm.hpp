@@ -418,6 +418,12 @@ __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, con
         const bool refill = kc + NSTAGE - 1 < nk;
         const int kn = kc + NSTAGE - 1, stn = kn % NSTAGE;
         const uint32_t sbase = lds0 + (uint32_t)((kc % NSTAGE) * T::STAGE_BYTES);
+#ifdef PAFUSE_HGEMM_BURST   // A/B build (tools/hgemm_bench.hip): the whole refill at the top of the chunk instead of piece by piece
+        if (refill) {
+#pragma unroll
+            for (int j = 0; j < CNT; ++j) issue_piece(kn, stn, j);
+        }
+#endif
         __builtin_amdgcn_s_setprio(1);
         constexpr int NG = NS2 * NT;          // groups (s2, nt) of three MFMAs on one accumulator
         u32x4 af[2][2], wf[2][2];             // [buffer][slice]: A fragment per 16-deep step, W' fragment per group
@@ -453,6 +459,7 @@ __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, con
             acc[nt] = mfma_f16_k16(w2, a_lo, acc[nt]);   // small terms first, the leading product last
             {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
                 constexpr int PER = (CNT + NG - 1) / NG, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
+#ifndef PAFUSE_HGEMM_BURST
                 if constexpr (j0 < j1) {
                     asm volatile("" ::: "memory");
                     if (refill) {
@@ -461,6 +468,7 @@ __device__ __forceinline__ void hgemm_tile(const GemmParams& p, const int b, con
                     }
                     asm volatile("" ::: "memory");
                 }
+#endif
             }
             PAFUSE_PIN_ACC(acc[nt]);
             acc[nt] = mfma_f16_k16(w1, a_hi, acc[nt]);
@@ -618,106 +626,18 @@ struct HfqaTile {
 };
 __device__ __forceinline__ int hfqa_swizzle(int row) { return (((row >> 1) & 3) << 1) ^ ((row >> 3) & 1); }
 
-template <int LP, int DP>
-__global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
-    PAFUSE_XQ_GUARD();
+// phases 2 and 3 of the fused kernel, shared by its two projection forms: the accumulators (token on the lane: lane (c, qd) of
+// wave w holds, for row blocks g = 0, 1, token 32 w + 16 g + c's outputs n = 16 nb + 4 qd + {0..3}) -> q | k | v tiles in LDS ->
+// attention per (sequence, 16-query tile) -> o as the H image.  The caller has passed a workgroup barrier behind its last use
+// of the LDS.
+template <int LP, int DP, class TokenOf>
+__device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4 (&acc)[2][3 * DP / 16], float* smem, const int64_t seq0,
+                                                      const int head, const int n0, const int wave, const int c, const int qd,
+                                                      const int tid, TokenOf token_of) {
     using FT = HfqaTile<LP, DP>;
-    constexpr int NB = FT::NB, LDV = FT::LDV, ROWS = FT::ROWS, IA = FT::IA, IW = FT::IW, CNT = FT::CNT, NSTAGE = FT::NSTAGE;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NB = FT::NB, LDV = FT::LDV, ROWS = FT::ROWS;
     const GemmParams& p = fp.g;
-    uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, qd = lane >> 4;
-    const int L = fp.L, NSEQ = fp.nseq_tile;
-    const int64_t ntiles = (fp.nseq + NSEQ - 1) / NSEQ;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int64_t tile = (int64_t)(idx / fp.heads) * 8 + xcd;
-    const int head = idx % fp.heads;
-    if (tile >= ntiles) return;   // (workgroup-uniform: the grid is padded to a multiple of 8 tiles)
-    const int K = p.K, nk = K / 32;
-    const int64_t seq0 = tile * NSEQ;
-    const int64_t last_seq = fp.nseq - 1;
-    // token (row of A / o) of tile row r: sequence seq0 + r / L, position r % L; rows of absent sequences alias the last one
-    auto token_of = [&](int r) -> int64_t {
-        int sl = r / L, t = r - sl * L;
-        if (sl >= NSEQ) sl = NSEQ - 1, t = L - 1;
-        int64_t sq = seq0 + sl;
-        if (sq > last_seq) sq = last_seq;
-        return (sq / fp.group) * fp.group_stride + (sq % fp.group) * fp.seq_stride + t * fp.tok_stride;
-    };
-
-    // ---- phase 1: the projection.  DMA instruction i of a chunk (0 .. IA + IW - 1) belongs to wave i % 4; A instruction ia
-    // covers tile rows 8 ia .. + 7 (lane l: row 8 ia + l / 8, LDS position l % 8), W instruction iw rows 8 iw .. of the head.
-    const int n0 = head * 3 * DP;
-    const uint8_t* src[CNT];
-#pragma unroll
-    for (int j = 0; j < CNT; ++j) {
-        int i = wave + 4 * j;
-        i = i < IA + IW ? i : IA + IW - 1;
-        const bool is_a = i < IA;
-        const int row = 8 * (is_a ? i : i - IA) + (lane >> 3);
-        const int slot = (lane & 7) ^ hfqa_swizzle(row);
-        src[j] = (is_a ? p.Ah + (size_t)token_of(row) * K * 4 : p.Wh + (size_t)(n0 + row) * K * 4) + slot * 16;
-    }
-    auto issue = [&](int kc, int st) {
-        uint8_t* const sa = lds + st * FT::STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < CNT; ++j) {
-            int i = wave + 4 * j;  // wave-uniform
-            i = i < IA + IW ? i : IA + IW - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)kc * 128),
-                                             (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
-        }
-    };
-    f32x4 acc[2][NB];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int sw = hfqa_swizzle(c);
-    const uint32_t pos0 = (uint32_t)(((2 * qd) ^ sw) & 7) * 16, pos1 = (uint32_t)(((2 * qd + 1) ^ sw) & 7) * 16;
-    const uint32_t a_row = (uint32_t)((32 * wave + c) * 128);         // + rb * 2048
-    const uint32_t w_row = (uint32_t)(FT::A_BYTES + c * 128);          // + nb * 2048
-    issue(0, 0);
-    for (int kc = 0; kc < nk; ++kc) {
-        wait_vmcnt<0>();                  // chunk kc of this wave has landed
-        __builtin_amdgcn_s_barrier();     // ... of every wave; every wave is done reading chunk kc - 1
-        if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
-        const uint32_t sbase = lds0 + (uint32_t)((kc & 1) * FT::STAGE_BYTES);
-        __builtin_amdgcn_s_setprio(1);
-        u32x4 af[2][2], wf[2][2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            af[g][0] = lds_read128<0>(sbase + a_row + g * 2048 + pos0);
-            af[g][1] = lds_read128<0>(sbase + a_row + g * 2048 + pos1);
-        }
-        wf[0][0] = lds_read128<0>(sbase + w_row + pos0);
-        wf[0][1] = lds_read128<0>(sbase + w_row + pos1);
-        static_for<NB>([&](auto N) {
-            constexpr int n = decltype(N)::value;
-            if constexpr (n + 1 < NB) {
-                wf[(n + 1) & 1][0] = lds_read128<(n + 1) * 2048>(sbase + w_row + pos0);
-                wf[(n + 1) & 1][1] = lds_read128<(n + 1) * 2048>(sbase + w_row + pos1);
-                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[n & 1][0]), "+v"(wf[n & 1][1]));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[n & 1][0]), "+v"(wf[n & 1][1]));
-            }
-            const f16x8 w0 = __builtin_bit_cast(f16x8, wf[n & 1][0]), w1 = __builtin_bit_cast(f16x8, wf[n & 1][1]);
-            const f16x8 w2 = w0 * (_Float16)0.00048828125f;   // 2^-11
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {   // small terms first, the leading product last
-                const f16x8 a_hi = __builtin_bit_cast(f16x8, af[g][0]), a_lo = __builtin_bit_cast(f16x8, af[g][1]);
-                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, a_lo, acc[g][n], 0, 0, 0);
-                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, a_hi, acc[g][n], 0, 0, 0);
-                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, a_hi, acc[g][n], 0, 0, 0);
-            }
-        });
-        __builtin_amdgcn_s_setprio(0);
-    }
-    __syncthreads();   // every wave is done with the ring: it becomes the q | k | v tiles
-
+    const int L = fp.L, NSEQ = fp.nseq_tile, K = p.K;
     // ---- phase 2: q | k | v of the tile's tokens to LDS (2^-k, bias or the folded LayerNorm applied)
     float* const Qs = smem;                    // [ROWS][LDV] each
     float* const Ks = Qs + ROWS * LDV;
@@ -839,6 +759,113 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
                 }
         }
     }
+}
+
+template <int LP, int DP>
+__global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
+    PAFUSE_XQ_GUARD();
+    using FT = HfqaTile<LP, DP>;
+    constexpr int NB = FT::NB, LDV = FT::LDV, ROWS = FT::ROWS, IA = FT::IA, IW = FT::IW, CNT = FT::CNT, NSTAGE = FT::NSTAGE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GemmParams& p = fp.g;
+    uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, qd = lane >> 4;
+    const int L = fp.L, NSEQ = fp.nseq_tile;
+    const int64_t ntiles = (fp.nseq + NSEQ - 1) / NSEQ;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int64_t tile = (int64_t)(idx / fp.heads) * 8 + xcd;
+    const int head = idx % fp.heads;
+    if (tile >= ntiles) return;   // (workgroup-uniform: the grid is padded to a multiple of 8 tiles)
+    const int K = p.K, nk = K / 32;
+    const int64_t seq0 = tile * NSEQ;
+    const int64_t last_seq = fp.nseq - 1;
+    // token (row of A / o) of tile row r: sequence seq0 + r / L, position r % L; rows of absent sequences alias the last one
+    auto token_of = [&](int r) -> int64_t {
+        int sl = r / L, t = r - sl * L;
+        if (sl >= NSEQ) sl = NSEQ - 1, t = L - 1;
+        int64_t sq = seq0 + sl;
+        if (sq > last_seq) sq = last_seq;
+        return (sq / fp.group) * fp.group_stride + (sq % fp.group) * fp.seq_stride + t * fp.tok_stride;
+    };
+
+    // ---- phase 1: the projection.  DMA instruction i of a chunk (0 .. IA + IW - 1) belongs to wave i % 4; A instruction ia
+    // covers tile rows 8 ia .. + 7 (lane l: row 8 ia + l / 8, LDS position l % 8), W instruction iw rows 8 iw .. of the head.
+    const int n0 = head * 3 * DP;
+    const uint8_t* src[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) {
+        int i = wave + 4 * j;
+        i = i < IA + IW ? i : IA + IW - 1;
+        const bool is_a = i < IA;
+        const int row = 8 * (is_a ? i : i - IA) + (lane >> 3);
+        const int slot = (lane & 7) ^ hfqa_swizzle(row);
+        src[j] = (is_a ? p.Ah + (size_t)token_of(row) * K * 4 : p.Wh + (size_t)(n0 + row) * K * 4) + slot * 16;
+    }
+    auto issue_piece = [&](int kc, int st, int j) {
+        uint8_t* const sa = lds + st * FT::STAGE_BYTES;
+        int i = wave + 4 * j;  // wave-uniform
+        i = i < IA + IW ? i : IA + IW - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)kc * 128),
+                                         (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
+    };
+    auto issue = [&](int kc, int st) {
+#pragma unroll
+        for (int j = 0; j < CNT; ++j) issue_piece(kc, st, j);
+    };
+    f32x4 acc[2][NB];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sw = hfqa_swizzle(c);
+    const uint32_t pos0 = (uint32_t)(((2 * qd) ^ sw) & 7) * 16, pos1 = (uint32_t)(((2 * qd + 1) ^ sw) & 7) * 16;
+    const uint32_t a_row = (uint32_t)((32 * wave + c) * 128);         // + rb * 2048
+    const uint32_t w_row = (uint32_t)(FT::A_BYTES + c * 128);          // + nb * 2048
+    issue(0, 0);
+    for (int kc = 0; kc < nk; ++kc) {
+        wait_vmcnt<0>();                  // chunk kc of this wave has landed
+        __builtin_amdgcn_s_barrier();     // ... of every wave; every wave is done reading chunk kc - 1
+        // the refill of the other stage, all of it at once: this phase is bound by the operand stream (one chunk in flight),
+        // and every cycle a piece waits for its issue slot behind MFMAs is a cycle the stream idles (spreading the pieces over
+        // the MFMA groups, as hgemm_tile does, cost 9 % here)
+        if (kc + 1 < nk) issue(kc + 1, (kc + 1) & 1);
+        const uint32_t sbase = lds0 + (uint32_t)((kc & 1) * FT::STAGE_BYTES);
+        __builtin_amdgcn_s_setprio(1);
+        u32x4 af[2][2], wf[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            af[g][0] = lds_read128<0>(sbase + a_row + g * 2048 + pos0);
+            af[g][1] = lds_read128<0>(sbase + a_row + g * 2048 + pos1);
+        }
+        wf[0][0] = lds_read128<0>(sbase + w_row + pos0);
+        wf[0][1] = lds_read128<0>(sbase + w_row + pos1);
+        static_for<NB>([&](auto N) {
+            constexpr int n = decltype(N)::value;
+            if constexpr (n + 1 < NB) {
+                wf[(n + 1) & 1][0] = lds_read128<(n + 1) * 2048>(sbase + w_row + pos0);
+                wf[(n + 1) & 1][1] = lds_read128<(n + 1) * 2048>(sbase + w_row + pos1);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[n & 1][0]), "+v"(wf[n & 1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(wf[n & 1][0]), "+v"(wf[n & 1][1]));
+            }
+            const f16x8 w0 = __builtin_bit_cast(f16x8, wf[n & 1][0]), w1 = __builtin_bit_cast(f16x8, wf[n & 1][1]);
+            const f16x8 w2 = w0 * (_Float16)0.00048828125f;   // 2^-11
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {   // small terms first, the leading product last
+                const f16x8 a_hi = __builtin_bit_cast(f16x8, af[g][0]), a_lo = __builtin_bit_cast(f16x8, af[g][1]);
+                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, a_lo, acc[g][n], 0, 0, 0);
+                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, a_hi, acc[g][n], 0, 0, 0);
+                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, a_hi, acc[g][n], 0, 0, 0);
+            }
+        });
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // every wave is done with the ring: it becomes the q | k | v tiles
+
+    hfqa_attention_phases<LP, DP>(fp, acc, smem, seq0, head, n0, wave, c, qd, tid, token_of);
 }
 
 }  // namespace pafuse

@@ -234,13 +234,13 @@ int hgemm_rowln(const GemmParams& p, hipStream_t s) {
     if (p.resid_h)   // the residual stream as its (centred) H image: the default of the folded-LayerNorm pipeline
         switch (p.N) {
             case 384: return launch_hgemm<4, 2, 6, EPI_ROWLN, 2, 32, 1, true>(p, s);
-            case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2, true>(p, s);
+            case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 32, 2, true>(p, s);
             case 224: return launch_hgemm<4, 1, 7, EPI_ROWLN, 3, 16, 2, true>(p, s);
             default: break;
         }
     switch (p.N) {
         case 384: return launch_hgemm<4, 2, 6, EPI_ROWLN, 2, 32, 1>(p, s);   // 128 rows, eight waves, 128 KB ring: one per CU
-        case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2>(p, s);   // 64 rows, four waves, three per CU
+        case 256: return launch_hgemm<2, 2, 4, EPI_ROWLN, 2, 32, 2>(p, s);   // 64 rows, four waves, 32-deep chunks, two per CU
         case 224: return launch_hgemm<4, 1, 7, EPI_ROWLN, 3, 16, 2>(p, s);   // 128 rows, four waves (7 column blocks do not split), two per CU
         default: return fail(PAFUSE_E_SHAPE, "no f16x2 whole-row kernel for channel width %d (have 224, 256, 384)", p.N);
     }

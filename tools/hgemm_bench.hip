@@ -16,7 +16,7 @@ using namespace pafuse;
 static const char* g_filter = nullptr;
 static int g_reps = 20;
 
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW>
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW, bool HRES = (EPI == EPI_ROWLN)>
 void run(const char* shape, GemmParams p) {
     using T = HTile<WM, WN, NT, BKC>;
     char tag[160];
@@ -24,7 +24,7 @@ void run(const char* shape, GemmParams p) {
     if (g_filter && !strstr(tag, g_filter)) return;
     if (p.N % T::BN) { printf("%s: N %% BN != 0, skipped\n", tag); return; }
     const size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
-    auto k = hgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW>;
+    auto k = hgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW, HRES>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     const size_t nw = tiles * (T::NTHR / 64);
@@ -116,29 +116,29 @@ int main() {
             const int K = layer == 0 ? C : 2 * C;
             images(C, K);
             GemmParams q{};
-            q.Ah = Ah, q.Wh = Wh, q.bias = vec, q.resid = x, q.out_x = x, q.out_xh = xh, q.ln_stats = stats;
+            q.Ah = Ah, q.Wh = Wh, q.bias = vec, q.resid_h = xh, q.out_xh = xh, q.ln_stats = stats;   // the production form: H-image residual in place
             q.post_w = layer ? vec + 400 : nullptr, q.post_b = vec + 800, q.post_eps = 1e-6f, q.next_w = vec + 1200, q.next_b = vec + 1600, q.next_eps = 1e-6f;
             q.M = pt.M, q.N = C, q.K = K, q.bf16 = 3;
             snprintf(shape, sizeof shape, "%s %s", pt.name, layer == 0 ? "proj" : "fc2");
             if (C == 384 && getenv("HB_ABLATE")) {   // where the whole-row epilogue's cycles go (results wrong by design)
                 char sh2[96];
-                { GemmParams a = q; a.out_xh = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no H image", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
-                { GemmParams a = q; a.out_xh = nullptr; a.out_x = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no stores", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
-                { GemmParams a = q; a.out_xh = nullptr; a.out_x = nullptr; a.next_w = nullptr; a.post_w = nullptr; snprintf(sh2, sizeof sh2, "%s ABL resid only", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
-                { GemmParams a = q; a.next_w = nullptr; a.post_w = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no LN / stats", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
+                { GemmParams a = q; a.out_xh = nullptr; snprintf(sh2, sizeof sh2, "%s ABL no store", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
+                { GemmParams a = q; a.out_xh = nullptr; a.next_w = nullptr; a.post_w = nullptr; snprintf(sh2, sizeof sh2, "%s ABL resid only", shape); run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(sh2, a); }
             }
             if (C == 384) {
                 run<4, 2, 6, EPI_ROWLN, 2, 32, 1>(shape, q);
                 run<4, 2, 6, EPI_ROWLN, 3, 16, 1>(shape, q);
                 run<2, 2, 6, EPI_ROWLN, 2, 16, 2>(shape, q);
                 run<2, 2, 6, EPI_ROWLN, 2, 32, 1>(shape, q);
-                run<3, 2, 6, EPI_ROWLN, 2, 16, 1>(shape, q);
+                run<2, 2, 6, EPI_ROWLN, 3, 16, 2>(shape, q);
+                run<4, 2, 6, EPI_ROWLN, 2, 16, 2>(shape, q);
             } else if (C == 256) {
                 run<4, 2, 4, EPI_ROWLN, 3, 32, 1>(shape, q);
                 run<4, 2, 4, EPI_ROWLN, 2, 16, 2>(shape, q);
                 run<2, 2, 4, EPI_ROWLN, 2, 16, 2>(shape, q);
                 run<2, 2, 4, EPI_ROWLN, 3, 16, 3>(shape, q);
                 run<2, 2, 4, EPI_ROWLN, 2, 32, 2>(shape, q);
+                run<4, 2, 4, EPI_ROWLN, 2, 16, 2>(shape, q);
             } else {
                 run<4, 1, 7, EPI_ROWLN, 3, 16, 2>(shape, q);
                 run<4, 1, 7, EPI_ROWLN, 2, 16, 2>(shape, q);
