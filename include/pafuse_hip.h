@@ -77,6 +77,14 @@ typedef struct pafuse_block_weights {
      * attention as the two kernels. */
     const void *qkv_hs;
     const float *qkv_hb, *qkv_hl;
+    /* f16x2 mode with the LayerNorm folded, optional: fc1 -> GELU -> fc2 (+ residual, + the LayerNorms behind it) of a block in
+     * ONE kernel (hmlp_kernel: the hidden activations [M, 2C] stay in registers, common/mixste.py:37-43,115).  fc2_hp is the
+     * PAFUSE_SPLIT_F16X2 image of fc2.weight with its columns (hidden units) re-ordered inside every group of 16:
+     *   column 16 b + 8 h + i of the image = column 16 b + 8 (i >> 2) + 4 h + (i & 3) of the weight   (h = 0, 1; i = 0 .. 7)
+     * - the order in which the first layer's accumulators hold a token's hidden units.  Used when set, the channel width is
+     * 224 / 256 / 384, the hidden width 2C and the residual stream is kept as its H image only (keep_f32_residual == 0);
+     * otherwise the block runs the two launches from fc1_ws / fc2_ws.  Same products, same K order between 16-deep steps. */
+    const void *fc2_hp;
 } pafuse_block_weights;
 
 /* One MixSTE2 (common/mixste.py:141-210): F frames, J joints of this part, C channels, `depth` spatial +
@@ -193,6 +201,15 @@ int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, f
 int pafuse_hsplit_rows(const float *X, int64_t R, int32_t K, void *out, void *stream);
 int pafuse_linear_h(const void *Ah, const void *Wh, const float *bias, float *out, void *out_h, int64_t M, int32_t N, int32_t K,
                     int32_t act, void *stream);
+
+/* The MLP of a block on H images in one kernel (the unit entry of hmlp_kernel; common/mixste.py:37-43,115 with norm2 folded):
+ *   y = xc + GELU(rstd * (xc W1^T) + bias1) W2^T + bias2,   xc = the rows of `xh` (the CENTRED image of the residual stream),
+ *   rstd = stats_in[2 m + 1] (NULL: 1);  out_xh = the H image of y - mean(y),  stats_out[m] = (mean(y), 1 / sqrt(var(y) + eps)).
+ * W1h: the PAFUSE_SPLIT_F16X2 image of fc1.weight [2C, C] (of W1 (.) g for a folded LayerNorm, bias1 = W1 beta + b1);
+ * W2hp: the image of fc2.weight [C, 2C] in the column order of pafuse_block_weights.fc2_hp.  C = 224, 256 or 384.
+ * out_xh may be xh itself (a workgroup owns its rows). */
+int pafuse_mlp_h(const void *xh, const float *stats_in, const void *W1h, const float *bias1, const void *W2hp, const float *bias2,
+                 void *out_xh, float *stats_out, int64_t M, int32_t C, float eps, void *stream);
 
 /* out[M,C] = LayerNorm(x[M,C]) * w + b  (biased variance, eps inside the sqrt). */
 int pafuse_layernorm(const float *x, const float *w, const float *b, float *out, int64_t M, int32_t C, float eps,

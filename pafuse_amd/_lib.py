@@ -24,7 +24,7 @@ class BlockWeights(C.Structure):
               "norm2_w", "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
               "qkv_ws", "proj_ws", "fc1_ws", "fc2_ws",
               "qkv_ls", "qkv_lt", "fc1_ls", "fc1_lt",
-              "qkv_hs", "qkv_hb", "qkv_hl")
+              "qkv_hs", "qkv_hb", "qkv_hl", "fc2_hp")
     _fields_ = [(n, C.c_void_p) for n in _names]
 
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     "pafuse_hsplit_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "pafuse_linear_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "pafuse_mlp_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "pafuse_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,
                                    C.c_void_p]),
     "pafuse_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

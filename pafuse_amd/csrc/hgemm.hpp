@@ -615,10 +615,10 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) hgemm_kernel(const GemmPara
 // Blocks: b -> XCD x = b & 7, (tile, head) = ((b >> 3) / heads * 8 + x, (b >> 3) % heads): the eight heads of a tile run on
 // one XCD (its A rows are L2 hits for seven of them).
 // ----------------------------------------------------------------------------------------------------------------
-template <int LP, int DP>
+template <int LP, int DP, int HPW = 1>   // HPW: heads per workgroup (their projections share the A stream, their attention phases run in turn)
 struct HfqaTile {
-    static constexpr int NB = 3 * DP / 16, LDV = DP + 4, ROWS = 128 + (LP == 48 ? 4 : 0), NSTAGE = 2;
-    static constexpr int A_BYTES = 128 * 128, W_BYTES = 3 * DP * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int NBH = 3 * DP / 16, NB = HPW * NBH, LDV = DP + 4, ROWS = 128 + (LP == 48 ? 4 : 0), NSTAGE = 2;
+    static constexpr int A_BYTES = 128 * 128, W_BYTES = HPW * 3 * DP * 128, STAGE_BYTES = A_BYTES + W_BYTES;
     static constexpr int IA = A_BYTES / 1024, IW = W_BYTES / 1024, CNT = (IA + IW + 3) / 4;
     static constexpr int QKV_BYTES = 3 * ROWS * LDV * 4;
     static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES > QKV_BYTES ? NSTAGE * STAGE_BYTES : QKV_BYTES;
@@ -635,7 +635,7 @@ __device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4
                                                       const int head, const int n0, const int wave, const int c, const int qd,
                                                       const int tid, TokenOf token_of) {
     using FT = HfqaTile<LP, DP>;
-    constexpr int NB = FT::NB, LDV = FT::LDV, ROWS = FT::ROWS;
+    constexpr int NB = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS;
     const GemmParams& p = fp.g;
     const int L = fp.L, NSEQ = fp.nseq_tile, K = p.K;
     // ---- phase 2: q | k | v of the tile's tokens to LDS (2^-k, bias or the folded LayerNorm applied)
@@ -761,11 +761,11 @@ __device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4
     }
 }
 
-template <int LP, int DP>
+template <int LP, int DP, int HPW>
 __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
     PAFUSE_XQ_GUARD();
-    using FT = HfqaTile<LP, DP>;
-    constexpr int NB = FT::NB, LDV = FT::LDV, ROWS = FT::ROWS, IA = FT::IA, IW = FT::IW, CNT = FT::CNT, NSTAGE = FT::NSTAGE;
+    using FT = HfqaTile<LP, DP, HPW>;
+    constexpr int NB = FT::NB, NBH = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS, IA = FT::IA, IW = FT::IW, CNT = FT::CNT, NSTAGE = FT::NSTAGE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GemmParams& p = fp.g;
     uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
@@ -776,8 +776,9 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
     const int L = fp.L, NSEQ = fp.nseq_tile;
     const int64_t ntiles = (fp.nseq + NSEQ - 1) / NSEQ;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int64_t tile = (int64_t)(idx / fp.heads) * 8 + xcd;
-    const int head = idx % fp.heads;
+    const int hgroups = fp.heads / HPW;                      // workgroups per tile
+    const int64_t tile = (int64_t)(idx / hgroups) * 8 + xcd;
+    const int head0 = (idx % hgroups) * HPW;                 // this workgroup's heads: head0 .. head0 + HPW - 1
     if (tile >= ntiles) return;   // (workgroup-uniform: the grid is padded to a multiple of 8 tiles)
     const int K = p.K, nk = K / 32;
     const int64_t seq0 = tile * NSEQ;
@@ -793,7 +794,7 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
 
     // ---- phase 1: the projection.  DMA instruction i of a chunk (0 .. IA + IW - 1) belongs to wave i % 4; A instruction ia
     // covers tile rows 8 ia .. + 7 (lane l: row 8 ia + l / 8, LDS position l % 8), W instruction iw rows 8 iw .. of the head.
-    const int n0 = head * 3 * DP;
+    const int n0 = head0 * 3 * DP;
     const uint8_t* src[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
@@ -815,11 +816,13 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j) issue_piece(kc, st, j);
     };
-    f32x4 acc[2][NB];
+    f32x4 acc[HPW][2][NBH];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
-        for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int n = 0; n < NBH; ++n) acc[hh][g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int sw = hfqa_swizzle(c);
     const uint32_t pos0 = (uint32_t)(((2 * qd) ^ sw) & 7) * 16, pos1 = (uint32_t)(((2 * qd + 1) ^ sw) & 7) * 16;
     const uint32_t a_row = (uint32_t)((32 * wave + c) * 128);         // + rb * 2048
@@ -856,16 +859,302 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {   // small terms first, the leading product last
                 const f16x8 a_hi = __builtin_bit_cast(f16x8, af[g][0]), a_lo = __builtin_bit_cast(f16x8, af[g][1]);
-                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, a_lo, acc[g][n], 0, 0, 0);
-                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, a_hi, acc[g][n], 0, 0, 0);
-                acc[g][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, a_hi, acc[g][n], 0, 0, 0);
+                f32x4& d = acc[n / NBH][g][n % NBH];
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, a_lo, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, a_hi, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, a_hi, d, 0, 0, 0);
             }
         });
         __builtin_amdgcn_s_setprio(0);
     }
-    __syncthreads();   // every wave is done with the ring: it becomes the q | k | v tiles
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh) {
+        __syncthreads();   // every wave is done with the ring / the tiles of the head before: the LDS becomes this head's q | k | v tiles
+        hfqa_attention_phases<LP, DP>(fp, acc[hh], smem, seq0, head0 + hh, n0 + hh * 3 * DP, wave, c, qd, tid, token_of);
+    }
+}
 
-    hfqa_attention_phases<LP, DP>(fp, acc, smem, seq0, head, n0, wave, c, qd, tid, token_of);
+
+// ----------------------------------------------------------------------------------------------------------------
+// The MLP of a block in ONE kernel, H pipeline (round 4):
+//   x <- epilogue(x + GELU(LNfold(x) W1^T + b1) W2^T + b2)        (common/mixste.py:37-43,115: fc1 -> GELU -> fc2 -> + residual)
+// replaces the fc1 hgemm launch + the fc2 whole-row launch and the [M, 2C] hidden H image between them (8 C bytes per token
+// written and read back: 28 % of the bytes a block still moves once qkv + attention are fused).
+// Workgroup = 4 waves = 128 tokens x all C channels; wave w owns tokens 32 w .. 32 w + 31 through BOTH layers.  The hidden
+// activations never leave the registers: with the weight fragment as the MFMA's first operand the accumulator of
+//   phase 1   acc1[nt1] = W1[slab rows 32 nt1 ..] . x^T     lane (r, h): token r, hidden units 8 q + 4 h + {0..3}, q = 0 .. 3
+// is, after bias / folded LayerNorm, GELU and the hi / lo split, exactly a B operand of the next MFMA
+//   phase 2   acc2[nt2] += W2[rows 32 nt2 .., 16 k-slots] . h^T     lane (r, h) supplies 8 k-slots of token r
+// if k-slot (h, i) of the 16-deep step s of column block nt1 is taken to be hidden unit 32 nt1 + 16 s + 8 (i >> 2) + 4 h + (i & 3)
+// - a permutation inside each group of 16 hidden units that the fc2 weight image carries in its column order
+// (pafuse_block_weights.fc2_hp: the H image of W2[:, perm]; the two operands of a product only have to agree on the slot).
+// Loop: hidden slabs of 64 units (NT1 = 2 column blocks per wave); per slab  [phase 1: C / 32 chunks of 32 k: A 128 x 128 B +
+// W1 64 x 128 B]  [phase 2: 4 stages of 16 k-slots: W2 C x 64 B], all through ONE ring of three 24 KB slots fed by LDS-DMA two
+// stages ahead (the A tile is re-streamed from L2 for every slab: 128 x 4 C bytes against 2 x 64 x 4 C of weights).  Two
+// workgroups per CU.  acc2 (C / 2 registers) lives through the whole loop; the whole-row epilogue is hgemm's.
+// ----------------------------------------------------------------------------------------------------------------
+struct MlpParams {
+    GemmParams g;            // the fc2 launch's parameters: Ah = fc1's operand (the centred H image of x), Wh = fc2_hp, bias = b2,
+    //                          resid_h / out_xh / ln_stats / post / next / head as for hgemm's whole-row epilogue; N = C, K = 2 C
+    const uint8_t* W1h;      // H image of fc1.weight (of W1 (.) g with the LayerNorm folded) [2C][C]
+    const float* bias1;      // [2C] fc1 bias (folded: lt)
+    const float* ln_in;      // folded LayerNorm in front of fc1: (mean, rstd) per row - the image is centred, only rstd is used - or null
+};
+
+template <int NT2>
+struct MlpTile {
+    static constexpr int C = 32 * NT2, HID = 2 * C, NSLAB = HID / 64, NK1 = C / 32;
+    static constexpr int SLOT = 24 * 1024, NSLOT = 3, RING = SLOT * NSLOT;
+    static constexpr int CNT1 = 6;                       // phase-1 stage: 16 A + 8 W1 DMA instructions over 4 waves
+    static constexpr int P2_PIECES = C * 64 / 1024, CNT2 = (P2_PIECES + 3) / 4;
+    static constexpr int LDS_BYTES = RING + HID * 4;     // + the fc1 bias vector
+    static_assert(C * 64 <= SLOT && CNT2 <= CNT1, "a phase-2 stage must fit a ring slot");
+};
+
+template <int NT2, int MINW>
+__global__ void __launch_bounds__(256, MINW) hmlp_kernel(const MlpParams mp) {
+    PAFUSE_XQ_GUARD();
+    using T = MlpTile<NT2>;
+    constexpr int C = T::C, HID = T::HID, NSLAB = T::NSLAB, NK1 = T::NK1, CNT1 = T::CNT1, CNT2 = T::CNT2, SLOT = T::SLOT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const GemmParams& p = mp.g;
+    uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;
+    float* const b1s = smem + T::RING / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int tile;
+    {   // XCD-aware tile order (speed only), as hgemm_tile
+        const int b = blockIdx.x, nb = gridDim.x;
+        const int xcd = b & 7, q = nb >> 3, rem = nb & 7;
+        tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const int64_t m0 = (int64_t)tile * 128;
+    if (m0 >= p.M) return;
+    PAFUSE_STAMP(0);
+
+    // ---- DMA sources (lane-constant parts).  Phase-1 stage: instruction i = wave + 4 j; j < 4: A rows 8 i .. (128-byte rows,
+    // lane l: row 8 i + l / 8, LDS position l % 8, source slot position ^ ((row >> 1) & 7)); j = 4, 5: W1 rows 8 (i - 16) .. of the
+    // slab.  Phase-2 stage: instruction i = wave + 4 j < P2_PIECES (surplus slots re-issue the last one): W2 rows 16 i .. (64-byte
+    // rows, lane l: row 16 i + l / 4, position l % 4, source slot position ^ ((row >> 2) & 3)).
+    const uint8_t* const Abase = p.Ah + (size_t)m0 * C * 4;
+    int a_off[4], w1_off[2], w2_off[CNT2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wave + 4 * j) + (lane >> 3);
+        const int64_t lim = p.M - 1 - m0;
+        const int grow = row < lim ? row : (int)lim;     // tail rows read a valid row (never stored)
+        a_off[j] = grow * C * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 8 * (wave + 4 * j) + (lane >> 3);     // 0 .. 63 inside the slab
+        w1_off[j] = row * C * 4 + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < CNT2; ++j) {
+        int i = wave + 4 * j;
+        i = i < T::P2_PIECES ? i : T::P2_PIECES - 1;
+        const int row = 16 * i + (lane >> 2);
+        w2_off[j] = row * HID * 4 + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
+    }
+    // stage (slab, idx): idx < NK1: phase-1 chunk idx; else phase-2 stage idx - NK1.  Piece j of it into ring slot `slot`.
+    auto issue_piece = [&](auto J, int slab, int idx, int slot) {
+        constexpr int j = decltype(J)::value;
+#if defined(PAFUSE_HMLP_ABL) && (PAFUSE_HMLP_ABL & 2)   // diagnostic: no operand stream (the compute side alone, on whatever the LDS holds)
+        return;
+#endif
+        uint8_t* const dst = lds + slot * SLOT;
+        if (idx < NK1) {      // workgroup-uniform
+            if constexpr (j < 4) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Abase + a_off[j] + idx * 128),
+                                                 (__attribute__((address_space(3))) void*)(dst + (wave + 4 * j) * 1024), 16, 0, 0);
+            } else if constexpr (j < 6) {
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(mp.W1h + (size_t)slab * 64 * C * 4 + w1_off[j - 4] + idx * 128),
+                    (__attribute__((address_space(3))) void*)(dst + (16 + wave + 4 * (j - 4)) * 1024), 16, 0, 0);
+            }
+        } else {
+            if constexpr (j < CNT2) {
+                int i = wave + 4 * j;
+                i = i < T::P2_PIECES ? i : T::P2_PIECES - 1;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(p.Wh + w2_off[j] + (slab * 64 + (idx - NK1) * 16) * 4),
+                    (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // the producer's position: the next stage to issue
+    int pslab = 0, pidx = 0, pslot = 0;
+    auto advance = [&]() {
+        pidx = pidx + 1 == NK1 + 4 ? 0 : pidx + 1;
+        pslab += pidx == 0;
+        pslot = pslot == 2 ? 0 : pslot + 1;
+    };
+    // fc1 bias -> LDS; this lane's row factor rstd * 2^-k1
+    for (int i = tid; i < HID / 4; i += 256) *reinterpret_cast<f32x4*>(b1s + 4 * i) = *reinterpret_cast<const f32x4*>(mp.bias1 + 4 * i);
+    float rs1 = *reinterpret_cast<const float*>(mp.W1h + (size_t)HID * C * 4);
+    {
+        const int64_t m = m0 + 32 * wave + r;
+        if (mp.ln_in) rs1 *= mp.ln_in[2 * (m < p.M ? m : p.M - 1) + 1];
+    }
+    wait_vmcnt<0>();   // (nothing but LDS-DMA may be in flight inside the loop: its waits count instructions)
+    asm volatile("" : "+v"(rs1));
+    __syncthreads();   // the bias vector is in place for every wave
+    static_for<CNT1>([&](auto J) { issue_piece(J, 0, 0, 0); });
+    static_for<CNT1>([&](auto J) { issue_piece(J, 0, 1, 1); });
+    pidx = 2, pslot = 2;
+    static_assert(NK1 >= 2, "two phase-1 chunks open the ring");
+
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[nt][i] = 0.f;
+
+    // fragment positions: phase 1, 128-byte rows (slot 2 (2 s2 + h) + slice, swizzle (r >> 1) & 7); phase 2, 64-byte rows
+    // (slot 2 h + slice, swizzle (r >> 2) & 3)
+    const int sw7 = (r >> 1) & 7, sw3 = (r >> 2) & 3;
+    uint32_t pos1[2][2], pos2[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) pos1[s2][sl] = (uint32_t)(((2 * (2 * s2 + h) + sl) ^ sw7) & 7) * 16;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) pos2[sl] = (uint32_t)(((2 * h + sl) ^ sw3) & 3) * 16;
+    const uint32_t a_row = (uint32_t)((wave * 32 + r) * 128);
+    const uint32_t w1_row = (uint32_t)(16 * 1024 + r * 128);     // + nt1 * 32 * 128
+    const uint32_t w2_row = (uint32_t)(r * 64);                  // + nt2 * 32 * 64
+
+    int cslot = 0;                                  // the consumer's ring slot
+    int left = NSLAB * (NK1 + 4);                   // stages not yet consumed
+    // top of a stage: its pieces have landed (the next stage's - CNT1 or CNT2 per wave, whichever it is - may still fly), every
+    // wave is past the stage before; then the refill two stages ahead goes out piece by piece behind the first MFMAs
+    auto open_stage = [&](bool next_is_p1) {
+        if (left == 1) wait_vmcnt<0>();
+        else if (next_is_p1) wait_vmcnt<CNT1>();
+        else wait_vmcnt<CNT2>();
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int slab = 0; slab < NSLAB; ++slab) {
+        f32x16 acc1[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc1[nt][i] = 0.f;
+        // ---- phase 1: acc1 = W1[slab] . x^T over the C input channels
+        for (int kc = 0; kc < NK1; ++kc) {
+            open_stage(kc + 1 < NK1);
+            if (slab == 0 && kc == 0) { PAFUSE_STAMP(3); }
+            const bool refill = left > 2;
+            const uint32_t sbase = lds0 + (uint32_t)(cslot * SLOT);
+            __builtin_amdgcn_s_setprio(1);
+            u32x4 af[2][2], wf[2][2];
+            af[0][0] = lds_read128<0>(sbase + a_row + pos1[0][0]);
+            af[0][1] = lds_read128<0>(sbase + a_row + pos1[0][1]);
+            wf[0][0] = lds_read128<0>(sbase + w1_row + pos1[0][0]);
+            wf[0][1] = lds_read128<0>(sbase + w1_row + pos1[0][1]);
+            static_for<4>([&](auto G) {
+                constexpr int g = decltype(G)::value, s2 = g >> 1, nt = g & 1;
+                constexpr bool next_a = g == 1;
+                if constexpr (next_a) {
+                    af[1][0] = lds_read128<0>(sbase + a_row + pos1[1][0]);
+                    af[1][1] = lds_read128<0>(sbase + a_row + pos1[1][1]);
+                }
+                if constexpr (g + 1 < 4) {
+                    constexpr int s2n = (g + 1) >> 1, off = ((g + 1) & 1) * 32 * 128;
+                    wf[(g + 1) & 1][0] = lds_read128<off>(sbase + w1_row + pos1[s2n][0]);
+                    wf[(g + 1) & 1][1] = lds_read128<off>(sbase + w1_row + pos1[s2n][1]);
+                }
+                if constexpr (next_a)
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af[s2][0]), "+v"(af[s2][1]), "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]));
+                else if constexpr (g + 1 < 4)
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[s2][0]), "+v"(af[s2][1]), "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[s2][0]), "+v"(af[s2][1]), "+v"(wf[g & 1][0]), "+v"(wf[g & 1][1]));
+                const f16x8 w0 = __builtin_bit_cast(f16x8, wf[g & 1][0]), w1 = __builtin_bit_cast(f16x8, wf[g & 1][1]);
+                const f16x8 w2 = w0 * (_Float16)0.00048828125f;   // 2^-11
+                const f16x8 a_hi = __builtin_bit_cast(f16x8, af[s2][0]), a_lo = __builtin_bit_cast(f16x8, af[s2][1]);
+                acc1[nt] = mfma_f16_k16(w2, a_lo, acc1[nt]);   // small terms first, the leading product last
+                if (refill) {   // two pieces of the refill per group (CNT1, CNT2 <= 6 < 8)
+                    issue_piece(std::integral_constant<int, 2 * g>{}, pslab, pidx, pslot);
+                    issue_piece(std::integral_constant<int, 2 * g + 1>{}, pslab, pidx, pslot);
+                }
+                acc1[nt] = mfma_f16_k16(w1, a_hi, acc1[nt]);
+                acc1[nt] = mfma_f16_k16(w0, a_hi, acc1[nt]);
+            });
+            __builtin_amdgcn_s_setprio(0);
+            if (refill) advance();
+            cslot = cslot == 2 ? 0 : cslot + 1;
+            --left;
+        }
+        // ---- phase 2: the slab's 64 hidden units as four 16-deep steps of fc2
+        static_for<4>([&](auto JJ) {
+            constexpr int jj = decltype(JJ)::value, nt1 = jj >> 1, s = jj & 1;
+            open_stage(jj == 3);   // (the stage behind the slab's last one is the next slab's first phase-1 chunk)
+            const bool refill = left > 2;
+            const uint32_t sbase = lds0 + (uint32_t)(cslot * SLOT);
+            u32x4 wf[2][2];
+            wf[0][0] = lds_read128<0>(sbase + w2_row + pos2[0]);
+            wf[0][1] = lds_read128<0>(sbase + w2_row + pos2[1]);
+            // this lane's 8 hidden values of the step: registers 4 q + e, q = 2 s, 2 s + 1 -> k-slots 4 (q - 2 s) + e
+            f32x4 v[2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * s + qq;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1s + slab * 64 + 32 * nt1 + 8 * q + 4 * h);
+#pragma unroll
+#if defined(PAFUSE_HMLP_ABL) && (PAFUSE_HMLP_ABL & 1)   // diagnostic builds of tools/hgemm_bench.hip: no GELU (results wrong by design)
+                for (int e = 0; e < 4; ++e) v[qq][e] = fmaf(rs1, acc1[nt1][4 * q + e], b4[e]);
+#else
+                for (int e = 0; e < 4; ++e) v[qq][e] = gelu_erf(fmaf(rs1, acc1[nt1][4 * q + e], b4[e]));
+#endif
+            }
+            const f16x8x2 hf = split2h(v[0], v[1]);
+            __builtin_amdgcn_s_setprio(1);
+            static_for<NT2>([&](auto N) {
+                constexpr int nt = decltype(N)::value;
+                if constexpr (nt + 1 < NT2) {
+                    wf[(nt + 1) & 1][0] = lds_read128<(nt + 1) * 32 * 64>(sbase + w2_row + pos2[0]);
+                    wf[(nt + 1) & 1][1] = lds_read128<(nt + 1) * 32 * 64>(sbase + w2_row + pos2[1]);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wf[nt & 1][0]), "+v"(wf[nt & 1][1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[nt & 1][0]), "+v"(wf[nt & 1][1]));
+                }
+                const f16x8 w0 = __builtin_bit_cast(f16x8, wf[nt & 1][0]), w1 = __builtin_bit_cast(f16x8, wf[nt & 1][1]);
+                const f16x8 w2 = w0 * (_Float16)0.00048828125f;
+                acc2[nt] = mfma_f16_k16(w2, hf.lo, acc2[nt]);
+                if constexpr (nt < CNT1) {
+                    if (refill) issue_piece(std::integral_constant<int, nt>{}, pslab, pidx, pslot);
+                }
+                acc2[nt] = mfma_f16_k16(w1, hf.hi, acc2[nt]);
+                acc2[nt] = mfma_f16_k16(w0, hf.hi, acc2[nt]);
+            });
+            __builtin_amdgcn_s_setprio(0);
+            if (refill) advance();
+            cslot = cslot == 2 ? 0 : cslot + 1;
+            --left;
+        });
+    }
+    PAFUSE_STAMP(1);
+    __syncthreads();   // the ring becomes the epilogue's scratch
+    const float ws2 = *reinterpret_cast<const float*>(p.Wh + (size_t)C * HID * 4);
+    {
+        constexpr int VEC = (7 * 128 + 3) / 4 * 4;
+        constexpr size_t RINGF = T::RING / sizeof(float);
+        constexpr auto need = [](int nth) { return (size_t)VEC + 5 * C + (size_t)4 * 32 * (32 * nth + 4); };
+        constexpr int NTH = (NT2 % 2 == 0 && need(2) <= RINGF) ? 2 : 1;
+        static_assert(need(NTH) <= RINGF, "epilogue scratch must fit the ring");
+        const float* const src[5] = {p.bias, p.post_w, p.post_b, p.next_w, p.next_b};
+#pragma unroll
+        for (int v = 0; v < 5; ++v)
+            if (src[v])
+                for (int i = tid; i < C / 4; i += 256)
+                    *reinterpret_cast<f32x4*>(smem + VEC + v * C + 4 * i) = *reinterpret_cast<const f32x4*>(src[v] + 4 * i);
+        __syncthreads();
+        epilogue_rows_h<1, NT2, 128, 4, NTH, true>(acc2, p, m0, 0, wave, 0, r, h, wave, lane, smem, ws2);
+    }
 }
 
 }  // namespace pafuse

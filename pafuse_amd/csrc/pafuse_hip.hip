@@ -125,18 +125,19 @@ static bool fqa_has(int L, int d) {   // (48, 48) would need 80.4 KB of LDS: one
 }
 
 // the same decomposition in the f16x2 H pipeline (hgemm.hpp hfqa_kernel): A and the head-major weight as H images, o as H image
-template <int LP, int DP>
+template <int LP, int DP, int HPW>
 int launch_hfqa(const FqaParams& f, hipStream_t s) {
-    using FT = HfqaTile<LP, DP>;
+    using FT = HfqaTile<LP, DP, HPW>;
     static_assert(FT::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
-    auto k = hfqa_kernel<LP, DP>;
+    if (f.heads % HPW) return fail(PAFUSE_E_SHAPE, "fused qkv-attention: %d heads do not split into groups of %d", f.heads, HPW);
+    auto k = hfqa_kernel<LP, DP, HPW>;
     if (FT::LDS_BYTES > 64 * 1024) {
         static DeviceOnce once;
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
     }
     if (!f.g.Ah || !f.g.Wh) return fail(PAFUSE_E_ARG, "fused qkv-attention (f16x2) without the H images of its operands");
     const int64_t ntiles = (f.nseq + f.nseq_tile - 1) / f.nseq_tile;
-    const int64_t blocks = (ntiles + 7) / 8 * 8 * f.heads;
+    const int64_t blocks = (ntiles + 7) / 8 * 8 * (f.heads / HPW);
     if (blocks <= 0 || blocks > 0x7fffffff) return fail(PAFUSE_E_ARG, "fused qkv-attention grid out of range");
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), FT::LDS_BYTES, s, f);
     return check_launch("hfqa_kernel");
@@ -146,15 +147,44 @@ int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
     if (f.nseq <= 0) return PAFUSE_OK;
     const int lp = fqa_lp(f.L), dp = fqa_dp(f.d);
     if (f.g.bf16 == 3) {
-        if (lp == 32 && dp == 48) return launch_hfqa<32, 48>(f, s);
-        if (lp == 32 && dp == 32) return launch_hfqa<32, 32>(f, s);
-        if (lp == 48 && dp == 32) return launch_hfqa<48, 32>(f, s);
+        // head dim <= 32: two heads per workgroup share the A stream (the ring grows to the 80 KB two workgroups per CU allow)
+        if (lp == 32 && dp == 48) return launch_hfqa<32, 48, 1>(f, s);
+        if (lp == 32 && dp == 32) return f.heads % 2 ? launch_hfqa<32, 32, 1>(f, s) : launch_hfqa<32, 32, 2>(f, s);
+        if (lp == 48 && dp == 32) return f.heads % 2 ? launch_hfqa<48, 32, 1>(f, s) : launch_hfqa<48, 32, 2>(f, s);
         return fail(PAFUSE_E_SHAPE, "fused qkv-attention: no kernel for L=%d, d=%d", f.L, f.d);
     }
     if (lp == 32 && dp == 48) return launch_fqa<32, 48>(f, s);
     if (lp == 32 && dp == 32) return launch_fqa<32, 32>(f, s);
     if (lp == 48 && dp == 32) return launch_fqa<48, 32>(f, s);
     return fail(PAFUSE_E_SHAPE, "fused qkv-attention: no kernel for L=%d, d=%d", f.L, f.d);
+}
+
+// fc1 -> GELU -> fc2 -> whole-row epilogue in one kernel (hgemm.hpp hmlp_kernel): f16x2, folded LayerNorm, H-image residual only
+static bool hmlp_has(int C, int hidden) { return hidden == 2 * C && (C == 224 || C == 256 || C == 384); }
+template <int NT2, int MINW>
+int launch_hmlp(const MlpParams& m, hipStream_t s) {
+    using T = MlpTile<NT2>;
+    static_assert(T::LDS_BYTES <= (MINW == 2 ? 80 : 160) * 1024, "LDS budget");
+    auto k = hmlp_kernel<NT2, MINW>;
+    {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+    }
+    const int64_t tiles = (m.g.M + 127) / 128;
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "fused MLP grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), T::LDS_BYTES, s, m);
+    return check_launch("hmlp_kernel");
+}
+int fused_mlp(const MlpParams& m, hipStream_t s) {
+    if (m.g.M <= 0) return PAFUSE_OK;
+    if (!m.g.Ah || !m.g.Wh || !m.W1h || !m.bias1 || !m.g.resid_h) return fail(PAFUSE_E_ARG, "fused MLP without its H images");
+    if (m.g.K != 2 * m.g.N) return fail(PAFUSE_E_SHAPE, "fused MLP: hidden width %d is not twice the channel width %d", m.g.K, m.g.N);
+    switch (m.g.N) {
+        case 224: return launch_hmlp<7, 2>(m, s);
+        case 256: return launch_hmlp<8, 2>(m, s);
+        case 384: return launch_hmlp<12, 1>(m, s);
+        default: return fail(PAFUSE_E_SHAPE, "fused MLP: no kernel for channel width %d", m.g.N);
+    }
 }
 
 // the qkv layers' kernel on v_mfma_f32_16x16x32_bf16 (kernels.hpp gemm16_tile); the image must be in the M16 layout
@@ -575,6 +605,8 @@ struct BlockLaunch {
     AttnParams attn;
     FqaParams fqa;   // qkv + attention in one kernel (fused == true: replaces the qkv and attn launches)
     bool fused;
+    MlpParams mlp;   // fc1 -> GELU -> fc2 in one kernel (mlp_fused == true: replaces the fc1 and fc2 launches)
+    bool mlp_fused;
 };
 
 BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
@@ -659,6 +691,16 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
             if (f2.out_xh) f2.out_x = nullptr;                    // (the head's block writes neither)
         }
     }
+    // the two MLP launches as one kernel: the hidden activations stay in registers (hgemm.hpp hmlp_kernel); fc2_hp is the H
+    // image of fc2.weight with the columns of each group of 16 in the order the kernel's accumulators hand them over
+    b.mlp_fused = false;
+    if (h_residual && bw.fc2_hp && hmlp_has(C, hidden)) {
+        MlpParams& m = b.mlp;
+        m.g = f2;
+        m.g.Ah = xn_h, m.g.Wh = (const uint8_t*)bw.fc2_hp;
+        m.W1h = (const uint8_t*)bw.fc1_ws, m.bias1 = f1.bias, m.ln_in = f1.ln_in;
+        b.mlp_fused = true;
+    }
     return b;
 }
 
@@ -734,6 +776,18 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
     }
     if (layer_mask & 1) count(n);
     if ((rc = layer(&BlockLaunch::proj, true, 2))) return rc;
+    bool mlp_fused = true;
+    for (int i = 0; i < n; ++i) mlp_fused = mlp_fused && bl[i].mlp_fused;
+    if (mlp_fused) {   // one kernel per part for fc1 + fc2 (a replay of the fc1 layer alone runs it, of fc2 alone nothing)
+        if (!(layer_mask & 4)) return PAFUSE_OK;
+        for (int i = 0; i < n; ++i) {
+            if ((rc = fused_mlp(bl[i].mlp, s))) return rc;
+            if (flops) *flops += 2.0 * (2.0 * bl[i].fc1.M * bl[i].fc1.N * bl[i].fc1.K);
+            if (bl[i].mlp.g.out_xh) PAFUSE_TRACE(bl[i].mlp.g.out_xh, (size_t)bl[i].fc2.M * bl[i].fc2.N * 4, s);
+        }
+        if (flops) *launches += n;
+        return PAFUSE_OK;
+    }
     if ((rc = layer(&BlockLaunch::fc1, false, 4))) return rc;
     return layer(&BlockLaunch::fc2, true, 8);
 }
@@ -934,6 +988,19 @@ int pafuse_linear_h(const void* Ah, const void* Wh, const float* bias, float* ou
     g.Ah = (const uint8_t*)Ah, g.Wh = (const uint8_t*)Wh, g.bias = bias, g.out = out, g.out_h = (uint8_t*)out_h;
     g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = 3;
     return gemm_bias(g, (hipStream_t)stream);
+}
+
+int pafuse_mlp_h(const void* xh, const float* stats_in, const void* W1h, const float* bias1, const void* W2hp, const float* bias2,
+                 void* out_xh, float* stats_out, int64_t M, int32_t C, float eps, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!xh || !W1h || !bias1 || !W2hp || !bias2 || !out_xh || !stats_out || M < 0) return fail(PAFUSE_E_ARG, "mlp_h: null pointer or negative M");
+    if (!hmlp_has(C, 2 * C)) return fail(PAFUSE_E_SHAPE, "mlp_h: no fused MLP kernel for channel width %d (have 224, 256, 384)", C);
+    MlpParams m{};
+    m.g.Ah = (const uint8_t*)xh, m.g.Wh = (const uint8_t*)W2hp, m.g.bias = bias2, m.g.resid_h = (const uint8_t*)xh;
+    m.g.out_xh = (uint8_t*)out_xh, m.g.ln_stats = stats_out, m.g.next_w = bias2, m.g.next_b = bias2, m.g.next_eps = eps;   // (folded: next_* only say "a LayerNorm follows")
+    m.g.M = M, m.g.N = C, m.g.K = 2 * C, m.g.bf16 = 3;
+    m.W1h = (const uint8_t*)W1h, m.bias1 = bias1, m.ln_in = stats_in;
+    return fused_mlp(m, (hipStream_t)stream);
 }
 
 int pafuse_layernorm(const float* x, const float* w, const float* b, float* out, int64_t M, int32_t C, float eps,

@@ -118,6 +118,12 @@ class MixSTE2(nn.Module):
         #                                sequence length has a fused form (include/pafuse_hip.h pafuse_block_weights.qkv_hs): q, k, v
         #                                never reach memory.  None = on in 'f16x2' (that pipeline is bound by the bytes it moves:
         #                                +7 % on the loop), off in 'bf16x3' (matrix-bound: equal in time)
+        self.fuse_mlp = None           # 'f16x2' with the LayerNorm folded and the residual stream as its image only: fc1 -> GELU -> fc2
+        #                                of a block in ONE kernel, the hidden activations [M, 2C] stay in registers (include/pafuse_hip.h
+        #                                pafuse_block_weights.fc2_hp).  None = on at the widths where it wins in the loop (224 and 256: the face and
+        #                                the hands; equal or slower as a launch of its own, faster beside the other parts' kernels because it moves
+        #                                8 C bytes per token less); True = wherever the kernel exists (also 384, where its 192 accumulator registers
+        #                                leave one workgroup per CU: slower), mlp_ratio 2 only
         self.keep_f32_residual = False  # 'f16x2' with the LayerNorm folded: False keeps the residual stream between the blocks in memory
         #                                only as the two-fp16-slice image the GEMMs read (22-23 significant bits; measured: the loop stays
         #                                closer to an fp64 evaluation than the reference's fp32 arithmetic, tests/test_hip_parity.py);
@@ -138,7 +144,7 @@ class MixSTE2(nn.Module):
             return attrgetter(name)(self)
         mode = int(self.operand_bf16)
         key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode, bool(images),
-                                                                     bool(self.keep_f32_residual))
+                                                                     bool(self.keep_f32_residual), self.fuse_mlp)
         if not images:
             hit = self._wcache_by_device.get(("train", self._freqs.device.index))
             if hit is not None and hit[0] == key:
@@ -174,7 +180,10 @@ class MixSTE2(nn.Module):
         w = _lib.MixSTE2Weights()
         images, event, stream = None, None, None
         if split:
-            images = self._split_images(get, fold, fuse, f16=(mode == 3))
+            fuse_mlp = (mode == 3 and fold and not self.keep_f32_residual and self.mlp_hidden == 2 * self.embed_dim
+                        and self.embed_dim in FUSED_MLP_WIDTHS
+                        and (self.embed_dim in FUSED_MLP_DEFAULT_WIDTHS if self.fuse_mlp is None else bool(self.fuse_mlp)))
+            images = self._split_images(get, fold, fuse, f16=(mode == 3), fuse_mlp=fuse_mlp)
             stream = torch.cuda.current_stream(dev)
             event = torch.cuda.Event()
             event.record(stream)
@@ -190,7 +199,7 @@ class MixSTE2(nn.Module):
             self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
         return w
 
-    def _split_images(self, get, fold=False, fuse=False, f16=False):
+    def _split_images(self, get, fold=False, fuse=False, f16=False, fuse_mlp=False):
         """Pre-split images (bf16x3, or f16x2 with `f16`) of every linear weight, made on the device by pafuse_split_weights:
         one uint8 tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct).
         `fold`: qkv / fc1 get the image of W (.) g and the two vectors of the folded LayerNorm (norm1 / norm2 of their
@@ -206,6 +215,8 @@ class MixSTE2(nn.Module):
                 images[name] = split_image(get(name), image_layout(name), f16)
             if fuse and name.endswith("attn.qkv.weight"):
                 images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = head_major_qkv(get, name, self.num_heads, fold, f16)
+            if fuse_mlp and name.endswith("mlp.fc2.weight"):
+                images[stem + "hp"] = fused_mlp_fc2_image(get(name))
         return images
 
     # ---------------------------------------------------------------------------------------------- forward
@@ -349,7 +360,7 @@ SPLIT_SUFFIXES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.
 FOLDED_LINEAR = {"attn.qkv.weight": "norm1", "mlp.fc1.weight": "norm2"}
 FOLD_SUFFIXES = ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.bias", "mlp.fc1.bias")
 BLOCK_FOLD = (("qkv_ls", "attn.qkv.ls"), ("qkv_lt", "attn.qkv.lt"), ("fc1_ls", "mlp.fc1.ls"), ("fc1_lt", "mlp.fc1.lt"),
-              ("qkv_hs", "attn.qkv.hs"), ("qkv_hb", "attn.qkv.hb"), ("qkv_hl", "attn.qkv.hl"))
+              ("qkv_hs", "attn.qkv.hs"), ("qkv_hb", "attn.qkv.hb"), ("qkv_hl", "attn.qkv.hl"), ("fc2_hp", "mlp.fc2.hp"))
 BLOCK_SPLIT = (("qkv_ws", "attn.qkv.weight"), ("proj_ws", "attn.proj.weight"), ("fc1_ws", "mlp.fc1.weight"),
                ("fc2_ws", "mlp.fc2.weight"))
 BLOCK_PARAMS = (("norm1_w", "norm1.weight"), ("norm1_b", "norm1.bias"), ("qkv_w", "attn.qkv.weight"),
@@ -408,6 +419,25 @@ def split_image(weight, layout, f16=False):
                                             img.data_ptr(),
                                             torch.cuda.current_stream(weight.device).cuda_stream))
     return img
+
+
+FUSED_MLP_WIDTHS = (224, 256, 384)     # channel widths hmlp_kernel is built for (csrc/pafuse_hip.hip fused_mlp)
+FUSED_MLP_DEFAULT_WIDTHS = (224, 256)  # ... and where MixSTE2.fuse_mlp = None turns it on
+
+
+def fused_mlp_column_order(hidden, device=None):
+    """Column order of fc2.weight in the fused MLP kernel's image (include/pafuse_hip.h pafuse_block_weights.fc2_hp): column
+    16 b + 8 h + i of the image is column 16 b + 8 (i >> 2) + 4 h + (i & 3) of the weight - inside every group of 16 hidden
+    units, the order in which fc1's accumulators hold them."""
+    c = torch.arange(hidden, device=device)
+    b, h, i = c // 16, (c // 8) % 2, c % 8
+    return 16 * b + 8 * (i // 4) + 4 * h + (i % 4)
+
+
+def fused_mlp_fc2_image(weight):
+    """The f16x2 image of fc2.weight [C, 2C] for the fused MLP kernel: the image of W[:, fused_mlp_column_order]."""
+    w = weight.detach()
+    return split_image(w[:, fused_mlp_column_order(w.shape[1], w.device)].contiguous(), LAYOUT_OF["mlp.fc2.weight"], True)
 
 
 def folded_linear(get, name, f16=False):

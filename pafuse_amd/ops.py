@@ -194,6 +194,35 @@ def hsplit_rows(x):
     return out
 
 
+def hjoin_rows(image, R, K):
+    """fp32 [R,K] tensor an activation H image stands for: hi + 2^-11 lo (exact in fp32)."""
+    v = image.view(torch.float16).view(R, K // 8, 2, 8).float()
+    return (v[:, :, 0] + v[:, :, 1] * 2.0 ** -11).reshape(R, K)
+
+
+def mlp_fused(xc, rstd, fc1_weight, fc1_bias, fc2_weight, fc2_bias, eps=1e-6, in_place=False):
+    """The fused MLP kernel on its own (pafuse_mlp_h): xc [M,C] = rows of the residual stream centred on their means, rstd [M] or
+    None -> (y - mean(y) as fp32 [M,C] decoded from the H image the kernel writes, stats [M,2] = (mean(y), rstd(y))) with
+    y = xc + GELU(rstd (xc W1^T) + b1) W2^T + b2."""
+    from .mixste2 import fused_mlp_fc2_image, split_image
+    lib = _lib.load()
+    M, Cw = xc.shape
+    _need(tuple(fc1_weight.shape) == (2 * Cw, Cw) and tuple(fc2_weight.shape) == (Cw, 2 * Cw), "mlp_fused: weights must be [2C,C] and [C,2C]")
+    xh = hsplit_rows(xc.contiguous())
+    stats_in = None
+    if rstd is not None:
+        stats_in = torch.stack([torch.zeros_like(rstd), rstd], dim=1).contiguous()
+    w1h = split_image(fc1_weight.contiguous(), 0, True)
+    w2hp = fused_mlp_fc2_image(fc2_weight)
+    out = xh if in_place else torch.empty(M * Cw * 4, dtype=torch.uint8, device=xc.device)
+    stats = stats_in if in_place and stats_in is not None else torch.empty(M, 2, device=xc.device, dtype=torch.float32)
+    with torch.cuda.device(xc.device):
+        _lib.check(lib.pafuse_mlp_h(xh.data_ptr(), stats_in.data_ptr() if stats_in is not None else None, w1h.data_ptr(),
+                                    _ptr(fc1_bias, "fc1_bias"), w2hp.data_ptr(), _ptr(fc2_bias, "fc2_bias"), out.data_ptr(),
+                                    stats.data_ptr(), M, Cw, float(eps), _stream(xc)))
+    return hjoin_rows(out, M, Cw), stats
+
+
 def split_weights(weight, layout=0, scheme="bf16x3"):
     """Pre-split image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights);
     layout 0: the 32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers;

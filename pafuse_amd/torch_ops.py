@@ -25,8 +25,8 @@ from typing import List
 import torch
 
 from . import _lib
-from .mixste2 import (FOLDED_LINEAR, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear, head_major_qkv,
-                      image_layout, sinusoid_frequencies, split_image)
+from .mixste2 import (FOLDED_LINEAR, FUSED_MLP_DEFAULT_WIDTHS, MixSTE2, SPLIT_SUFFIXES, _ptr, fill_weights_struct, folded_linear,
+                      fused_mlp_fc2_image, head_major_qkv, image_layout, sinusoid_frequencies, split_image)
 
 BLOCK_KEYS = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
@@ -119,6 +119,18 @@ def cached_head_major_qkv(table, name, heads, f16=False):
     return hit[0]
 
 
+def cached_fused_mlp_fc2(weight):
+    """The fused MLP kernel's image of an fc2 weight (mixste2.fused_mlp_fc2_image), made once per (storage, version); the entry
+    pins the tensor (see cached_split_image)."""
+    key = ("fused-mlp", weight.data_ptr(), weight._version, weight.device, tuple(weight.shape))
+    hit = _image_cache.get(key)
+    if hit is None:
+        while len(_image_cache) >= _IMAGE_CACHE_MAX:
+            _image_cache.pop(next(iter(_image_cache)))
+        hit = _image_cache[key] = (fused_mlp_fc2_image(weight), weight)
+    return hit[0]
+
+
 def _mode(precision):
     if precision not in PRECISIONS:
         raise _lib.PafuseError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
@@ -142,13 +154,15 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
     if mode in (2, 3):
         images = {}
         for n, t in table.items():
-            if n.endswith(tuple(FOLDED_LINEAR)):
-                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, mode == 3)
+            if mode == 3 and n.endswith(tuple(FOLDED_LINEAR)):    # the modules' defaults: LayerNorm folded in 'f16x2' only
+                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, True)
             elif n.endswith(SPLIT_SUFFIXES):
                 images[n] = cached_split_image(t, image_layout(n), mode == 3)
             if mode == 3 and n.endswith("attn.qkv.weight"):     # the modules' default in 'f16x2': qkv + attention in one kernel
                 stem = n[:-len("weight")]
                 images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = cached_head_major_qkv(table, n, heads, True)
+            if mode == 3 and n.endswith("mlp.fc2.weight") and channels in FUSED_MLP_DEFAULT_WIDTHS and t.shape[1] == 2 * channels:
+                images[n[:-len("weight")] + "hp"] = cached_fused_mlp_fc2(t)    # ... and the MLP in one kernel where the modules do
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
     return w, (table, fr, images)
 

@@ -435,6 +435,73 @@ def test_fused_qkv_attention_kernel_is_the_same_function(fold, precision):
     assert float((fused - ref).abs().mean()) <= 1.25 * float((two - ref).abs().mean()) + 1e-8
 
 
+@pytest.mark.parametrize("C_", [224, 256, 384])
+def test_fused_mlp_kernel_against_fp64(C_):
+    """hmlp_kernel on its own (pafuse_mlp_h): y = xc + GELU(rstd (xc W1^T) + b1) W2^T + b2 with the hidden activations in
+    registers, the fc2 image in the kernel's column order - against an fp64 evaluation; M = 300 and 7344 end in ragged tiles;
+    in place (the loop's form) and out of place.  The result comes back as the centred two-slice image of y: its own grid
+    (2^-22 of the row's largest |value|) is inside the bound.  Small integers (every product and sum exact, GELU of +-64 k
+    is the identity or zero) must come out exactly up to that grid."""
+    from pafuse_amd import ops
+    g = torch.Generator().manual_seed(3 + C_)
+    for M in (128, 300, 7344):
+        x = torch.randn(M, C_, generator=g)
+        xc = x - x.mean(1, keepdim=True)
+        rstd = (1.0 / torch.sqrt(xc.double().pow(2).mean(1) + 1e-6)).float()
+        W1 = torch.randn(2 * C_, C_, generator=g) * C_ ** -0.5
+        b1 = torch.randn(2 * C_, generator=g) * 0.1
+        W2 = torch.randn(C_, 2 * C_, generator=g) * (2 * C_) ** -0.5
+        b2 = torch.randn(C_, generator=g) * 0.1
+        hid = torch.nn.functional.gelu(rstd.double()[:, None] * (xc.double() @ W1.double().t()) + b1.double())
+        ref = xc.double() + hid @ W2.double().t() + b2.double()
+        mean = ref.mean(1, keepdim=True)
+        var = (ref - mean).pow(2).mean(1)
+        for in_place in (False, True):
+            y, st = ops.mlp_fused(xc.to(DEV), rstd.to(DEV), W1.to(DEV), b1.to(DEV), W2.to(DEV), b2.to(DEV), in_place=in_place)
+            d = (y.cpu().double() - (ref - mean)).abs()
+            assert float(d.max()) <= 6e-6 and float(d.mean()) <= 4e-7, (C_, M, in_place, float(d.max()), float(d.mean()))
+            assert float((st[:, 0].cpu().double() - mean[:, 0]).abs().max()) <= 1e-6
+            assert float((st[:, 1].cpu().double() * torch.sqrt(var + 1e-6) - 1).abs().max()) <= 1e-5
+    M = 300
+    xi = torch.randint(-2, 3, (M, C_), generator=g).float()
+    W1 = torch.randint(-2, 3, (2 * C_, C_), generator=g).float()
+    b1 = (torch.randint(0, 2, (2 * C_,), generator=g).float() * 2 - 1) * 4096.0   # GELU(v +- 4096) = v + 4096 or 0, exactly
+    W2 = torch.randint(-1, 2, (C_, 2 * C_), generator=g).float() * 2.0 ** -12
+    y, _ = ops.mlp_fused(xi.to(DEV), None, W1.to(DEV), b1.to(DEV), W2.to(DEV), torch.zeros(C_, device=DEV))
+    ref = xi.double() + torch.nn.functional.gelu(xi.double() @ W1.double().t() + b1.double()) @ W2.double().t()
+    ref = ref - ref.mean(1, keepdim=True)
+    assert float((y.cpu().double() - ref).abs().max()) <= 2.0 ** -20 * float(ref.abs().max())
+
+
+def test_fused_mlp_kernel_is_the_same_function():
+    """The MLP of a block as ONE kernel (hmlp_kernel, MixSTE2.fuse_mlp; default on for the face and the hands) against the fc1
+    and fc2 launches it replaces, in the loop: same products, the same K order between 16-deep steps (inside a step the fc2 sum
+    takes the hidden units in the accumulators' order) - rounding-level differences, both within 1e-5 of the oracle and equally
+    far from it.  B = 2, P = 3: ragged last tiles; every part fused, the body too (opt-in there)."""
+    from __graft_entry__ import make_model
+    model, sd = make_model(3, 2, seed=57)
+    model.precision = "f16x2"
+    x2d, x2f = gu.synthetic_inputs_2d(B=2)
+    noises = gu.synthetic_noises(B=2, P=3, n=2, seed=6)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    parts = model.denoisers()
+    assert {n: bool(m.weights_struct().ste[0].fc2_hp) for n, m in parts.items()} == {"body": False, "face": True, "hands": True}
+    outs = {}
+    for tag, flag in (("two", False), ("default", None), ("all", True)):
+        for m in parts.values():
+            m.fuse_mlp = flag
+        outs[tag] = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    assert all(bool(m.weights_struct().tte[7].fc2_hp) for m in parts.values())
+    ref = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    for tag in ("default", "all"):
+        assert float((outs[tag] - outs["two"]).abs().max()) <= 4e-6, (tag, float((outs[tag] - outs["two"]).abs().max()))
+        assert float((outs[tag] - ref).abs().max()) <= 1e-5
+        assert float((outs[tag] - ref).abs().mean()) <= 1.25 * float((outs["two"] - ref).abs().mean()) + 1e-8
+    for m in parts.values():      # with the fp32 residual rows kept, or without the fold, the block runs the two launches
+        m.fuse_mlp, m.keep_f32_residual = True, True
+    assert not any(bool(m.weights_struct().ste[0].fc2_hp) for m in parts.values())
+
+
 def test_g5_p1t1_both_samplers_golden(g5):
     from __graft_entry__ import make_model
     z, _, sd = g5

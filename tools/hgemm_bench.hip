@@ -54,6 +54,43 @@ void run(const char* shape, GemmParams p) {
     CK(hipFree(st));
 }
 
+// the fused MLP kernel (hmlp_kernel): fc1 -> GELU -> fc2 -> whole-row epilogue of one part
+template <int NT2, int MINW>
+void run_mlp(const char* part, MlpParams m) {
+    using T = MlpTile<NT2>;
+    char tag[160];
+    snprintf(tag, sizeof tag, "%s mlp fused <%d> minw%d", part, NT2, MINW);
+    if (g_filter && !strstr(tag, g_filter)) return;
+    auto k = hmlp_kernel<NT2, MINW>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
+    const int64_t tiles = (m.g.M + 127) / 128;
+    const size_t nw = tiles * 4;
+    unsigned long long* st; CK(hipMalloc(&st, nw * 32)); CK(hipMemset(st, 0, nw * 32));
+    m.g.stamps = st;
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, T::LDS_BYTES));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(256), T::LDS_BYTES, 0, m);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < g_reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(256), T::LDS_BYTES, 0, m);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(nw * 4);
+    CK(hipMemcpy(h.data(), st, nw * 32, hipMemcpyDeviceToHost));
+    double pro = 0, loop = 0, epi = 0; size_t n = 0;
+    for (size_t w = 0; w < nw; ++w) {
+        if (!h[w * 4] || !h[w * 4 + 2]) continue;
+        pro += h[w * 4 + 3] - h[w * 4]; loop += h[w * 4 + 1] - h[w * 4 + 3]; epi += h[w * 4 + 2] - h[w * 4 + 1]; ++n;
+    }
+    const double us = ms * 1e3 / g_reps, tf = 2.0 * 2.0 * m.g.M * T::C * T::HID / (us * 1e-6) / 1e12;
+    const double mfma = (double)T::NSLAB * (T::NK1 * 12 + 4 * NT2 * 3) * 32;
+    printf("%-58s tiles %5ld (%.2f rounds at %d/CU) %7.2f us %6.1f TF (%.3f of 833) | per wave: prologue %5.0f  loop %6.0f (MFMA %5.0f)  epilogue %6.0f\n",
+           tag, (long)tiles, (double)tiles / (256.0 * occ), occ, us, tf, tf / 833.3, n ? pro / n : 0, n ? loop / n : 0, mfma, n ? epi / n : 0);
+    fflush(stdout);
+    CK(hipFree(st));
+}
+
 int main() {
     g_filter = getenv("HB_FILTER");
     if (getenv("HB_REPS")) g_reps = atoi(getenv("HB_REPS"));
@@ -110,6 +147,24 @@ int main() {
                 run<4, 1, 7, EPI_BIAS, 2, 16, 2>(shape, p);
                 run<8, 1, 7, EPI_BIAS, 3, 16, 1>(shape, p);
             }
+        }
+        {   // ---- the MLP as one kernel (weights in natural column order: timing only)
+            images(2 * C, C);
+            uint8_t* W2h;
+            CK(hipMalloc(&W2h, (size_t)C * 2 * C * 4 + 256));
+            CK(hipMemset(W2h + (size_t)C * 2 * C * 4, 0, 256));
+            hipLaunchKernelGGL(absmax_kernel, dim3(256), dim3(256), 0, 0, W, (int64_t)C * 2 * C, reinterpret_cast<uint32_t*>(W2h + (size_t)C * 2 * C * 4) + 1);
+            hipLaunchKernelGGL(hsplit_weights_kernel, dim3((unsigned)(((int64_t)C * (2 * C / 8) + 255) / 256)), dim3(256), 0, 0, W, W2h, C, 2 * C);
+            MlpParams m{};
+            m.g.Ah = xh, m.g.Wh = W2h, m.g.bias = vec, m.g.resid_h = xh, m.g.out_xh = xh, m.g.ln_stats = stats;
+            m.g.post_w = vec + 400, m.g.post_b = vec + 800, m.g.post_eps = 1e-6f, m.g.next_w = vec + 1200, m.g.next_b = vec + 1600, m.g.next_eps = 1e-6f;
+            m.g.M = pt.M, m.g.N = C, m.g.K = 2 * C, m.g.bf16 = 3;
+            m.W1h = Wh, m.bias1 = vec + 2000, m.ln_in = stats;
+            if (C == 224) { run_mlp<7, 2>(pt.name, m); }
+            if (C == 256) { run_mlp<8, 2>(pt.name, m); }
+            if (C == 384) { run_mlp<12, 1>(pt.name, m); }
+            CK(hipDeviceSynchronize());
+            CK(hipFree(W2h));
         }
         // ---- whole-row layers
         for (int layer = 0; layer < 2; ++layer) {
