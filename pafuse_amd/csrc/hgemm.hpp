@@ -617,9 +617,11 @@ __global__ void __launch_bounds__(WM* WN * 64, MINW) hgemm_kernel(const GemmPara
 // ----------------------------------------------------------------------------------------------------------------
 template <int LP, int DP, int HPW = 1>   // HPW: heads per workgroup (their projections share the A stream, their attention phases run in turn)
 struct HfqaTile {
-    static constexpr int NBH = 3 * DP / 16, NB = HPW * NBH, LDV = DP + 4, ROWS = 128 + (LP == 48 ? 4 : 0), NSTAGE = 2;
-    static constexpr int A_BYTES = 128 * 128, W_BYTES = HPW * 3 * DP * 128, STAGE_BYTES = A_BYTES + W_BYTES;
-    static constexpr int IA = A_BYTES / 1024, IW = W_BYTES / 1024, CNT = (IA + IW + 3) / 4;
+    // waves = 32-row strips of the tile: 4 (128 rows); the 80-token form (68 joints of the face: two sequences = 136 rows) takes 5
+    static constexpr int NWV = LP == 80 ? 5 : 4, TROWS = 32 * NWV, NTHR = 64 * NWV;
+    static constexpr int NBH = 3 * DP / 16, NB = HPW * NBH, LDV = DP + 4, ROWS = TROWS + (LP == 48 ? 4 : 0), NSTAGE = 2;
+    static constexpr int A_BYTES = TROWS * 128, W_BYTES = HPW * 3 * DP * 128, STAGE_BYTES = A_BYTES + W_BYTES;
+    static constexpr int IA = A_BYTES / 1024, IW = W_BYTES / 1024, CNT = (IA + IW + NWV - 1) / NWV;
     static constexpr int QKV_BYTES = 3 * ROWS * LDV * 4;
     static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES > QKV_BYTES ? NSTAGE * STAGE_BYTES : QKV_BYTES;
     static_assert(W_BYTES % 1024 == 0, "whole DMA pieces");
@@ -633,31 +635,26 @@ __device__ __forceinline__ int hfqa_swizzle(int row) { return (((row >> 1) & 3) 
 template <int LP, int DP, class TokenOf>
 __device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4 (&acc)[2][3 * DP / 16], float* smem, const int64_t seq0,
                                                       const int head, const int n0, const int wave, const int c, const int qd,
-                                                      const int tid, TokenOf token_of) {
+                                                      const int tid, TokenOf token_of, const f32x4 (&bias4)[3 * DP / 16], const float (&row_rstd)[2],
+                                                      const float (&row_nmr)[2], const float ws, const int hh = 0) {
     using FT = HfqaTile<LP, DP>;
-    constexpr int NB = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS;
+    constexpr int NB = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS, NWV = FT::NWV, TROWS = FT::TROWS;
     const GemmParams& p = fp.g;
     const int L = fp.L, NSEQ = fp.nseq_tile, K = p.K;
     // ---- phase 2: q | k | v of the tile's tokens to LDS (2^-k, bias or the folded LayerNorm applied)
     float* const Qs = smem;                    // [ROWS][LDV] each
     float* const Ks = Qs + ROWS * LDV;
     float* const Vs = Ks + ROWS * LDV;
-    const float ws = *reinterpret_cast<const float*>(p.Wh + (size_t)p.N * K * 4);   // 2^-k of the head-major image
+    // (2^-k of the image, the rows' LayerNorm factors and this head's bias were fetched before / during the projection: a
+    // global load issued here costs the workgroup its whole latency, 2 - 4 thousand cycles under the other workgroups' streams)
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int r = 32 * wave + 16 * g + c;
-        float rstd = 1.0f, nmr = 0.0f;
-        if (p.ln_in) {
-            const int64_t m = token_of(r);
-            const float mean = p.ln_in[2 * m];
-            rstd = p.ln_in[2 * m + 1];
-            nmr = -mean * rstd;
-        }
-        rstd *= ws;
+        const float rstd = row_rstd[g] * ws, nmr = row_nmr[g];
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
+            const f32x4 b4 = bias4[n];
             f32x4 v;
             if (p.ln_in && p.ln_s) {
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + col);
@@ -674,98 +671,148 @@ __device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4
             *reinterpret_cast<f32x4*>(Qs + part * ROWS * LDV + r * LDV + cc) = v;
         }
     }
-    if (ROWS > 128)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
-        for (int i = tid; i < 3 * (ROWS - 128) * LDV; i += 256) {
-            const int part = i / ((ROWS - 128) * LDV), rem = i % ((ROWS - 128) * LDV);
-            Qs[part * ROWS * LDV + 128 * LDV + rem] = 0.f;
+    if (ROWS > TROWS)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
+        for (int i = tid; i < 3 * (ROWS - TROWS) * LDV; i += FT::NTHR) {
+            const int part = i / ((ROWS - TROWS) * LDV), rem = i % ((ROWS - TROWS) * LDV);
+            Qs[part * ROWS * LDV + TROWS * LDV + rem] = 0.f;
         }
     __syncthreads();
+#if PAFUSE_STAMP_SLOTS >= 8
+    PAFUSE_STAMP(4 + 2 * hh);   // diagnostic builds: q | k | v of this head are in LDS
+#endif
 
-    // ---- phase 3: attention per (sequence of the tile, 16-query tile), one item per wave at a time (attn_kernel's arithmetic)
-    constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16;
+    // ---- phase 3: attention per (sequence of the tile, 16-query tile) - attn_kernel's arithmetic per item, TWO items of a wave in
+    // flight together: an item is one dependent chain (scores -> row maximum across the lane groups -> exponentials -> row sum ->
+    // weights -> P V) and a wave that walks it alone waits for every cross-lane exchange and every MFMA result; the second
+    // item's instructions fill those waits (same results: the items do not interact).
+#ifndef PAFUSE_HFQA_ITEMS
+#define PAFUSE_HFQA_ITEMS 1
+#endif
+    constexpr int QT = LP / 16, KT = LP / 16, CT = DP / 16, SD = DP / 16, U = PAFUSE_HFQA_ITEMS;
     const int l15 = c, g4 = qd;
     const int nseq_here = (int)((fp.nseq - seq0) < NSEQ ? (fp.nseq - seq0) : NSEQ);
-    for (int item = wave; item < nseq_here * QT; item += 4) {
-        const int sl = item / QT, qt = item % QT;
-        const int rb = sl * L;
-        if (qt * 16 >= L) continue;
-        f32x4 qf[SD];
+    const int n_items = nseq_here * QT;
+    for (int base = wave; base < n_items; base += U * NWV) {
+        int rb[U], qt[U];
+        bool valid[U];
 #pragma unroll
-        for (int sd = 0; sd < SD; ++sd) qf[sd] = *reinterpret_cast<const f32x4*>(Qs + (rb + qt * 16 + l15) * LDV + 16 * sd + 4 * g4);
-        const float* Kb = Ks + rb * LDV;
-        const float* Vb = Vs + rb * LDV;
-        f32x4 sc[KT];
+        for (int u = 0; u < U; ++u) {
+            const int item = base + u * NWV;
+            const int it = item < n_items ? item : base;       // an absent second item repeats the first (never stored)
+            const int sl = it / QT;
+            qt[u] = it - sl * QT, rb[u] = sl * L;
+            valid[u] = item < n_items && qt[u] * 16 < L;
+        }
+        if (!valid[0] && !valid[U - 1]) continue;              // (wave-uniform)
+        f32x4 qf[U][SD];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int sd = 0; sd < SD; ++sd) qf[u][sd] = *reinterpret_cast<const f32x4*>(Qs + (rb[u] + qt[u] * 16 + l15) * LDV + 16 * sd + 4 * g4);
+        f32x4 sc[U][KT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) sc[u][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sd = 0; sd < SD; ++sd) {
-            f32x4 kf[KT];
+            f32x4 kf[U][KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) kf[kt] = *reinterpret_cast<const f32x4*>(Kb + (kt * 16 + l15) * LDV + 16 * sd + 4 * g4);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) kf[u][kt] = *reinterpret_cast<const f32x4*>(Ks + (rb[u] + kt * 16 + l15) * LDV + 16 * sd + 4 * g4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j], qf[sd][j], sc[kt], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        sc[u][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u][kt][j], qf[u][sd][j], sc[u][kt], 0, 0, 0);
         }
-        float mx = -INFINITY;
+        float mx[U], sum[U];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int u = 0; u < U; ++u) {
+            mx[u] = -INFINITY;
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int key = kt * 16 + 4 * g4 + reg;
-                const float v = key < L ? sc[kt][reg] * fp.scale : -INFINITY;
-                sc[kt][reg] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float e = __builtin_amdgcn_exp2f((sc[kt][reg] - mx) * 1.44269504088896340736f);
-                sc[kt][reg] = e;
-                sum += e;
-            }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) sc[kt][reg] *= inv;
-        f32x4 oc[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) oc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float* vrow = Vb + (kt * 16 + 4 * g4 + reg) * LDV + l15;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    oc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ct * 16], sc[kt][reg], oc[ct], 0, 0, 0);
-            }
-        const int q = qt * 16 + l15;
-        if (q < L) {   // channel ch = head d + 16 ct + 4 g4 (a multiple of 4): sub-block ch / 8, its second half when ch & 4
-            uint8_t* const hrow = reinterpret_cast<uint8_t*>(fp.o) + (size_t)token_of(rb + q) * fp.C * 4;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-                if (ct * 16 + 4 * g4 < fp.d) {
-                    const int ch = head * fp.d + ct * 16 + 4 * g4;
-                    hsplit_store4(hrow + (ch >> 3) * 32, ch & 4, oc[ct]);
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int key = kt * 16 + 4 * g4 + reg;
+                    const float v = key < L ? sc[u][kt][reg] * fp.scale : -INFINITY;
+                    sc[u][kt][reg] = v;
+                    mx[u] = fmaxf(mx[u], v);
                 }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], 16));
+#pragma unroll
+        for (int u = 0; u < U; ++u) mx[u] = fmaxf(mx[u], __shfl_xor(mx[u], 32));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sum[u] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float e = __builtin_amdgcn_exp2f((sc[u][kt][reg] - mx[u]) * 1.44269504088896340736f);
+                    sc[u][kt][reg] = e;
+                    sum[u] += e;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum[u] += __shfl_xor(sum[u], 16);
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum[u] += __shfl_xor(sum[u], 32);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float inv = 1.0f / sum[u];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) sc[u][kt][reg] *= inv;
+        }
+        f32x4 oc[U][CT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) oc[u][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float* vrow = Vs + (rb[u] + kt * 16 + 4 * g4 + reg) * LDV + l15;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        oc[u][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ct * 16], sc[u][kt][reg], oc[u][ct], 0, 0, 0);
+                }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = qt[u] * 16 + l15;
+            if (valid[u] && q < L) {   // channel ch = head d + 16 ct + 4 g4 (a multiple of 4): sub-block ch / 8, its second half when ch & 4
+                uint8_t* const hrow = reinterpret_cast<uint8_t*>(fp.o) + (size_t)token_of(rb[u] + q) * fp.C * 4;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    if (ct * 16 + 4 * g4 < fp.d) {
+                        const int ch = head * fp.d + ct * 16 + 4 * g4;
+                        hsplit_store4(hrow + (ch >> 3) * 32, ch & 4, oc[u][ct]);
+                    }
+            }
+        }
     }
+#if PAFUSE_STAMP_SLOTS >= 8
+    PAFUSE_STAMP(5 + 2 * hh);   // diagnostic builds: this head's items are done
+#endif
 }
 
 template <int LP, int DP, int HPW>
-__global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
+// (two workgroups per CU; the five-wave form asks for the register budget of three)
+__global__ void __launch_bounds__((HfqaTile<LP, DP, HPW>::NTHR), (HfqaTile<LP, DP, HPW>::NWV == 5 ? 3 : 2)) hfqa_kernel(const FqaParams fp) {
     PAFUSE_XQ_GUARD();
     using FT = HfqaTile<LP, DP, HPW>;
     constexpr int NB = FT::NB, NBH = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS, IA = FT::IA, IW = FT::IW, CNT = FT::CNT, NSTAGE = FT::NSTAGE;
+    constexpr int NWV = FT::NWV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const GemmParams& p = fp.g;
     uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
@@ -780,16 +827,21 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
     const int64_t tile = (int64_t)(idx / hgroups) * 8 + xcd;
     const int head0 = (idx % hgroups) * HPW;                 // this workgroup's heads: head0 .. head0 + HPW - 1
     if (tile >= ntiles) return;   // (workgroup-uniform: the grid is padded to a multiple of 8 tiles)
+    PAFUSE_STAMP(0);
     const int K = p.K, nk = K / 32;
     const int64_t seq0 = tile * NSEQ;
     const int64_t last_seq = fp.nseq - 1;
     // token (row of A / o) of tile row r: sequence seq0 + r / L, position r % L; rows of absent sequences alias the last one
+    // (32-bit arithmetic: sequence counts and token indices of the hot path fit - the launcher checks - and a 64-bit division
+    // costs a wave hundreds of instructions; a lane calls this eight times)
+    const uint32_t grp = (uint32_t)fp.group, grp_stride = (uint32_t)fp.group_stride, sq_stride = (uint32_t)fp.seq_stride, tk_stride = (uint32_t)fp.tok_stride;
     auto token_of = [&](int r) -> int64_t {
         int sl = r / L, t = r - sl * L;
         if (sl >= NSEQ) sl = NSEQ - 1, t = L - 1;
-        int64_t sq = seq0 + sl;
-        if (sq > last_seq) sq = last_seq;
-        return (sq / fp.group) * fp.group_stride + (sq % fp.group) * fp.seq_stride + t * fp.tok_stride;
+        int64_t sq64 = seq0 + sl;
+        if (sq64 > last_seq) sq64 = last_seq;
+        const uint32_t sq = (uint32_t)sq64, gi = sq / grp;
+        return (int64_t)(gi * grp_stride + (sq - gi * grp) * sq_stride + (uint32_t)t * tk_stride);
     };
 
     // ---- phase 1: the projection.  DMA instruction i of a chunk (0 .. IA + IW - 1) belongs to wave i % 4; A instruction ia
@@ -798,7 +850,7 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
     const uint8_t* src[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) {
-        int i = wave + 4 * j;
+        int i = wave + NWV * j;
         i = i < IA + IW ? i : IA + IW - 1;
         const bool is_a = i < IA;
         const int row = 8 * (is_a ? i : i - IA) + (lane >> 3);
@@ -807,7 +859,7 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
     }
     auto issue_piece = [&](int kc, int st, int j) {
         uint8_t* const sa = lds + st * FT::STAGE_BYTES;
-        int i = wave + 4 * j;  // wave-uniform
+        int i = wave + NWV * j;  // wave-uniform
         i = i < IA + IW ? i : IA + IW - 1;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)kc * 128),
                                          (__attribute__((address_space(3))) void*)(sa + i * 1024), 16, 0, 0);
@@ -816,6 +868,26 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
 #pragma unroll
         for (int j = 0; j < CNT; ++j) issue_piece(kc, st, j);
     };
+    // what phase 2 needs from memory, asked for now: 2^-k of the image, (mean, rstd) of this lane's two rows, the first head's bias
+    const float ws = *reinterpret_cast<const float*>(p.Wh + (size_t)p.N * K * 4);
+    float row_rstd[2] = {1.0f, 1.0f}, row_nmr[2] = {0.0f, 0.0f};
+    if (p.ln_in) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int64_t m = token_of(32 * wave + 16 * g + c);
+            row_rstd[g] = p.ln_in[2 * m + 1];
+            if (p.ln_s) row_nmr[g] = -p.ln_in[2 * m] * row_rstd[g];
+        }
+    }
+    f32x4 bias_cur[NBH], bias_nxt[NBH];
+    auto fetch_bias = [&](f32x4 (&dst)[NBH], int first_col) {
+#pragma unroll
+        for (int n = 0; n < NBH; ++n) dst[n] = *reinterpret_cast<const f32x4*>(p.bias + first_col + 16 * n + 4 * qd);
+    };
+    // (the five-wave form cannot afford the registers across the loop: two of its workgroups share a CU only while four waves
+    // fit one SIMD - 128 registers each - since both may start on the same SIMD)
+    constexpr bool EARLY_BIAS = NWV != 5;
+    if (EARLY_BIAS) fetch_bias(bias_cur, n0);
     f32x4 acc[HPW][2][NBH];
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
@@ -831,6 +903,7 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
     for (int kc = 0; kc < nk; ++kc) {
         wait_vmcnt<0>();                  // chunk kc of this wave has landed
         __builtin_amdgcn_s_barrier();     // ... of every wave; every wave is done reading chunk kc - 1
+        if (kc == 0) { PAFUSE_STAMP(3); }
         // the refill of the other stage, all of it at once: this phase is bound by the operand stream (one chunk in flight),
         // and every cycle a piece waits for its issue slot behind MFMAs is a cycle the stream idles (spreading the pieces over
         // the MFMA groups, as hgemm_tile does, cost 9 % here)
@@ -867,11 +940,20 @@ __global__ void __launch_bounds__(256, 2) hfqa_kernel(const FqaParams fp) {
         });
         __builtin_amdgcn_s_setprio(0);
     }
+    PAFUSE_STAMP(1);
+    if (!EARLY_BIAS) fetch_bias(bias_cur, n0);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh) {
+        if (hh + 1 < HPW) fetch_bias(bias_nxt, n0 + (hh + 1) * 3 * DP);   // (lands during this head's phases)
         __syncthreads();   // every wave is done with the ring / the tiles of the head before: the LDS becomes this head's q | k | v tiles
-        hfqa_attention_phases<LP, DP>(fp, acc[hh], smem, seq0, head0 + hh, n0 + hh * 3 * DP, wave, c, qd, tid, token_of);
+        hfqa_attention_phases<LP, DP>(fp, acc[hh], smem, seq0, head0 + hh, n0 + hh * 3 * DP, wave, c, qd, tid, token_of, bias_cur, row_rstd,
+                                      row_nmr, ws, hh);
+        if (hh + 1 < HPW) {
+#pragma unroll
+            for (int n = 0; n < NBH; ++n) bias_cur[n] = bias_nxt[n];
+        }
     }
+    PAFUSE_STAMP(2);
 }
 
 

@@ -330,9 +330,12 @@ __device__ __forceinline__ unsigned long long pafuse_stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
+#ifndef PAFUSE_STAMP_SLOTS
+#define PAFUSE_STAMP_SLOTS 4
+#endif
 #define PAFUSE_STAMP(i)                                                                         \
     if (p.stamps && (threadIdx.x & 63) == 0)                                                    \
-    p.stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (i)] = pafuse_stamp()
+    p.stamps[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * PAFUSE_STAMP_SLOTS + (i)] = pafuse_stamp()
 #else
 #define PAFUSE_STAMP(i)
 #endif

@@ -117,12 +117,17 @@ int launch_fqa(const FqaParams& f, hipStream_t s) {
 }
 
 // padded sizes of the fused kernel for a sequence length / head dim, 0 = no fused form (the caller keeps qkv GEMM + attention)
-static int fqa_lp(int L) { return L <= 32 ? 32 : (L <= 48 ? 48 : 0); }
+// (mode 3, f16x2, also has an 80-token form on five waves - 160-row tiles - for head dim <= 32: the face's 68 joints)
+static int fqa_lp(int L, int bf16 = 2) { return L <= 32 ? 32 : (L <= 48 ? 48 : (bf16 == 3 && L <= 80 ? 80 : 0)); }
 static int fqa_dp(int d) { return (d % 4 || d > 48) ? 0 : (d <= 32 ? 32 : 48); }
-static bool fqa_has(int L, int d) {   // (48, 48) would need 80.4 KB of LDS: one workgroup per CU, not built
-    const int lp = fqa_lp(L), dp = fqa_dp(d);
-    return lp && dp && !(lp == 48 && dp == 48);
+static bool fqa_has(int L, int d, int bf16 = 2) {   // (48, 48) would need 80.4 KB of LDS: one workgroup per CU, not built
+    const int lp = fqa_lp(L, bf16), dp = fqa_dp(d);
+    return lp && dp && !(lp >= 48 && dp == 48);
 }
+// rows of the fused kernel's q | k | v tiles, and whole sequences per tile (the last one's LP-row key tile inside the buffer)
+static int fqa_rows(int lp) { return lp == 80 ? 160 : 128 + (lp == 48 ? 4 : 0); }
+static int fqa_tile_rows(int lp) { return lp == 80 ? 160 : 128; }
+static int fqa_nseq_tile(int L, int lp) { return (fqa_rows(lp) - lp) / L + 1; }
 
 // the same decomposition in the f16x2 H pipeline (hgemm.hpp hfqa_kernel): A and the head-major weight as H images, o as H image
 template <int LP, int DP, int HPW>
@@ -136,17 +141,19 @@ int launch_hfqa(const FqaParams& f, hipStream_t s) {
         if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
     }
     if (!f.g.Ah || !f.g.Wh) return fail(PAFUSE_E_ARG, "fused qkv-attention (f16x2) without the H images of its operands");
+    if (f.g.M >= (int64_t)1 << 31 || f.nseq >= (int64_t)1 << 31) return fail(PAFUSE_E_ARG, "fused qkv-attention: more than 2^31 tokens");
     const int64_t ntiles = (f.nseq + f.nseq_tile - 1) / f.nseq_tile;
     const int64_t blocks = (ntiles + 7) / 8 * 8 * (f.heads / HPW);
     if (blocks <= 0 || blocks > 0x7fffffff) return fail(PAFUSE_E_ARG, "fused qkv-attention grid out of range");
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), FT::LDS_BYTES, s, f);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FT::NTHR), FT::LDS_BYTES, s, f);
     return check_launch("hfqa_kernel");
 }
 
 int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
     if (f.nseq <= 0) return PAFUSE_OK;
-    const int lp = fqa_lp(f.L), dp = fqa_dp(f.d);
+    const int lp = fqa_lp(f.L, f.g.bf16), dp = fqa_dp(f.d);
     if (f.g.bf16 == 3) {
+        if (lp == 80 && dp == 32) return launch_hfqa<80, 32, 1>(f, s);
         // head dim <= 32: two heads per workgroup share the A stream (the ring grows to the 80 KB two workgroups per CU allow)
         if (lp == 32 && dp == 48) return launch_hfqa<32, 48, 1>(f, s);
         if (lp == 32 && dp == 32) return f.heads % 2 ? launch_hfqa<32, 32, 1>(f, s) : launch_hfqa<32, 32, 2>(f, s);
@@ -636,18 +643,18 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     if (hp) a.o_h = reinterpret_cast<uint8_t*>(pb.o);
     // the two in one kernel where a head-major image was supplied and the shape has a fused form
     b.fused = false;
-    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads) && (!fold || bw.qkv_hl)) {
-        const int lp = fqa_lp(L), dp = fqa_dp(C / heads), rows = 128 + (lp == 48 ? 4 : 0);
+    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads, bf16) && (!fold || bw.qkv_hl)) {
+        const int lp = fqa_lp(L, bf16), dp = fqa_dp(C / heads);
         FqaParams& f = b.fqa;
         f.g = g;
         f.g.Wsplit = (const uint8_t*)bw.qkv_hs, f.g.bias = bw.qkv_hb, f.g.ln_s = fold ? bw.qkv_hl : nullptr;
         if (hp) f.g.Wh = (const uint8_t*)bw.qkv_hs, f.g.ln_s = nullptr;   // (Ah is the qkv launch's: centred; o is written as an H image)
         f.g.N = heads * 3 * dp;
         f.o = pb.o, f.nseq = nseq, f.L = L, f.C = C, f.heads = heads, f.d = C / heads;
-        f.nseq_tile = (rows - lp) / L + 1;    // whole sequences per 128-row tile, the last one's LP-row key tile inside the buffer
+        f.nseq_tile = fqa_nseq_tile(L, lp);   // whole sequences per tile, the last one's LP-row key tile inside the buffer
         f.group = group, f.group_stride = group_stride, f.seq_stride = seq_stride, f.tok_stride = tok_stride;
         f.scale = a.scale;
-        b.fused = f.nseq_tile * L <= 128;
+        b.fused = f.nseq_tile * L <= fqa_tile_rows(lp);
     }
     // x = x + o Wproj^T + b ; xn = LN2(x)                                               mixste.py:80,114-115
     GemmParams& pj = b.proj;
@@ -922,9 +929,9 @@ int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights* w) {
         const pafuse_block_weights* pair[2] = {&w->ste[i], &w->tte[i]};
         const int len[2] = {w->joints, w->frames};
         for (int k = 0; k < 2; ++k)   // the condition of make_block, plus the tile-capacity check it makes
-            if (w->operand_bf16 >= 2 && pair[k]->qkv_hs && pair[k]->qkv_hb && fqa_has(len[k], d) && (!fold || pair[k]->qkv_hl)) {
-                const int lp = fqa_lp(len[k]), rows = 128 + (lp == 48 ? 4 : 0);
-                n += (((rows - lp) / len[k] + 1) * len[k] <= 128) ? 1 : 0;
+            if (w->operand_bf16 >= 2 && pair[k]->qkv_hs && pair[k]->qkv_hb && fqa_has(len[k], d, w->operand_bf16) && (!fold || pair[k]->qkv_hl)) {
+                const int lp = fqa_lp(len[k], w->operand_bf16);
+                n += (fqa_nseq_tile(len[k], lp) * len[k] <= fqa_tile_rows(lp)) ? 1 : 0;
             }
     }
     return n;

@@ -3,10 +3,13 @@
 // lifetime split by in-kernel stamps (prologue = until the first chunk is visible, K loop, epilogue), in shader cycles.
 //   hipcc <library flags> -DPAFUSE_STAMPS tools/hgemm_bench.hip -o tools/bin/hgemm_bench ;  HB_FILTER=<substring> ./hgemm_bench
 #define PAFUSE_STAMPS 1
+#define PAFUSE_STAMP_SLOTS 8
+#define SL PAFUSE_STAMP_SLOTS
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 #include "../pafuse_amd/csrc/hgemm.hpp"
@@ -28,7 +31,7 @@ void run(const char* shape, GemmParams p) {
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
     const size_t nw = tiles * (T::NTHR / 64);
-    unsigned long long* st; CK(hipMalloc(&st, nw * 32)); CK(hipMemset(st, 0, nw * 32));
+    unsigned long long* st; CK(hipMalloc(&st, nw * SL * 8)); CK(hipMemset(st, 0, nw * SL * 8));
     p.stamps = st;
     int occ = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T::NTHR, lds));
@@ -39,12 +42,12 @@ void run(const char* shape, GemmParams p) {
     for (int i = 0; i < g_reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(T::NTHR), lds, 0, p);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> h(nw * 4);
-    CK(hipMemcpy(h.data(), st, nw * 32, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(nw * SL);
+    CK(hipMemcpy(h.data(), st, nw * SL * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0; size_t n = 0;
     for (size_t w = 0; w < nw; ++w) {
-        if (!h[w * 4] || !h[w * 4 + 2]) continue;
-        pro += h[w * 4 + 3] - h[w * 4]; loop += h[w * 4 + 1] - h[w * 4 + 3]; epi += h[w * 4 + 2] - h[w * 4 + 1]; ++n;
+        if (!h[w * SL] || !h[w * SL + 2]) continue;
+        pro += h[w * SL + 3] - h[w * SL]; loop += h[w * SL + 1] - h[w * SL + 3]; epi += h[w * SL + 2] - h[w * SL + 1]; ++n;
     }
     const double us = ms * 1e3 / g_reps, tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
     const double mfma = (double)(p.K / 16) * 3 * NT * 32;   // this wave's own MFMA issue cycles
@@ -65,7 +68,7 @@ void run_mlp(const char* part, MlpParams m) {
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES));
     const int64_t tiles = (m.g.M + 127) / 128;
     const size_t nw = tiles * 4;
-    unsigned long long* st; CK(hipMalloc(&st, nw * 32)); CK(hipMemset(st, 0, nw * 32));
+    unsigned long long* st; CK(hipMalloc(&st, nw * SL * 8)); CK(hipMemset(st, 0, nw * SL * 8));
     m.g.stamps = st;
     int occ = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, T::LDS_BYTES));
@@ -76,17 +79,64 @@ void run_mlp(const char* part, MlpParams m) {
     for (int i = 0; i < g_reps; ++i) hipLaunchKernelGGL(k, dim3(tiles), dim3(256), T::LDS_BYTES, 0, m);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> h(nw * 4);
-    CK(hipMemcpy(h.data(), st, nw * 32, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> h(nw * SL);
+    CK(hipMemcpy(h.data(), st, nw * SL * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, epi = 0; size_t n = 0;
     for (size_t w = 0; w < nw; ++w) {
-        if (!h[w * 4] || !h[w * 4 + 2]) continue;
-        pro += h[w * 4 + 3] - h[w * 4]; loop += h[w * 4 + 1] - h[w * 4 + 3]; epi += h[w * 4 + 2] - h[w * 4 + 1]; ++n;
+        if (!h[w * SL] || !h[w * SL + 2]) continue;
+        pro += h[w * SL + 3] - h[w * SL]; loop += h[w * SL + 1] - h[w * SL + 3]; epi += h[w * SL + 2] - h[w * SL + 1]; ++n;
     }
     const double us = ms * 1e3 / g_reps, tf = 2.0 * 2.0 * m.g.M * T::C * T::HID / (us * 1e-6) / 1e12;
     const double mfma = (double)T::NSLAB * (T::NK1 * 12 + 4 * NT2 * 3) * 32;
     printf("%-58s tiles %5ld (%.2f rounds at %d/CU) %7.2f us %6.1f TF (%.3f of 833) | per wave: prologue %5.0f  loop %6.0f (MFMA %5.0f)  epilogue %6.0f\n",
            tag, (long)tiles, (double)tiles / (256.0 * occ), occ, us, tf, tf / 833.3, n ? pro / n : 0, n ? loop / n : 0, mfma, n ? epi / n : 0);
+    fflush(stdout);
+    CK(hipFree(st));
+}
+
+// the fused qkv + attention kernel (hfqa_kernel) of one block kind: L tokens per sequence, head dim d, temporal or spatial addressing
+template <int LP, int DP, int HPW>
+void run_fqa(const char* shape, FqaParams f) {
+    using FT = HfqaTile<LP, DP, HPW>;
+    char tag[160];
+    snprintf(tag, sizeof tag, "%s qkv+attn fused <%d,%d,%d>", shape, LP, DP, HPW);
+    if (g_filter && !strstr(tag, g_filter)) return;
+    auto k = hfqa_kernel<LP, DP, HPW>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES));
+    const int64_t ntiles = (f.nseq + f.nseq_tile - 1) / f.nseq_tile;
+    const int64_t blocks = (ntiles + 7) / 8 * 8 * (f.heads / HPW);
+    const size_t nw = blocks * FT::NWV;
+    unsigned long long* st; CK(hipMalloc(&st, nw * SL * 8)); CK(hipMemset(st, 0, nw * SL * 8));
+    f.g.stamps = st;
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, FT::NTHR, FT::LDS_BYTES));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(FT::NTHR), FT::LDS_BYTES, 0, f);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < g_reps; ++i) hipLaunchKernelGGL(k, dim3(blocks), dim3(FT::NTHR), FT::LDS_BYTES, 0, f);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(nw * SL);
+    CK(hipMemcpy(h.data(), st, nw * SL * 8, hipMemcpyDeviceToHost));
+    double pro = 0, loop = 0, epi = 0; size_t n = 0;
+    for (size_t w = 0; w < nw; ++w) {
+        if (!h[w * SL] || !h[w * SL + 2]) continue;
+        pro += h[w * SL + 3] - h[w * SL]; loop += h[w * SL + 1] - h[w * SL + 3]; epi += h[w * SL + 2] - h[w * SL + 1]; ++n;
+    }
+    double p2[2] = {0, 0}, p3[2] = {0, 0};
+    for (size_t w = 0; w < nw; ++w) {
+        if (!h[w * SL] || !h[w * SL + 2]) continue;
+        unsigned long long t = h[w * SL + 1];
+        for (int hh = 0; hh < HPW; ++hh) { p2[hh] += h[w * SL + 4 + 2 * hh] - t; p3[hh] += h[w * SL + 5 + 2 * hh] - h[w * SL + 4 + 2 * hh]; t = h[w * SL + 5 + 2 * hh]; }
+    }
+    const double us = ms * 1e3 / g_reps;
+    const double mfma = (double)(f.g.K / 32) * 2 * FT::NB * 3 * 16;
+    if (n) printf("    heads: phase 2 %6.0f / phase 3 %6.0f", p2[0] / n, p3[0] / n);
+    if (n && HPW == 2) printf("  |  phase 2 %6.0f / phase 3 %6.0f", p2[1] / n, p3[1] / n);
+    if (n) printf("\n");
+    printf("%-58s wgs %6ld (%.2f rounds at %d/CU) %7.2f us | per wave: prologue %5.0f  projection loop %6.0f (MFMA %5.0f)  attention phases %6.0f\n",
+           tag, (long)blocks, (double)blocks / (256.0 * occ), occ, us, n ? pro / n : 0, n ? loop / n : 0, mfma, n ? epi / n : 0);
     fflush(stdout);
     CK(hipFree(st));
 }
@@ -146,6 +196,26 @@ int main() {
                 run<4, 1, 7, EPI_BIAS, 3, 16, 2>(shape, p);
                 run<4, 1, 7, EPI_BIAS, 2, 16, 2>(shape, p);
                 run<8, 1, 7, EPI_BIAS, 3, 16, 1>(shape, p);
+            }
+        }
+        {   // ---- qkv + attention as one kernel: the part's spatial (L = joints) and temporal (L = 27 frames) blocks
+            const int heads = 8, d = C / heads, dp = d <= 32 ? 32 : 48, J = (int)(pt.M / 27 / 40);
+            images(heads * 3 * dp, C);
+            for (int temporal = 0; temporal < 2; ++temporal) {
+                const int L = temporal ? 27 : J, lp = L <= 32 ? 32 : (L <= 48 ? 48 : 80);
+                FqaParams f{};
+                f.g.Ah = Ah, f.g.Wh = Wh, f.g.bias = vec, f.g.ln_in = stats, f.g.M = pt.M, f.g.N = heads * 3 * dp, f.g.K = C, f.g.bf16 = 3;
+                f.o = reinterpret_cast<float*>(outh), f.L = L, f.C = C, f.heads = heads, f.d = d;
+                f.nseq = temporal ? 40 * J : 40 * 27;
+                f.nseq_tile = ((lp == 80 ? 160 : 128 + (lp == 48 ? 4 : 0)) - lp) / L + 1;
+                if (temporal) f.group = J, f.group_stride = 27 * J, f.seq_stride = 1, f.tok_stride = J;
+                else f.group = 1, f.group_stride = J, f.seq_stride = 0, f.tok_stride = 1;
+                f.scale = 1.0f / sqrtf((float)d);
+                snprintf(shape, sizeof shape, "%s %s L=%d", pt.name, temporal ? "temporal" : "spatial", L);
+                if (lp == 32 && dp == 48) run_fqa<32, 48, 1>(shape, f);
+                if (lp == 32 && dp == 32) { run_fqa<32, 32, 1>(shape, f); run_fqa<32, 32, 2>(shape, f); }
+                if (lp == 48 && dp == 32) { run_fqa<48, 32, 1>(shape, f); run_fqa<48, 32, 2>(shape, f); }
+                if (lp == 80 && dp == 32) run_fqa<80, 32, 1>(shape, f);
             }
         }
         {   // ---- the MLP as one kernel (weights in natural column order: timing only)
