@@ -18,6 +18,8 @@ using namespace pafuse;
 
 static const char* g_filter = nullptr;
 static int g_reps = 20;
+static std::vector<float> g_hX, g_hW, g_hvec;
+static float g_rstd = 1.3f;   // host copies of the activations, the weights and the vector pool (value checks)
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW, bool HRES = (EPI == EPI_ROWLN)>
 void run(const char* shape, GemmParams p) {
@@ -130,6 +132,43 @@ void run_fqa(const char* shape, FqaParams f) {
         unsigned long long t = h[w * SL + 1];
         for (int hh = 0; hh < HPW; ++hh) { p2[hh] += h[w * SL + 4 + 2 * hh] - t; p3[hh] += h[w * SL + 5 + 2 * hh] - h[w * SL + 4 + 2 * hh]; t = h[w * SL + 5 + 2 * hh]; }
     }
+    {   // values: a few sequences against an fp64 evaluation on the host (q | k | v over the DP padded columns, as the kernel)
+        const int C = f.g.K, d = f.d, L = f.L;
+        std::vector<uint8_t> oh((size_t)f.g.M * C * 4);
+        CK(hipMemcpy(oh.data(), f.o, oh.size(), hipMemcpyDeviceToHost));
+        auto tok = [&](int64_t sq, int t) { return (sq / f.group) * f.group_stride + (sq % f.group) * f.seq_stride + t * f.tok_stride; };
+        double emax = 0, esum = 0; size_t en = 0;
+        const int64_t picks[6] = {0, 1, 5, f.nseq / 2, f.nseq - 2, f.nseq - 1};
+        for (int64_t sq : picks)
+            for (int head = 0; head < f.heads; head += 3) {
+                std::vector<double> q(L * DP), k(L * DP), v(L * DP);
+                for (int t = 0; t < L; ++t)
+                    for (int n = 0; n < 3 * DP; ++n) {
+                        const float* x = &g_hX[(size_t)tok(sq, t) * C];
+                        const float* w = &g_hW[(size_t)(head * 3 * DP + n) * C];
+                        double a = 0;
+                        for (int kk = 0; kk < C; ++kk) a += (double)x[kk] * w[kk];
+                        a = (double)g_rstd * a + g_hvec[head * 3 * DP + n];
+                        (n < DP ? q : (n < 2 * DP ? k : v))[t * DP + n % DP] = a;
+                    }
+                for (int t = 0; t < L; ++t) {
+                    std::vector<double> pr(L);
+                    double mx = -1e300, sum = 0;
+                    for (int u = 0; u < L; ++u) { double a = 0; for (int e = 0; e < DP; ++e) a += q[t * DP + e] * k[u * DP + e]; pr[u] = a * f.scale; mx = std::max(mx, pr[u]); }
+                    for (int u = 0; u < L; ++u) { pr[u] = exp(pr[u] - mx); sum += pr[u]; }
+                    for (int ch = 0; ch < d; ++ch) {
+                        double o = 0;
+                        for (int u = 0; u < L; ++u) o += pr[u] / sum * v[u * DP + ch];
+                        const size_t col = (size_t)head * d + ch;
+                        const _Float16* sb = reinterpret_cast<const _Float16*>(&oh[((size_t)tok(sq, t) * C + (col & ~(size_t)7)) * 4]);
+                        const double got = (double)(float)sb[col & 7] + (double)(float)sb[8 + (col & 7)] * 0.00048828125;
+                        const double e = fabs(got - o);
+                        emax = std::max(emax, e); esum += e; ++en;
+                    }
+                }
+            }
+        printf("    values vs fp64 on %zu outputs: max |err| %.3e  mean %.3e\n", en, emax, esum / en);
+    }
     const double us = ms * 1e3 / g_reps;
     const double mfma = (double)(f.g.K / 32) * 2 * FT::NB * 3 * 16;
     if (n) printf("    heads: phase 2 %6.0f / phase 3 %6.0f", p2[0] / n, p3[0] / n);
@@ -144,6 +183,7 @@ void run_fqa(const char* shape, FqaParams f) {
 int main() {
     g_filter = getenv("HB_FILTER");
     if (getenv("HB_REPS")) g_reps = atoi(getenv("HB_REPS"));
+    if (getenv("HB_RSTD")) g_rstd = (float)atof(getenv("HB_RSTD"));
     const int64_t Mmax = 73440;
     float *X, *W, *vec, *out, *x, *stats;
     uint8_t *Ah, *Wh, *outh, *xh;
@@ -153,12 +193,15 @@ int main() {
     std::vector<float> h(Mmax * 768);
     for (auto& v : h) v = (float)(rand() % 2001 - 1000) * 1e-3f;
     CK(hipMemcpy(X, h.data(), Mmax * 768 * 4, hipMemcpyHostToDevice));
+    g_hX = h;
     for (size_t i = 0; i < 1152 * 768; ++i) h[i] *= 0.05f;
     CK(hipMemcpy(W, h.data(), 1152 * 768 * 4, hipMemcpyHostToDevice));
+    g_hW.assign(h.begin(), h.begin() + 1152 * 768);
     CK(hipMemcpy(vec, h.data() + 999, 4096 * 4, hipMemcpyHostToDevice));
+    g_hvec.assign(h.begin() + 999, h.begin() + 999 + 4096);
     CK(hipMemcpy(x, h.data() + 5, Mmax * 384 * 4, hipMemcpyHostToDevice));
     std::vector<float> sth(Mmax * 2);
-    for (int64_t i = 0; i < Mmax; ++i) sth[2 * i] = 0.01f, sth[2 * i + 1] = 1.3f;
+    for (int64_t i = 0; i < Mmax; ++i) sth[2 * i] = 0.01f, sth[2 * i + 1] = g_rstd;
     CK(hipMemcpy(stats, sth.data(), Mmax * 8, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(hsplit_rows_kernel, dim3((unsigned)((Mmax * 96 + 255) / 256)), dim3(256), 0, 0, X, Ah, Mmax, 768);   // (row stride 4 K: re-made per K below)
 
