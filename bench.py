@@ -12,11 +12,13 @@ sharded (weak scaling: P = 20*N, 20 per rank) and every step ends with the singl
 per-rank predictions.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      the dominant kernel family, the linear-layer GEMMs (`gemm16_kernel` / `gemm_kernel` / `gemm_dma_kernel`; with --streams 0
-                the single-stream schedule's shared grids `grouped_bias_kernel` / `grouped_rowln_kernel`): algorithmic
-                FLOPs of the GEMM launches of one flip-TTA denoiser pass (192 part by part; 128 when proj, fc1 and fc2
-                are grouped) divided by their HIP-event time, launched back to back on the stream torch uses, against
-                416.7 TFLOP/s (bf16 matrix peak / 6 products) or the 157.3 TFLOP/s f32 matrix peak.  The timed loop runs
+  roofline      the dominant kernel family, the linear-layer launches - default (f16x2): `hfqa_kernel` (qkv + attention),
+                `hgemm_kernel` (proj; the body's fc1 and fc2), `hmlp_kernel` (fc1 + fc2 of the face and the hands in one kernel):
+                160 launches per flip-TTA denoiser pass; bf16x3: `gemm16_kernel` / `gemm_kernel` / `gemm_dma_kernel` (192, or the
+                single-stream schedule's shared grids with --streams 0); f32: `gemm_kernel`.  Algorithmic FLOPs (2 M N K per
+                linear layer) of those launches divided by their HIP-event time, launched back to back on the stream torch
+                uses, against 833.3 TFLOP/s (fp16 matrix peak / 3 products), 416.7 (bf16 / 6) or the 157.3 TFLOP/s f32 matrix
+                peak.  The timed loop runs
                 the three parts on three streams (queues), where a kernel's own duration is not observable (kernels
                 of different queues share the CUs); the replay runs the SAME kernels of the SAME launches one after
                 the other, which is the kernel-quality number, and `roofline_loop` is what the overlap makes of it.
@@ -262,9 +264,12 @@ def main():
         achieved = flops.value / (ms * 1e-3) / 1e12
         # the same for each layer kind alone (pafuse_d3dp_replay_layers): which kernels of the family are how far from peak
         by_layer = {}
-        layer_kernel = ({1: "hfqa_kernel: qkv projection + attention in one kernel (the face's spatial blocks: hgemm_kernel, qkv only)",
-                         2: "hgemm_kernel<..EPI_ROWLN> (one launch per part)", 4: "hgemm_kernel<..EPI_BIAS> (one launch per part)",
-                         8: "hgemm_kernel<..EPI_ROWLN> (one launch per part)"} if args.dtype == "f16x2" else
+        layer_kernel = ({1: "hfqa_kernel: qkv projection + attention in one kernel (every block of every part)",
+                         2: "hgemm_kernel<..EPI_ROWLN> (one launch per part)",
+                         4: "hmlp_kernel: fc1 + GELU + fc2 + residual + LayerNorms in one kernel (face, hands; its FLOPs are both layers'); "
+                            "hgemm_kernel<..EPI_BIAS> (body)",
+                         8: "hgemm_kernel<..EPI_ROWLN> (the body only: fc2 of the face and the hands is inside the fused MLP launch)"}
+                        if args.dtype == "f16x2" else
                         {1: "gemm16_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
                          8: "grouped_rowln_kernel"} if not per_part else
                         {1: "gemm16_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
@@ -318,6 +323,16 @@ def main():
         #     row instead); 16 blocks per pass; + the 139.8 MB of weights once
         per_token = 14 if (args.dtype in SPLIT_DTYPES and not args.no_ln_fold and (args.dtype == "f16x2" or args.ln_fold)) else 16
         alg_unfused = (mc * 4 * per_token * 16 + 139.8e6) / launches
+        if args.dtype == "f16x2" and not (args.no_ln_fold or args.f32_residual or args.fuse_qkv_attention == "off"):
+            # round 4's launch boundaries (4 bytes per element everywhere: fp32 or the two-slice image).  Per token and block, in
+            # units of C: qkv + attention reads x, writes o (2); proj reads o and the residual, writes x (3); the MLP as one
+            # kernel reads x (operand and residual: once from memory) and writes x (2) - as two launches it also writes and
+            # reads the 2C hidden and re-reads the residual (7)
+            fused_mlp = {"body": args.fuse_mlp == "on" and "body" in args.fuse_mlp_parts.split(","),
+                         "face": args.fuse_mlp == "auto" or (args.fuse_mlp == "on" and "face" in args.fuse_mlp_parts.split(",")),
+                         "hands": args.fuse_mlp == "auto" or (args.fuse_mlp == "on" and "hands" in args.fuse_mlp_parts.split(","))}
+            units = {k: 2 + 3 + (2 if v else 7) for k, v in fused_mlp.items()}
+            alg_unfused = (rows * 4 * 16 * (24 * 384 * units["body"] + 68 * 224 * units["face"] + 42 * 256 * units["hands"]) + 139.8e6) / launches
         alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
         mfma = ("v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
                 "v_mfma_f32_32x32x16_bf16; the qkv layers v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16x3" else
@@ -329,7 +344,7 @@ def main():
                               f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
                      "bf16": "dense bf16 matrix peak"}[args.dtype]
         products = {"bf16x3": 6, "f16x2": 3}.get(args.dtype, 1)          # matrix instructions executed per useful product
-        family = ("hgemm_kernel, hfqa_kernel (whose attention phase is inside the timed launches)" if args.dtype == "f16x2" else
+        family = ("hgemm_kernel, hfqa_kernel (whose attention phase is inside the timed launches), hmlp_kernel" if args.dtype == "f16x2" else
                   ("gemm16_kernel, gemm_kernel, gemm_dma_kernel" if per_part else
                    "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype == "bf16x3" else "gemm_kernel")
         line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {family} ({mfma})",
@@ -348,10 +363,10 @@ def main():
                                               "SQ_VALU_MFMA_BUSY_CYCLES of the same launches: profiles/r04_pmc_mfma_util.json",
                             "traffic": traffic,
                             "traffic_unit": "HBM bytes per launch",
-                            "algorithmic_bytes_per_launch": {"this_design_unfused_between_gemms": round(alg_unfused),
+                            "algorithmic_bytes_per_launch": {"this_design_launch_boundaries": round(alg_unfused),
                                                              "survey_8d_fused_blocks": round(alg_fused)},
                             "traffic_over_algorithmic": None if traffic is None else {
-                                "vs_unfused": round(traffic / alg_unfused, 2), "vs_survey_8d": round(traffic / alg_fused, 2)},
+                                "vs_this_design": round(traffic / alg_unfused, 2), "vs_survey_8d": round(traffic / alg_fused, 2)},
                             **traffic_info,
                             "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
                             "flops_per_launch": round(flops.value / n / 1e9, 3),

@@ -746,16 +746,19 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
         for (int i = 0; i < n; ++i) *flops += 2.0 * g[i].M * g[i].N * g[i].K;
         *launches += layers;
     };
-    const bool grouped = shared_grids && n >= 2;
-    auto layer = [&](GemmParams BlockLaunch::*which, bool rowln, int bit) -> int {
+    auto layer_of = [&](const BlockLaunch* bl, int n, GemmParams BlockLaunch::*which, bool rowln, int bit) -> int {
         if (!(layer_mask & bit)) return PAFUSE_OK;
+        const bool grouped = shared_grids && n >= 2;
         bool all = grouped;
         for (int i = 0; i < n; ++i) {
             g[i] = bl[i].*which;
             all = all && g[i].M > 0 && (rowln ? group_ok_rowln(g[i]) : group_ok_bias(g[i]));
         }
         const int r = rowln ? gemm_group<true>(g, n, s, shared_grids) : gemm_group<false>(g, n, s, shared_grids);
-        count(all ? 1 : n);
+        if (flops) {
+            for (int i = 0; i < n; ++i) *flops += 2.0 * g[i].M * g[i].N * g[i].K;
+            *launches += all ? 1 : n;
+        }
         for (int i = 0; i < n; ++i) {
             if (rowln) {
                 if (g[i].out_x) PAFUSE_TRACE(g[i].out_x, (size_t)g[i].M * g[i].N * 4, s);
@@ -782,21 +785,24 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
         PAFUSE_TRACE(bl[i].attn.o, (size_t)g[i].M * bl[i].attn.C * 4, s);
     }
     if (layer_mask & 1) count(n);
-    if ((rc = layer(&BlockLaunch::proj, true, 2))) return rc;
-    bool mlp_fused = true;
-    for (int i = 0; i < n; ++i) mlp_fused = mlp_fused && bl[i].mlp_fused;
-    if (mlp_fused) {   // one kernel per part for fc1 + fc2 (a replay of the fc1 layer alone runs it, of fc2 alone nothing)
-        if (!(layer_mask & 4)) return PAFUSE_OK;
-        for (int i = 0; i < n; ++i) {
-            if ((rc = fused_mlp(bl[i].mlp, s))) return rc;
-            if (flops) *flops += 2.0 * (2.0 * bl[i].fc1.M * bl[i].fc1.N * bl[i].fc1.K);
-            if (bl[i].mlp.g.out_xh) PAFUSE_TRACE(bl[i].mlp.g.out_xh, (size_t)bl[i].fc2.M * bl[i].fc2.N * 4, s);
+    if ((rc = layer_of(bl, n, &BlockLaunch::proj, true, 2))) return rc;
+    // the MLP: one kernel where the part's block has the fused form (a replay of the fc1 layer alone runs it, of fc2 alone
+    // nothing of that part), the fc1 and fc2 launches for the other parts
+    BlockLaunch rest[GROUP_MAX];
+    int nrest = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!bl[i].mlp_fused) {
+            rest[nrest++] = bl[i];
+            continue;
         }
-        if (flops) *launches += n;
-        return PAFUSE_OK;
+        if (!(layer_mask & 4)) continue;
+        if ((rc = fused_mlp(bl[i].mlp, s))) return rc;
+        if (flops) *flops += 2.0 * (2.0 * bl[i].fc1.M * bl[i].fc1.N * bl[i].fc1.K), *launches += 1;
+        if (bl[i].mlp.g.out_xh) PAFUSE_TRACE(bl[i].mlp.g.out_xh, (size_t)bl[i].fc2.M * bl[i].fc2.N * 4, s);
     }
-    if ((rc = layer(&BlockLaunch::fc1, false, 4))) return rc;
-    return layer(&BlockLaunch::fc2, true, 8);
+    if (!nrest) return PAFUSE_OK;
+    if ((rc = layer_of(rest, nrest, &BlockLaunch::fc1, false, 4))) return rc;
+    return layer_of(rest, nrest, &BlockLaunch::fc2, true, 8);
 }
 
 int run_block(const pafuse_block_weights& bw, const PartBuffers& pb, int64_t M, int C, int heads, int64_t nseq, int L,
