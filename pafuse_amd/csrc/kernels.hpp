@@ -127,7 +127,12 @@ __device__ __forceinline__ f16x8x2 split2h(const f32x4 lo4, const f32x4 hi4) {
     f16x8x2 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float x = i < 4 ? lo4[i] : hi4[i - 4];
+        float x = i < 4 ? lo4[i] : hi4[i - 4];
+        // ONE value of x for both slices: under register pressure the compiler re-evaluates the expression x came from (a GELU, a
+        // LayerNorm) for its second use, contracted differently - two results one fp32 ulp apart round to DIFFERENT fp16 values
+        // when they straddle a tie, and the low slice then belongs to another high slice than the one stored: an error of one
+        // fp16 ulp in a few elements per million (found in the register-resident form of the fused MLP, round 4)
+        asm volatile("" : "+v"(x));
         const _Float16 h = (_Float16)x;                  // RNE
         o.hi[i] = h;
         o.lo[i] = (_Float16)((x - (float)h) * 2048.0f);  // exact difference, exact scaling, RNE
@@ -138,7 +143,8 @@ __device__ __forceinline__ f16x8x2 split2h(const f32x4 lo4, const f32x4 hi4) {
 // second - [rows][K/8][hi 8 x f16 | lo 8 x f16] (weights: [w0 | w1]).  Producers that own four consecutive values of a row
 // store their halves of a sub-block: 8 bytes of hi, 8 bytes of lo.
 __device__ __forceinline__ void hsplit_store4(uint8_t* sub_block_base, int first /* 0 or 4: position inside the sub-block */,
-                                              const f32x4 v) {
+                                              f32x4 v) {
+    asm volatile("" : "+v"(v));   // one value for both slices (see split2h)
     f16x2_t h0 = {(_Float16)v[0], (_Float16)v[1]}, h1 = {(_Float16)v[2], (_Float16)v[3]};   // v_cvt_pk_f16_f32 (RNE)
     f16x2_t l0 = {(_Float16)((v[0] - (float)h0[0]) * 2048.0f), (_Float16)((v[1] - (float)h0[1]) * 2048.0f)};
     f16x2_t l1 = {(_Float16)((v[2] - (float)h1[0]) * 2048.0f), (_Float16)((v[3] - (float)h1[1]) * 2048.0f)};
