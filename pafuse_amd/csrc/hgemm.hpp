@@ -12,8 +12,11 @@
 //   * a WEIGHT image holds w0 = f16(Ws), w1 = f16(Ws - w0) of Ws = 2^k W (4 bytes per element instead of 6); the third slice
 //     w2 = f16(w0 2^-11) is four v_pk_mul_f16 per fragment, in registers (RNE into the fp16 subnormals exactly as the stored
 //     slice of the first implementation was).  Two LDS reads per weight fragment instead of three, 2/3 of the L2 stream.
-//   * tiles of 128 - 256 rows per workgroup of eight waves (four for the face's whole rows), one workgroup per CU: the weight
-//     stream per row halves against the bf16x3 family's 64-row tiles at two workgroups per CU.
+//   * 128-row tiles (the hands' whole rows: 64) on eight or four waves, one to three workgroups per CU, picked per shape
+//     with tools/hgemm_bench.hip (pafuse_hip.hip: hgemm_bias, hgemm_rowln).
+// Three kernels live here: hgemm_kernel (one linear layer: plain, or whole-row with residual + LayerNorms), hfqa_kernel (qkv
+// projection + attention of whole sequences x 1 - 2 heads) and hmlp_kernel (fc1 -> GELU -> fc2 -> whole-row epilogue with the
+// hidden activations in registers).
 // Arithmetic per product and its order (lo w2, hi w1, hi w0 into one accumulator, fp32, one rounding per MFMA; the
 // accumulator times 2^-k in the epilogue) are those of the first f16x2 kernels - same bits as gemm_tile<.., BF16 = 3> on the
 // same operands up to the order of the K sum inside a 16-deep step (identical: both feed k = 16 s + 8 h + j to lane half h).
@@ -24,9 +27,9 @@
 // s ^ ((r >> 2) & 3) (BKC = 16, 64-byte rows) - applied on the SOURCE address of the LDS-DMA (its LDS side is lane-linear)
 // and again on the fragment reads: conflict-free ds_read_b128 for both operands.
 // Accumulators are row-per-lane (the weight fragment is the MFMA's A operand): lane (r, h) of wave (wm, wn) owns token
-// m0 + 32 wm + r and, per 32-column block, the columns 8 q + 4 h + {0..3} - kernels.hpp's epilogue_row_per_lane serves the
-// whole-row layers unchanged; the plain layers transpose through LDS and store whole rows (fp32, or the H image of the
-// output with the split done on the way out).
+// m0 + 32 wm + r and, per 32-column block, the columns 8 q + 4 h + {0..3}.  Every row a tile reads or writes in its
+// epilogue goes through a per-wave LDS slab so that a wave instruction covers whole row segments (epilogue_rows_h for the
+// whole-row layers; the plain layers store fp32 rows or the H image of their output, split on the way out).
 #pragma once
 #include "kernels.hpp"
 
