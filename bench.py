@@ -418,7 +418,7 @@ def main():
         dist.destroy_process_group()
 
 
-def train_leg(dev, streams, B=37, steps=3):
+def train_leg(dev, streams, B=37, steps=6):
     """The `train` object of the inference line: D3DP train step (fwd + bwd + AdamW) at B = 37 clips, one GPU, 'bf16x3' products
     (the single-process default; `python bench.py --train` is the full training bench with its CPU baseline and DDP)."""
     import torch
@@ -426,6 +426,8 @@ def train_leg(dev, streams, B=37, steps=3):
     from pafuse_amd import synthetic as gu
     model, _ = ge.make_model(1, 1, seed=51, device=dev, is_train=True)
     model.n_aux_streams = streams
+    # (the side streams are the inference model's: pafuse_amd.d3dp keeps one set per device and process - a second set would
+    # share the process' hardware queues with the first: 376 clips/s with five streams alive against 435 - 441 with three)
     x2d, _ = gu.synthetic_inputs_2d(B=B, seed=1234)
     target = gu.synthetic_target_3d(B=B, seed=1235).to(dev)
     x2d = x2d.to(dev)
@@ -440,7 +442,8 @@ def train_leg(dev, streams, B=37, steps=3):
         opt.step()
         return loss
 
-    step()
+    for _ in range(6):      # the optimiser allocates its state in the first step, the caching allocator settles in the second, and
+        step()              # the chip has idled through the CPU baseline: a few steps bring its clocks back up
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -8,6 +8,8 @@ fp64 epsilon, stochastic update - is one call into ``pafuse_d3dp_sample`` (inclu
 import ctypes as C
 import math
 
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -27,6 +29,9 @@ def cosine_beta_schedule(timesteps, s=0.008):
     acp = acp / acp[0]
     return torch.clip(1 - (acp[1:] / acp[:-1]), 0, 0.999)
 
+
+_SHARED_AUX = {}                      # device index -> side streams of this process (D3DP._aux_for)
+_SHARED_AUX_LOCK = threading.Lock()
 
 class D3DP(nn.Module):
     def __init__(self, args, joints_left, joints_right, dataset, is_train=True, num_proposals=1,
@@ -255,8 +260,17 @@ class D3DP(nn.Module):
         stream of another device to the library)."""
         if self.aux_streams is not None:
             return [s for s in self.aux_streams if s.device == dev]
-        if dev.index not in self._aux_by_device:
-            self._aux_by_device[dev.index] = [torch.cuda.Stream(device=dev) for _ in range(self.n_aux_streams)]
+        # ONE set of side streams per device and process, shared by every D3DP instance (an inference model beside a training
+        # model, the models of successive tests ...): a HIP process drives a handful of hardware queues, and side streams
+        # beyond them share a queue with each other - measured: the training step at 376 clips/s with five streams alive in
+        # the process against 435 - 441 with three (bench.py's train leg, round 4).  Streams are lanes, not state: instances
+        # that run one after the other lose nothing, instances that run concurrently on one device stay correct (every
+        # call forks from and joins into its own stream by events) and share the lanes.
+        with _SHARED_AUX_LOCK:
+            have = _SHARED_AUX.setdefault(dev.index, [])
+            while len(have) < self.n_aux_streams:
+                have.append(torch.cuda.Stream(device=dev))
+            self._aux_by_device[dev.index] = have[:self.n_aux_streams]
         return self._aux_by_device[dev.index]
 
     def _sample_chunk(self, lib, inputs_2d, input_2d_flip, noise, steps, n_draws, flip):
