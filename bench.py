@@ -37,13 +37,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_DTYPE = "f16x2"    # the fp32-equivalent split-precision path (pafuse_amd.D3DP's inference default, round 4)
+DEFAULT_DTYPE = "bf16x3"   # split-precision products on operands that carry all 24 bits of the fp32 numbers (three bf16 slices each),
+#                            on the image pipeline of round 5 (pafuse_amd.D3DP's default)
 GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md section 3 (one denoiser pass)
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 matrix peak (opt-in --dtype bf16 runs are priced against this)
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # bf16x3: six bf16 MFMA products per fp32-equivalent product = 416.7
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3   # f16x2: three fp16 MFMA products per fp32-equivalent product = 833.3
-SPLIT_DTYPES = ("bf16x3", "f16x2")             # the fp32-equivalent split-precision modes (same kernels, same schedule)
+SPLIT_DTYPES = ("bf16x3", "bf16x3_r3", "f16x2")   # the split-precision modes
 
 
 def main():
@@ -71,7 +72,7 @@ def main():
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
-    ap.add_argument("--dtype", choices=("f32", "bf16x3", "f16x2", "bf16"), default=DEFAULT_DTYPE,
+    ap.add_argument("--dtype", choices=("f32", "bf16x3", "bf16x3_r3", "f16x2", "bf16"), default=DEFAULT_DTYPE,
                     help="matrix-product mode of the linear layers: f32 = fp32-input matrix cores; bf16x3 = split "
                          "precision (fp32 operands as three bf16 slices, six bf16 MFMA products, fp32 accumulate: "
                          "fp32-equivalent results, same parity bounds); f16x2 = split precision on the fp16 matrix cores "
@@ -197,8 +198,9 @@ def main():
     # HIP streams (hardware queues) the library spread one rank's loop over
     lanes = _lib.check(_lib.load().pafuse_d3dp_lanes(C.byref(model.config_struct(True)), B, P_local, args.streams))
     loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
-    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "f16x2": PEAK_F16X2_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
-    dtype_label = {"f32": "f32",
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "bf16x3_r3": PEAK_SPLIT_TFLOPS, "f16x2": PEAK_F16X2_TFLOPS,
+            "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
+    dtype_label = {"f32": "f32", "bf16x3_r3": "bf16x3 on the round-3 kernels",
                    "bf16x3": "bf16x3 (fp32 operands split into three bf16 slices, six bf16 MFMA products per fp32-"
                              "equivalent product, fp32 accumulate; activations and everything in memory fp32)",
                    "f16x2": "f16x2 (fp32 activations split into two fp16 slices, power-of-two-scaled fp32 weights into three, "

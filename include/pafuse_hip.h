@@ -104,6 +104,13 @@ typedef struct pafuse_mixste2_weights {
                              3: split precision "f16x2" (inference only): activations as two fp16 slices, weights as two
                                 stored + one derived (PAFUSE_SPLIT_F16X2 images in *_ws), three products per k on the fp16
                                 matrix cores - fp32-equivalent results at 5.3x the fp32 matrix rate.
+                             4: split precision "bf16x3" on the image pipeline (round 5, inference only; the default of the
+                                part-based model): the arithmetic of mode 2 - every operand the exact sum of three bf16 slices,
+                                the six products above 2^-24 relative, fp32 accumulation - with both GEMM operands as pre-split
+                                "X images" (PAFUSE_SPLIT_X images in *_ws / qkv_hs; activations split once by their producer),
+                                qkv + attention fused in every block (qkv_hs, qkv_hb required), and - with the LayerNorm
+                                folded - the residual stream kept only as the X image of x - mean(row): exactly that fp32 row.
+                                Widths 224 / 256 / 384, sequence lengths <= 80 (head dim <= 32) / <= 32 (head dim <= 48).
                              1: opt-in reduced precision - operands rounded to ONE bf16 (RNE), fp32 accumulate
                                 (BASELINE configs[1]; inference only) */
     int32_t mlp_hidden;   /* MixSTE2(mlp_ratio=...): hidden width int(C * mlp_ratio) of every block's MLP, a multiple of 32,
@@ -160,6 +167,11 @@ typedef struct pafuse_ddim_step {
 
 const char *pafuse_version(void);
 const char *pafuse_last_error(void);
+/* Layout version of the structs above (bumped whenever a field is added, moved or removed: this header has no size fields).
+ * A caller built against another header gets shifted pointers, not an error - compare with PAFUSE_ABI_VERSION at load time
+ * (pafuse_amd/_lib.py does; tests/cabi/linear_smoke.c shows the C side). */
+#define PAFUSE_ABI_VERSION 5
+int pafuse_abi_version(void);
 
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU; +2: bf16 operands (see operand_bf16).
  * K,N multiples of 32. */
@@ -199,6 +211,23 @@ int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, f
  * (act: 0 none, 1 GELU): fp32 `out` [M,N], or - when out_h is given - the H image of the output instead (either may be
  * NULL, not both).  N a multiple of 128 or 224, K of 32.  Replaces the same nn.Linear call sites (common/mixste.py:38-42,65,80). */
 #define PAFUSE_SPLIT_F16X2 4
+
+/* The bf16x3 scheme on the image pipeline (operand_bf16 == 4, round 5): the products of mode 2, both operands as "X images" -
+ * rows of 6 K bytes (K % 32 == 0), per chunk of 32 k the 32 bf16 of slice 0, then of slice 1, then of slice 2:
+ * [rows][K/32][3][32 x bf16].  x = s0 + s1 + s2 exactly (s0 = bf16(x), s1 = bf16(x - s0), s2 = bf16(x - s0 - s1), RNE, the
+ * subtractions exact), so an X image IS the fp32 tensor, bit for bit; no scaling, no range limit beyond fp32's, inf / NaN stay
+ * inf / NaN (in every slice).
+ *   weight W      pafuse_split_weights(W, N, K, PAFUSE_SPLIT_X, out, stream): 6 N K bytes = pafuse_split_weights_bytes(N, K);
+ *                 one geometry for every layer, whatever the value of the layout bits;
+ *   activation    written in this form by the kernel that PRODUCES the tensor; pafuse_xsplit_rows: X [R,K] fp32 -> its X image
+ *                 (unit tests, pafuse_block_forward).
+ * pafuse_linear_x: nn.Linear on X images (act: 0 none, 1 GELU): fp32 `out` [M,N], or - when out_x is given - the X image of the
+ * output instead.  N a multiple of 128, 224 or 96, K of 32.  Replaces the same nn.Linear call sites (common/mixste.py:38-42,65,80). */
+#define PAFUSE_SPLIT_X 8
+int pafuse_xsplit_rows(const float *X, int64_t R, int32_t K, void *out, void *stream);
+int pafuse_linear_x(const void *Ax, const void *Wx, const float *bias, float *out, void *out_x, int64_t M, int32_t N, int32_t K,
+                    int32_t act, void *stream);
+
 int pafuse_hsplit_rows(const float *X, int64_t R, int32_t K, void *out, void *stream);
 int pafuse_linear_h(const void *Ah, const void *Wh, const float *bias, float *out, void *out_h, int64_t M, int32_t N, int32_t K,
                     int32_t act, void *stream);
@@ -225,7 +254,8 @@ int pafuse_attention(const float *qkv, float *o, int64_t nseq, int32_t L, int32_
                      int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void *stream);
 
 /* x[S*L,C] <- Block(x) in place for S contiguous sequences of L tokens (Block.forward, eps 1e-6).  operand_bf16: the
- * matrix-product mode of the four linear layers (as pafuse_mixste2_weights.operand_bf16; 2 needs the *_ws images). */
+ * matrix-product mode of the four linear layers (as pafuse_mixste2_weights.operand_bf16; 2, 3 and 4 need the *_ws images of
+ * their scheme, 4 also qkv_hs / qkv_hb). */
 size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C);
 int pafuse_block_forward(const pafuse_block_weights *w, float *x, int64_t S, int32_t L, int32_t C, int32_t heads,
                          int32_t operand_bf16, void *workspace, size_t workspace_bytes, void *stream);
@@ -233,6 +263,11 @@ int pafuse_block_forward(const pafuse_block_weights *w, float *x, int64_t S, int
 /* temb[B,C] = time_mlp(t[B]);  hid_scratch: [B,2C] floats of device scratch */
 int pafuse_time_embed(const pafuse_mixste2_weights *w, const int64_t *t, int32_t B, float *temb, float *hid_scratch,
                       void *stream);
+
+/* 1 when the inference kernels of matrix-product mode `mode` (pafuse_mixste2_weights.operand_bf16) exist for a denoiser of
+ * channel width C, MLP hidden width `hidden` (0 = 2C), `heads` heads and sequences of `joints` / `frames` tokens, else 0 -
+ * callers pick mode 4 where it is supported and mode 2 elsewhere (the single-model variant, width 288). */
+int pafuse_mode_supported(int32_t mode, int32_t C, int32_t hidden, int32_t heads, int32_t joints, int32_t frames);
 
 /* How many of the 2 * depth blocks of `w` will run qkv + attention as the one fused kernel (pafuse_block_weights.qkv_hs
  * set and the block's sequence length / head dim have a fused form); negative = an error code.  Callers and tests use

@@ -57,6 +57,7 @@ class DDIMStep(C.Structure):
 SIGNATURES = {
     "pafuse_version": (C.c_char_p, []),
     "pafuse_last_error": (C.c_char_p, []),
+    "pafuse_abi_version": (C.c_int, []),
     "pafuse_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "pafuse_split_weights_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
@@ -64,6 +65,9 @@ SIGNATURES = {
     "pafuse_linear_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]),
     "pafuse_hsplit_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pafuse_xsplit_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pafuse_linear_x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
     "pafuse_linear_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
     "pafuse_mlp_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -78,6 +82,7 @@ SIGNATURES = {
     "pafuse_time_embed": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "pafuse_mixste2_fused_blocks": (C.c_int, [C.POINTER(MixSTE2Weights)]),
+    "pafuse_mode_supported": (C.c_int, [C.c_int32] * 6),
     "pafuse_mixste2_workspace_bytes": (C.c_size_t, [C.POINTER(MixSTE2Weights), C.c_int32, C.c_int32]),
     "pafuse_mixste2_forward": (C.c_int, [C.POINTER(MixSTE2Weights), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -107,7 +112,9 @@ SIGNATURES = {
 
 _lib = None
 
-KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/hgemm.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
+ABI_VERSION = 5      # include/pafuse_hip.h PAFUSE_ABI_VERSION: the struct layouts mirrored above
+
+KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/hgemm.hpp", "pafuse_amd/csrc/xgemm.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
                   "pafuse_amd/csrc/train_host.inc", "include/pafuse_hip.h")
 
 
@@ -142,8 +149,12 @@ def load(path=None):
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         lib = C.CDLL(lib_path)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None:
+                raise PafuseError(f"{lib_path} does not export {name}: a stale build - rebuild it (__graft_entry__.build())")
             fn.restype, fn.argtypes = res, args
+        if lib.pafuse_abi_version() != ABI_VERSION:    # struct layouts carry no size fields: a mismatch would shift pointers silently
+            raise PafuseError(f"{lib_path} has struct layout version {lib.pafuse_abi_version()}, these bindings {ABI_VERSION}: rebuild")
         _lib = lib
     elif path is not None and os.path.abspath(path) != os.path.abspath(getattr(_lib, "_name", "")):
         raise PafuseError("the library is already loaded from " + str(getattr(_lib, "_name", "?")))

@@ -78,11 +78,15 @@ __global__ void __launch_bounds__(256) hsplit_weights_kernel(const float* W, uin
 // cost 30 000 line transactions: 62 000 cycles of epilogue against 35 000 of K loop (tools/hgemm_bench.hip stamps).  Through
 // the slab a wave instruction moves 1 KiB in 8 lines (4 rows x 256 B).
 // LDS (the dead ring): [7 BM WN floats: cross-wave partial sums][5 BN floats: per-column vectors][NW slabs of 32 x (32 NTH + 4)].
-template <int WN, int NT, int BM, int NW, int NTH, bool HRES>   // HRES: the residual is the centred H image of x (p.resid_h)
+// SL = 3: the X pipeline (xgemm.hpp) - images are X images (three bf16 slices, 6 bytes per element, exact), ws = 1
+template <int WN, int NT, int BM, int NW, int NTH, bool HRES, int SL = 2>   // HRES: the residual is the centred image of x (p.resid_h)
 __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0, const int wm,
                                                 const int wn, const int r, const int h, const int wave, const int lane, float* smem,
                                                 const float ws) {
-    constexpr int BNV = WN * NT * 32, VEC = (7 * BM * WN + 3) / 4 * 4, SLAB0 = VEC + 5 * BNV, ST = 32 * NTH + 4;
+    static_assert(SL == 2 || SL == 3, "H image (two fp16 slices) or X image (three bf16 slices)");
+    constexpr int SEG = (HRES && SL == 3) ? 48 : 32;   // floats of a slab row per 32-column block: a row segment of the X image is 192 bytes
+    constexpr int EB = (HRES && SL == 3) ? 6 : 4;      // bytes per element of the residual's storage
+    constexpr int BNV = WN * NT * 32, VEC = (7 * BM * WN + 3) / 4 * 4, SLAB0 = VEC + 5 * BNV, ST = SEG * NTH + 4;
     constexpr int NPASS = (NT + NTH - 1) / NTH;
     float* const red = smem;
     float* const slab = smem + SLAB0 + wave * 32 * ST;
@@ -135,31 +139,32 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
 
     // ---- y = ws acc + bias + resid: the residual rows of a pass come in as whole row segments (lane l: float4 l % (8 nth) of
     // row l / (8 nth) of each group of 64 / (8 nth) rows), the next pass' loads fly while this pass is consumed
-    constexpr int LD = 32 * 8 * NTH / 64;        // float4 per lane per (full) pass
+    constexpr int Q4 = SEG / 4;                  // float4 per row and 32-column block
+    constexpr int LD = 32 * Q4 * NTH / 64;       // float4 per lane per (full) pass
     constexpr int NBUF = NT * 16 + 8 * LD <= 160 ? 2 : 1;   // the next pass in flight only where the registers allow it
     f32x4 rin[NBUF][LD];
     // (the residual is either fp32 rows or - p.resid_h - the H image of x: the same 4 bytes per element, so the same
     // row-segment loads; what differs is how a lane picks its four values out of the slab)
-    const float* const resid_rows = HRES ? reinterpret_cast<const float*>(p.resid_h) : p.resid;
+    const uint8_t* const resid_rows = HRES ? p.resid_h : reinterpret_cast<const uint8_t*>(p.resid);
     // The H image of x is CENTRED: it holds x - mean(row), so what the next GEMM multiplies has no common mode.  The mean
     // itself is carried nowhere: every reader of the residual stream is a LayerNorm (norm1, norm2, the block's post-norm, the
     // head's) or the residual add that feeds them, and LayerNorm does not see a row's mean - x and x - mean(x) give the same
     // network output.  So the residual here is the image as it is, the sum is re-centred on its own mean before it is stored,
     // and no number of the stream is ever rounded at the magnitude of an outlier mean (the fp32 reference rounds there).
     auto load_resid = [&](int ps, f32x4 (&dst)[LD]) {
-        const int nth = pass_cols(ps), qpr = 8 * nth;
+        const int nth = pass_cols(ps), qpr = Q4 * nth;
         const int ncol0 = n0 + (wn * NT + ps * NTH) * 32;
 #pragma unroll
         for (int it = 0; it < LD; ++it) {
             const int idx = it * 64 + lane, row = idx / qpr, c4 = idx % qpr;
             const int64_t mr = mw + row < p.M ? mw + row : p.M - 1;
-            if (idx < 32 * qpr) dst[it] = *reinterpret_cast<const f32x4*>(resid_rows + mr * p.N + ncol0 + 4 * c4);
+            if (idx < 32 * qpr) dst[it] = *reinterpret_cast<const f32x4*>(resid_rows + ((size_t)mr * p.N + ncol0) * EB + 16 * c4);
         }
     };
     load_resid(0, rin[0]);
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-        const int nth = pass_cols(ps), qpr = 8 * nth;
+        const int nth = pass_cols(ps), qpr = Q4 * nth;
         if (NBUF == 2 && ps + 1 < NPASS) load_resid(ps + 1, rin[(ps + 1) % NBUF]);
 #pragma unroll
         for (int it = 0; it < LD; ++it) {
@@ -176,7 +181,11 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                     const int nt = ps * NTH + j;
                     const f32x4 b4 = vec4(0, nb + 32 * nt + 8 * q);
                     f32x4 r4;
-                    if constexpr (HRES) {   // sub-block (32 j + 8 q) / 8 of the slab row: hi at + 0, lo at + 16 bytes; this lane's half 4 h
+                    if constexpr (HRES && SL == 3) {   // chunk j of the slab row: slice planes at + 0, + 64, + 128 bytes; sub-block q, this lane's half 4 h
+                        const uint8_t* sbk = reinterpret_cast<const uint8_t*>(slab + r * ST + SEG * j) + 16 * q + 8 * h;
+                        r4 = xjoin4(*reinterpret_cast<const u32x2*>(sbk), *reinterpret_cast<const u32x2*>(sbk + 64),
+                                    *reinterpret_cast<const u32x2*>(sbk + 128));   // exact: the fp32 number that was split
+                    } else if constexpr (HRES) {   // sub-block (32 j + 8 q) / 8 of the slab row: hi at + 0, lo at + 16 bytes; this lane's half 4 h
                         const uint8_t* sbk = reinterpret_cast<const uint8_t*>(slab + r * ST + 32 * j + 8 * q);
                         typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
                         const f16x4_t hi = *reinterpret_cast<const f16x4_t*>(sbk + 8 * h), lo = *reinterpret_cast<const f16x4_t*>(sbk + 16 + 8 * h);
@@ -241,9 +250,13 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
 #pragma unroll
                             for (int e = 0; e < 4; ++e) c0[e] -= mu, c1[e] -= mu;
                         }
-                        const f16x8x2 sp = split2h(c0, c1);
-                        *reinterpret_cast<f16x8*>(dsth + at * 4) = sp.hi;
-                        *reinterpret_cast<f16x8*>(dsth + at * 4 + 16) = sp.lo;
+                        if constexpr (SL == 3) {
+                            xsplit_store8(dsth + (size_t)(mw + row) * p.N * 6, ncol0 + 8 * sb, c0, c1);
+                        } else {
+                            const f16x8x2 sp = split2h(c0, c1);
+                            *reinterpret_cast<f16x8*>(dsth + at * 4) = sp.hi;
+                            *reinterpret_cast<f16x8*>(dsth + at * 4 + 16) = sp.lo;
+                        }
                     }
                 }
             }
@@ -631,60 +644,19 @@ struct HfqaTile {
 };
 __device__ __forceinline__ int hfqa_swizzle(int row) { return (((row >> 1) & 3) << 1) ^ ((row >> 3) & 1); }
 
-// phases 2 and 3 of the fused kernel, shared by its two projection forms: the accumulators (token on the lane: lane (c, qd) of
-// wave w holds, for row blocks g = 0, 1, token 32 w + 16 g + c's outputs n = 16 nb + 4 qd + {0..3}) -> q | k | v tiles in LDS ->
-// attention per (sequence, 16-query tile) -> o as the H image.  The caller has passed a workgroup barrier behind its last use
-// of the LDS.
-template <int LP, int DP, class TokenOf>
-__device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4 (&acc)[2][3 * DP / 16], float* smem, const int64_t seq0,
-                                                      const int head, const int n0, const int wave, const int c, const int qd,
-                                                      const int tid, TokenOf token_of, const f32x4 (&bias4)[3 * DP / 16], const float (&row_rstd)[2],
-                                                      const float (&row_nmr)[2], const float ws, const int hh = 0) {
-    using FT = HfqaTile<LP, DP>;
-    constexpr int NB = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS, NWV = FT::NWV, TROWS = FT::TROWS;
-    const GemmParams& p = fp.g;
-    const int L = fp.L, NSEQ = fp.nseq_tile, K = p.K;
-    // ---- phase 2: q | k | v of the tile's tokens to LDS (2^-k, bias or the folded LayerNorm applied)
+// phase 3 of the fused qkv + attention kernels (hfqa_kernel here, xfqa_kernel in xgemm.hpp): attention per (sequence of the tile,
+// 16-query tile) from the q | k | v tiles in LDS ([ROWS][DP + 4] fp32 each, token i of tile sequence s at row s L + i) -
+// attn_kernel's arithmetic per item on v_mfma_f32_16x16x4_f32 - and o written once, as the image the proj GEMM reads
+// (SL = 2: H image, SL = 3: X image).  Lane (c, qd) = (lane & 15, lane >> 4).
+template <int LP, int DP, int NWV, int ROWS, int SL, class TokenOf>
+__device__ __forceinline__ void fqa_attention_from_lds(const FqaParams& fp, float* smem, const int64_t seq0, const int head, const int wave,
+                                                       const int c, const int qd, TokenOf token_of) {
+    constexpr int LDV = DP + 4;
+    const int L = fp.L, NSEQ = fp.nseq_tile;
     float* const Qs = smem;                    // [ROWS][LDV] each
     float* const Ks = Qs + ROWS * LDV;
     float* const Vs = Ks + ROWS * LDV;
-    // (2^-k of the image, the rows' LayerNorm factors and this head's bias were fetched before / during the projection: a
-    // global load issued here costs the workgroup its whole latency, 2 - 4 thousand cycles under the other workgroups' streams)
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int r = 32 * wave + 16 * g + c;
-        const float rstd = row_rstd[g] * ws, nmr = row_nmr[g];
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
-            const f32x4 b4 = bias4[n];
-            f32x4 v;
-            if (p.ln_in && p.ln_s) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + col);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
-            } else if (p.ln_in) {   // centred A: no mean term
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[g][n][e], ws, b4[e]);
-            }
-            const int part = (16 * n) / DP, cc = col - part * DP;
-            *reinterpret_cast<f32x4*>(Qs + part * ROWS * LDV + r * LDV + cc) = v;
-        }
-    }
-    if (ROWS > TROWS)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
-        for (int i = tid; i < 3 * (ROWS - TROWS) * LDV; i += FT::NTHR) {
-            const int part = i / ((ROWS - TROWS) * LDV), rem = i % ((ROWS - TROWS) * LDV);
-            Qs[part * ROWS * LDV + TROWS * LDV + rem] = 0.f;
-        }
-    __syncthreads();
-#if PAFUSE_STAMP_SLOTS >= 8
-    PAFUSE_STAMP(4 + 2 * hh);   // diagnostic builds: q | k | v of this head are in LDS
-#endif
-
-    // ---- phase 3: attention per (sequence of the tile, 16-query tile) - attn_kernel's arithmetic per item, TWO items of a wave in
+    // attn_kernel's arithmetic per item, TWO items of a wave in
     // flight together: an item is one dependent chain (scores -> row maximum across the lane groups -> exponentials -> row sum ->
     // weights -> P V) and a wave that walks it alone waits for every cross-lane exchange and every MFMA result; the second
     // item's instructions fill those waits (same results: the items do not interact).
@@ -794,16 +766,74 @@ __device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4
         for (int u = 0; u < U; ++u) {
             const int q = qt[u] * 16 + l15;
             if (valid[u] && q < L) {   // channel ch = head d + 16 ct + 4 g4 (a multiple of 4): sub-block ch / 8, its second half when ch & 4
-                uint8_t* const hrow = reinterpret_cast<uint8_t*>(fp.o) + (size_t)token_of(rb[u] + q) * fp.C * 4;
+                uint8_t* const hrow = reinterpret_cast<uint8_t*>(fp.o) + (size_t)token_of(rb[u] + q) * fp.C * (SL == 3 ? 6 : 4);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     if (ct * 16 + 4 * g4 < fp.d) {
                         const int ch = head * fp.d + ct * 16 + 4 * g4;
-                        hsplit_store4(hrow + (ch >> 3) * 32, ch & 4, oc[u][ct]);
+                        if constexpr (SL == 3) xsplit_store4(hrow, ch, oc[u][ct]);
+                        else hsplit_store4(hrow + (ch >> 3) * 32, ch & 4, oc[u][ct]);
                     }
             }
         }
     }
+}
+
+// phases 2 and 3 of the fused kernel, shared by its two projection forms: the accumulators (token on the lane: lane (c, qd) of
+// wave w holds, for row blocks g = 0, 1, token 32 w + 16 g + c's outputs n = 16 nb + 4 qd + {0..3}) -> q | k | v tiles in LDS ->
+// attention per (sequence, 16-query tile) -> o as the H image.  The caller has passed a workgroup barrier behind its last use
+// of the LDS.
+template <int LP, int DP, class TokenOf>
+__device__ __forceinline__ void hfqa_attention_phases(const FqaParams& fp, f32x4 (&acc)[2][3 * DP / 16], float* smem, const int64_t seq0,
+                                                      const int head, const int n0, const int wave, const int c, const int qd,
+                                                      const int tid, TokenOf token_of, const f32x4 (&bias4)[3 * DP / 16], const float (&row_rstd)[2],
+                                                      const float (&row_nmr)[2], const float ws, const int hh = 0) {
+    using FT = HfqaTile<LP, DP>;
+    constexpr int NB = FT::NBH, LDV = FT::LDV, ROWS = FT::ROWS, NWV = FT::NWV, TROWS = FT::TROWS;
+    const GemmParams& p = fp.g;
+    const int L = fp.L, NSEQ = fp.nseq_tile, K = p.K;
+    // ---- phase 2: q | k | v of the tile's tokens to LDS (2^-k, bias or the folded LayerNorm applied)
+    float* const Qs = smem;                    // [ROWS][LDV] each
+    float* const Ks = Qs + ROWS * LDV;
+    float* const Vs = Ks + ROWS * LDV;
+    // (2^-k of the image, the rows' LayerNorm factors and this head's bias were fetched before / during the projection: a
+    // global load issued here costs the workgroup its whole latency, 2 - 4 thousand cycles under the other workgroups' streams)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int r = 32 * wave + 16 * g + c;
+        const float rstd = row_rstd[g] * ws, nmr = row_nmr[g];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
+            const f32x4 b4 = bias4[n];
+            f32x4 v;
+            if (p.ln_in && p.ln_s) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
+            } else if (p.ln_in) {   // centred A: no mean term
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[g][n][e], ws, b4[e]);
+            }
+            const int part = (16 * n) / DP, cc = col - part * DP;
+            *reinterpret_cast<f32x4*>(Qs + part * ROWS * LDV + r * LDV + cc) = v;
+        }
+    }
+    if (ROWS > TROWS)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
+        for (int i = tid; i < 3 * (ROWS - TROWS) * LDV; i += FT::NTHR) {
+            const int part = i / ((ROWS - TROWS) * LDV), rem = i % ((ROWS - TROWS) * LDV);
+            Qs[part * ROWS * LDV + TROWS * LDV + rem] = 0.f;
+        }
+    __syncthreads();
+#if PAFUSE_STAMP_SLOTS >= 8
+    PAFUSE_STAMP(4 + 2 * hh);   // diagnostic builds: q | k | v of this head are in LDS
+#endif
+
+    // ---- phase 3
+    fqa_attention_from_lds<LP, DP, NWV, ROWS, 2>(fp, smem, seq0, head, wave, c, qd, token_of);
 #if PAFUSE_STAMP_SLOTS >= 8
     PAFUSE_STAMP(5 + 2 * hh);   // diagnostic builds: this head's items are done
 #endif

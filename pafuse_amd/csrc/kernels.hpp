@@ -151,6 +151,63 @@ __device__ __forceinline__ void hsplit_store4(uint8_t* sub_block_base, int first
     *reinterpret_cast<u32x2*>(sub_block_base + 2 * first) = u32x2{__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1)};
     *reinterpret_cast<u32x2*>(sub_block_base + 16 + 2 * first) = u32x2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)};
 }
+// "X image" of a matrix [rows][K] (K % 32 == 0; the bf16x3 scheme on the LDS-DMA pipeline, xgemm.hpp): rows of 6 K bytes, per
+// chunk of 32 k the 32 bf16 of slice 0, then of slice 1, then of slice 2 - [rows][K/32][3][32 x bf16].  The slices of an fp32
+// number are exact (x = s0 + s1 + s2, split3), so an X image holds the fp32 tensor itself, bit for bit, in 6 bytes per element.
+__host__ __device__ inline size_t ximage_bytes(int64_t R, int64_t K) { return (size_t)R * (size_t)K * 6; }
+// byte offset of element k's slice-0 bf16 inside its row (slices 1, 2 at + 64, + 128)
+__device__ __forceinline__ size_t xoff(int k) { return (size_t)(k >> 5) * 192 + (size_t)(((k >> 3) & 3) * 16 + (k & 7) * 2); }
+// the three packed bf16 pairs of two fp32 values (low half = the first value): every step exact but the roundings to bf16
+__device__ __forceinline__ void xsplit_pair(float x0, float x1, uint32_t& s0, uint32_t& s1, uint32_t& s2) {
+    asm volatile("" : "+v"(x0), "+v"(x1));   // ONE value for all slices (see split2h: a re-evaluated input would mix two roundings)
+    SplitPair sp{x0, x1};
+    sp.stage<0>(), sp.stage<1>(), sp.stage<2>(), sp.stage<3>(), sp.stage<4>();
+    s0 = sp.s0, s1 = sp.s1, s2 = sp.s2;
+}
+// four consecutive values of a row at element k (k % 4 == 0): 8 bytes in each slice plane
+__device__ __forceinline__ void xsplit_store4(uint8_t* row_base, int k, const f32x4 v) {
+    uint32_t a0, a1, a2, b0, b1, b2;
+    xsplit_pair(v[0], v[1], a0, a1, a2);
+    xsplit_pair(v[2], v[3], b0, b1, b2);
+    uint8_t* const d = row_base + xoff(k);
+    *reinterpret_cast<u32x2*>(d) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(d + 64) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(d + 128) = u32x2{a2, b2};
+}
+// a whole sub-block of eight values at element k (k % 8 == 0): 16 bytes in each slice plane
+__device__ __forceinline__ void xsplit_store8(uint8_t* row_base, int k, const f32x4 lo, const f32x4 hi) {
+    uint32_t s0[4], s1[4], s2[4];
+    xsplit_pair(lo[0], lo[1], s0[0], s1[0], s2[0]);
+    xsplit_pair(lo[2], lo[3], s0[1], s1[1], s2[1]);
+    xsplit_pair(hi[0], hi[1], s0[2], s1[2], s2[2]);
+    xsplit_pair(hi[2], hi[3], s0[3], s1[3], s2[3]);
+    uint8_t* const d = row_base + xoff(k);
+    *reinterpret_cast<u32x4*>(d) = u32x4{s0[0], s0[1], s0[2], s0[3]};
+    *reinterpret_cast<u32x4*>(d + 64) = u32x4{s1[0], s1[1], s1[2], s1[3]};
+    *reinterpret_cast<u32x4*>(d + 128) = u32x4{s2[0], s2[1], s2[2], s2[3]};
+}
+// the fp32 values of four consecutive elements from their three packed slices (two bf16 pairs per slice): s0 + (s1 + s2),
+// both sums exact (s1 + s2 has at most 16 significant bits, the total is the number that was split)
+__device__ __forceinline__ f32x4 xjoin4(const u32x2 s0, const u32x2 s1, const u32x2 s2) {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float l0 = __builtin_bit_cast(float, s0[i] << 16), h0 = __builtin_bit_cast(float, s0[i] & 0xffff0000u);
+        const float l1 = __builtin_bit_cast(float, s1[i] << 16), h1 = __builtin_bit_cast(float, s1[i] & 0xffff0000u);
+        const float l2 = __builtin_bit_cast(float, s2[i] << 16), h2 = __builtin_bit_cast(float, s2[i] & 0xffff0000u);
+        v[2 * i] = l0 + (l1 + l2), v[2 * i + 1] = h0 + (h1 + h2);
+    }
+    return v;
+}
+__global__ void __launch_bounds__(256) xsplit_weights_kernel(const float* W, uint8_t* out, int N, int K) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one (n, sub-block of 8 k) per thread
+    const int spr = K / 8;
+    if (idx >= (int64_t)N * spr) return;
+    const int64_t n = idx / spr;
+    const int k = (int)(idx % spr) * 8;
+    const float* src = W + n * K + k;
+    xsplit_store8(out + (size_t)n * K * 6, k, *reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+}
 constexpr int HSPLIT_TAIL_BYTES = 256;   // behind a WEIGHT H image: [0] float 2^-k (what the epilogue multiplies by), [1] scratch
 __host__ __device__ inline size_t hsplit_bytes(int64_t R, int64_t K) { return (size_t)R * (size_t)K * 4 + HSPLIT_TAIL_BYTES; }
 __device__ __forceinline__ f32x16 mfma_f16_k16(const f16x8 a, const f16x8 b, f32x16 c) {
@@ -2068,6 +2125,7 @@ struct EmbedParams {
     float *x, *xn;  // [M,C]  (x may be null when only the H image of x is wanted)
     uint8_t* xh;    // f16x2 H pipeline: the H image [M,C] the first qkv hgemm reads - of x - mean(row) when `stats` is set
     //                 (LayerNorm folded), else of the normalised row (then xn is not written)
+    int x_image;    // xh is an X image (bf16x3 on the LDS-DMA pipeline, xgemm.hpp: 6 bytes per element) instead of an H image
     float* stats;   // folded LayerNorm (GemmParams::ln_in of the first qkv GEMM): (mean, rstd) of row row0 + i at stats[2 i]
     //                 instead of xn; null = write xn
     int B, P, F, J, J3, C, nflip;
@@ -2163,7 +2221,8 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
                     f32x4 cv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cv[e] = v[i][e] - mean;
-                    hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), cv);
+                    if (p.x_image) xsplit_store4(p.xh + (size_t)row * p.C * 6, 4 * c4, cv);
+                    else hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), cv);
                 }
             }
         }
@@ -2178,7 +2237,8 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g4[e] + b4[e];
-            if (live && p.xh) hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), o);
+            if (live && p.xh && p.x_image) xsplit_store4(p.xh + (size_t)row * p.C * 6, 4 * c4, o);
+            else if (live && p.xh) hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), o);
             else if (live) *reinterpret_cast<f32x4*>(p.xn + row * p.C + 4 * c4) = o;
         }
     }

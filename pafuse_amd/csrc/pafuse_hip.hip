@@ -13,6 +13,7 @@
 
 #include "kernels.hpp"
 #include "hgemm.hpp"
+#include "xgemm.hpp"
 #include "train_kernels.hpp"
 
 using namespace pafuse;
@@ -118,12 +119,14 @@ int launch_fqa(const FqaParams& f, hipStream_t s) {
 
 // padded sizes of the fused kernel for a sequence length / head dim, 0 = no fused form (the caller keeps qkv GEMM + attention)
 // (mode 3, f16x2, also has an 80-token form on five waves - 160-row tiles - for head dim <= 32: the face's 68 joints)
-static int fqa_lp(int L, int bf16 = 2) { return L <= 32 ? 32 : (L <= 48 ? 48 : (bf16 == 3 && L <= 80 ? 80 : 0)); }
+static int fqa_lp(int L, int bf16 = 2) { return L <= 32 ? 32 : (L <= 48 ? 48 : (bf16 >= 3 && L <= 80 ? 80 : 0)); }
 static int fqa_dp(int d) { return (d % 4 || d > 48) ? 0 : (d <= 32 ? 32 : 48); }
 static bool fqa_has(int L, int d, int bf16 = 2) {   // (48, 48) would need 80.4 KB of LDS: one workgroup per CU, not built
     const int lp = fqa_lp(L, bf16), dp = fqa_dp(d);
     return lp && dp && !(lp >= 48 && dp == 48);
 }
+// mode 4 (xgemm.hpp xfqa_kernel): the workgroup's columns come in whole 32-column blocks - two heads at head dim 33 .. 48
+static bool xfqa_has(int L, int d, int heads) { return fqa_has(L, d, 4) && (fqa_dp(d) == 32 || heads % 2 == 0); }
 // rows of the fused kernel's q | k | v tiles, and whole sequences per tile (the last one's LP-row key tile inside the buffer)
 static int fqa_rows(int lp) { return lp == 80 ? 160 : 128 + (lp == 48 ? 4 : 0); }
 static int fqa_tile_rows(int lp) { return lp == 80 ? 160 : 128; }
@@ -149,9 +152,37 @@ int launch_hfqa(const FqaParams& f, hipStream_t s) {
     return check_launch("hfqa_kernel");
 }
 
+// ... and in the bf16x3 X pipeline (xgemm.hpp xfqa_kernel): A and the head-major weight as X images, o as X image
+template <int LP, int DP, int HPW>
+int launch_xfqa(const FqaParams& f, hipStream_t s) {
+    using FT = XfqaTile<LP, DP, HPW>;
+    static_assert(2 * FT::LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+    if (f.heads % HPW) return fail(PAFUSE_E_SHAPE, "fused qkv-attention: %d heads do not split into groups of %d", f.heads, HPW);
+    auto k = xfqa_kernel<LP, DP, HPW>;
+    if (FT::LDS_BYTES > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, FT::LDS_BYTES);
+    }
+    if (!f.g.Ah || !f.g.Wh) return fail(PAFUSE_E_ARG, "fused qkv-attention (bf16x3 images) without the X images of its operands");
+    if (f.g.K % 32 || f.g.K <= 0) return fail(PAFUSE_E_SHAPE, "fused qkv-attention: K=%d must be a positive multiple of 32", f.g.K);
+    if (f.g.M >= (int64_t)1 << 31 || f.nseq >= (int64_t)1 << 31) return fail(PAFUSE_E_ARG, "fused qkv-attention: more than 2^31 tokens");
+    const int64_t ntiles = (f.nseq + f.nseq_tile - 1) / f.nseq_tile;
+    const int64_t blocks = (ntiles + 7) / 8 * 8 * (f.heads / HPW);
+    if (blocks <= 0 || blocks > 0x7fffffff) return fail(PAFUSE_E_ARG, "fused qkv-attention grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(FT::NTHR), FT::LDS_BYTES, s, f);
+    return check_launch("xfqa_kernel");
+}
+
 int fused_qkv_attention(const FqaParams& f, hipStream_t s) {
     if (f.nseq <= 0) return PAFUSE_OK;
     const int lp = fqa_lp(f.L, f.g.bf16), dp = fqa_dp(f.d);
+    if (f.g.bf16 == 4) {
+        if (lp == 80 && dp == 32) return launch_xfqa<80, 32, 1>(f, s);
+        if (lp == 32 && dp == 48) return launch_xfqa<32, 48, 2>(f, s);
+        if (lp == 32 && dp == 32) return f.heads % 2 ? launch_xfqa<32, 32, 1>(f, s) : launch_xfqa<32, 32, 2>(f, s);
+        if (lp == 48 && dp == 32) return f.heads % 2 ? launch_xfqa<48, 32, 1>(f, s) : launch_xfqa<48, 32, 2>(f, s);
+        return fail(PAFUSE_E_SHAPE, "fused qkv-attention: no kernel for L=%d, d=%d", f.L, f.d);
+    }
     if (f.g.bf16 == 3) {
         if (lp == 80 && dp == 32) return launch_hfqa<80, 32, 1>(f, s);
         // head dim <= 32: two heads per workgroup share the A stream (the ring grows to the 80 KB two workgroups per CU allow)
@@ -283,6 +314,55 @@ int hgemm_rowln(const GemmParams& p, hipStream_t s) {
     }
 }
 
+// ---- bf16x3 "X pipeline" (xgemm.hpp): both operands arrive as X images
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, int MINW, bool HRES = false>
+int launch_xgemm(const GemmParams& p, hipStream_t s) {
+    using T = XTile<WM, WN, NT, BKC>;
+    constexpr size_t lds = (size_t)NSTAGE * T::STAGE_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(EPI == EPI_BIAS || (size_t)7 * T::BM * WN * sizeof(float) <= lds, "cross-wave reduction scratch must fit");
+    if (!p.Ah || !p.Wh) return fail(PAFUSE_E_ARG, "bf16x3 image GEMM without the X images of its operands");
+    if (p.K % 32 || p.K <= 0 || p.N % T::BN) return fail(PAFUSE_E_SHAPE, "bf16x3 image GEMM: N=%d, K=%d do not fit the %d-column tile", p.N, p.K, T::BN);
+    if (HRES && !p.resid_h) return fail(PAFUSE_E_ARG, "bf16x3 whole-row GEMM: no X-image residual");
+    auto k = xgemm_kernel<WM, WN, NT, EPI, NSTAGE, BKC, MINW, HRES>;
+    if (lds > 64 * 1024) {
+        static DeviceOnce once;
+        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const int64_t tiles = (p.M + T::BM - 1) / T::BM * (p.N / T::BN);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, s, p);
+    return check_launch("xgemm_kernel");
+}
+
+// tile choice per shape (tools/hgemm_bench.hip -DX): six products per k make these layers matrix-bound again, so the tiles are
+// the H pipeline's with the ring re-cut for 6 bytes per element: 16-deep chunks throughout, two workgroups per CU where the
+// ring allows it (the epilogue of one tile under the K loop of the other)
+int xgemm_bias(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return PAFUSE_OK;
+    if (p.N % 128 == 0) return launch_xgemm<4, 2, 2, EPI_BIAS, 3, 16, 2>(p, s);   // 128 x 128, eight waves, 72 KB ring: two per CU
+    if (p.N % 224 == 0) return launch_xgemm<4, 1, 7, EPI_BIAS, 2, 16, 2>(p, s);   // 128 x 224 (the face: 448 = 2 x 224), 66 KB: two per CU
+    if (p.N % 96 == 0) return launch_xgemm<4, 1, 3, EPI_BIAS, 3, 16, 2>(p, s);    // 128 x 96 (unit tests: 672, 96)
+    return fail(PAFUSE_E_SHAPE, "bf16x3 image linear: N=%d must be a multiple of 128, 224 or 96", p.N);
+}
+
+int xgemm_rowln(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0) return PAFUSE_OK;
+    if (p.resid_h)   // the residual stream as its (centred) X image: the default of the folded-LayerNorm pipeline
+        switch (p.N) {
+            case 384: return launch_xgemm<4, 2, 6, EPI_ROWLN, 3, 16, 1, true>(p, s);   // 128 rows, eight waves, 144 KB ring: one per CU
+            case 256: return launch_xgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2, true>(p, s);   // 64 rows, four waves, 60 KB: two per CU
+            case 224: return launch_xgemm<4, 1, 7, EPI_ROWLN, 2, 16, 2, true>(p, s);   // 128 rows, four waves, 66 KB: two per CU
+            default: break;
+        }
+    switch (p.N) {
+        case 384: return launch_xgemm<4, 2, 6, EPI_ROWLN, 3, 16, 1>(p, s);
+        case 256: return launch_xgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2>(p, s);
+        case 224: return launch_xgemm<4, 1, 7, EPI_ROWLN, 2, 16, 2>(p, s);
+        default: return fail(PAFUSE_E_SHAPE, "no bf16x3 image whole-row kernel for channel width %d (have 224, 256, 384)", p.N);
+    }
+}
+
 // diagnostic switch, compiled only into -DPAFUSE_DIAG builds (tools/): environment PAFUSE_DEBUG_F32_MASK, read once -
 // bit 0 = plain linear layers, bit 1 = whole-row layers fall back to the fp32 matrix cores even in split-precision mode.
 // The shipped library reads no environment variable: nothing outside its arguments changes which kernels it runs.
@@ -310,6 +390,7 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
     if (p.bf16 == 3) return hgemm_bias(p, s);   // f16x2: the H pipeline
+    if (p.bf16 == 4) return xgemm_bias(p, s);   // bf16x3 on images: the X pipeline
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile
     // prologue/epilogue (measured with tools/gemm_bench.hip: 128x64 tiles reach 72-74 % of the f32 MFMA peak at the
     // qkv shape, 128x96/double-buffered 65-67 %, 128x128 58-60 %)
@@ -346,9 +427,9 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
     if (p.bf16 == 2 && (debug_f32_mask() & 2)) p.bf16 = 0;
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.K <= 0) return fail(PAFUSE_E_SHAPE, "rowln: K=%d must be a positive multiple of 32", p.K);
-    if (p.bf16 == 3) {   // f16x2: the H pipeline (inference only)
-        if constexpr (EPI == EPI_ROWLN) return hgemm_rowln(p, s);
-        else return fail(PAFUSE_E_ARG, "training has no f16x2 kernels");
+    if (p.bf16 == 3 || p.bf16 == 4) {   // f16x2: the H pipeline; bf16x3 on images: the X pipeline (inference only)
+        if constexpr (EPI == EPI_ROWLN) return p.bf16 == 3 ? hgemm_rowln(p, s) : xgemm_rowln(p, s);
+        else return fail(PAFUSE_E_ARG, "training has no image-pipeline kernels");
     }
     if constexpr (EPI == EPI_ROWLN_TRAIN) {   // training forward with split products: the three PAFUSE widths (train_host.inc)
         if (p.bf16 == 2) {
@@ -509,24 +590,29 @@ int attention(const AttnParams& p, hipStream_t s) {
 // --------------------------------------------------------------------------------------- per-part activations
 struct PartBuffers {
     float *x, *xn, *o, *wide;  // [M,C], [M,C], [M,C], [M,3C] (qkv, then the MLP hidden [M,2C])
-    //                            f16x2 mode: xn, o and (as the hidden) wide hold H images of those tensors - same bytes
+    //                            f16x2 mode: xn, o and (as the hidden) wide hold H images of those tensors - same bytes;
+    //                            bf16x3 on images (mode 4): X images, 6 bytes per element - xn and o are carved at that size
+    //                            (`eb`), the [M,2C] hidden image is exactly the [M,3C] floats of `wide`
+    int eb;                    // bytes per element of xn and o: 4, or 6 in mode 4
     float* temb;               // [B,C]
     float* pred;               // [M,3]
     float* stats;              // [M,2] (mean, rstd) of a row when the LayerNorm is folded into the consumer GEMM
 };
 
-size_t part_buffer_bytes(int64_t M, int C, int B) {
-    return 3 * align_up((size_t)M * C * 4) + align_up((size_t)M * 3 * C * 4) + align_up((size_t)B * C * 4) +
+static int image_elem_bytes(int operand_mode) { return operand_mode == 4 ? 6 : 4; }
+size_t part_buffer_bytes(int64_t M, int C, int B, int eb = 4) {
+    return align_up((size_t)M * C * 4) + 2 * align_up((size_t)M * C * eb) + align_up((size_t)M * 3 * C * 4) + align_up((size_t)B * C * 4) +
            align_up((size_t)M * 3 * 4) + align_up((size_t)M * 2 * 4);
 }
 
-char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb) {
+char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb, int eb = 4) {
+    pb.eb = eb;
     pb.x = (float*)base;
     base += align_up((size_t)M * C * 4);
     pb.xn = (float*)base;
-    base += align_up((size_t)M * C * 4);
+    base += align_up((size_t)M * C * eb);
     pb.o = (float*)base;
-    base += align_up((size_t)M * C * 4);
+    base += align_up((size_t)M * C * eb);
     pb.wide = (float*)base;
     base += align_up((size_t)M * 3 * C * 4);
     pb.temb = (float*)base;
@@ -542,7 +628,8 @@ char* carve_part(char* base, int64_t M, int C, int B, PartBuffers& pb) {
 // that run on different streams; temb and the scratch behind `wide` stay shared / are offset like the rest)
 PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
     PartBuffers o = pb;
-    o.x = pb.x + row0 * C, o.xn = pb.xn + row0 * C, o.o = pb.o + row0 * C, o.wide = pb.wide + row0 * 3 * C;
+    const int64_t img = row0 * C * pb.eb / 4;   // (floats; C is a multiple of 32)
+    o.x = pb.x + row0 * C, o.xn = pb.xn + img, o.o = pb.o + img, o.wide = pb.wide + row0 * 3 * C;
     o.pred = pb.pred + row0 * 3;
     o.stats = pb.stats + row0 * 2;
     return o;
@@ -550,7 +637,7 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
 
 static bool ln_folded(const pafuse_mixste2_weights* w) { return w->ste[0].qkv_ls != nullptr; }
 // f16x2 with the LayerNorm folded: the residual stream between the blocks lives in memory as its H image only
-static bool h_residual_only(const pafuse_mixste2_weights* w) { return w->operand_bf16 == 3 && ln_folded(w) && !w->keep_f32_residual; }
+static bool h_residual_only(const pafuse_mixste2_weights* w) { return w->operand_bf16 >= 3 && ln_folded(w) && !w->keep_f32_residual; }
 
 // `training`: the training entry points make the images of the weights they multiply themselves (weights change every step)
 int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
@@ -564,22 +651,30 @@ int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
     if (d % 4 || d > 48) return fail(PAFUSE_E_SHAPE, "head dim %d unsupported", d);
     if (w->joints < 1 || w->joints > 144 || w->frames < 1 || w->frames > 144)
         return fail(PAFUSE_E_SHAPE, "sequence lengths J=%d F=%d must be in 1..144", w->joints, w->frames);
-    if (w->operand_bf16 < 0 || w->operand_bf16 > 3) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
-    if (w->operand_bf16 == 3) {   // f16x2: the PAFUSE part widths; plain layers that tile by 128 or 224 columns
+    if (w->operand_bf16 < 0 || w->operand_bf16 > 4) return fail(PAFUSE_E_ARG, "matrix-product mode %d", w->operand_bf16);
+    if (w->operand_bf16 >= 3) {   // the image pipelines: the PAFUSE part widths; plain layers that tile by 128 or 224 columns
         const int hidden = w->mlp_hidden > 0 ? w->mlp_hidden : 2 * w->channels;
         if (!hgemm_width(w->channels) || !hgemm_plain_n(3 * w->channels) || !hgemm_plain_n(hidden) || hidden % 32)
-            return fail(PAFUSE_E_SHAPE, "f16x2 products serve the widths 224 / 256 / 384 with an MLP hidden width that is a multiple "
-                                        "of 128 or 224 (got C = %d, hidden = %d): use 'bf16x3'", w->channels, hidden);
+            return fail(PAFUSE_E_SHAPE, "the image pipelines (f16x2, bf16x3 on images) serve the widths 224 / 256 / 384 with an MLP hidden "
+                                        "width that is a multiple of 128 or 224 (got C = %d, hidden = %d): use mode 2", w->channels, hidden);
+    }
+    if (w->operand_bf16 == 4 && !training) {   // bf16x3 on images: qkv + attention fused in every block (no unfused attention on X images)
+        for (int i = 0; i < w->depth; ++i)
+            for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]})
+                if (!b->qkv_hs || !b->qkv_hb) return fail(PAFUSE_E_ARG, "bf16x3 on images needs the head-major qkv image of every block (qkv_hs, qkv_hb)");
+        if (!xfqa_has(w->joints, d, w->heads) || !xfqa_has(w->frames, d, w->heads))
+            return fail(PAFUSE_E_SHAPE, "bf16x3 on images: no fused qkv + attention form for sequences of %d / %d tokens at head dim %d, %d heads: "
+                                        "use mode 2", w->joints, w->frames, d, w->heads);
     }
     if (w->mlp_hidden < 0 || (w->mlp_hidden > 0 && (w->mlp_hidden % 32 || w->mlp_hidden > 3 * w->channels)))
         return fail(PAFUSE_E_SHAPE, "mlp hidden width %d must be a multiple of 32 and at most 3C = %d", w->mlp_hidden, 3 * w->channels);
     if (!(w->qk_scale >= 0.f)) return fail(PAFUSE_E_ARG, "qk_scale must be positive (0 = head_dim^-0.5)");
-    if (training && (w->operand_bf16 == 1 || w->operand_bf16 == 3))
+    if (training && (w->operand_bf16 == 1 || w->operand_bf16 >= 3))
         return fail(PAFUSE_E_ARG, "training runs fp32 ('f32') or split-precision ('bf16x3') products");
     if (w->operand_bf16 >= 2 && !training)
         for (int i = 0; i < w->depth; ++i)
             for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]})
-                if (!b->qkv_ws || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)
+                if ((!b->qkv_ws && w->operand_bf16 != 4) || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)   // (mode 4 multiplies qkv_hs only)
                     return fail(PAFUSE_E_ARG, "split-precision mode needs the pre-split image of every linear weight "
                                               "(pafuse_split_weights)");
     // a folded LayerNorm (pafuse_block_weights.qkv_ls ...) is a property of the whole denoiser: the producer of a block's
@@ -626,7 +721,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     float* const stats = pb.stats;
     // f16x2 (bf16 == 3): every GEMM operand is an H image - xn (of x with the fold, else of LN(x)), o, and the MLP hidden in
     // `wide` are written in that form by their producers (hgemm.hpp); the *_ws pointers are the weights' H images
-    const bool hp = bf16 == 3;
+    const bool hp = bf16 >= 3;   // (mode 4, bf16x3 on images: the same flow on X images - 6 bytes per element, exact)
     uint8_t* const xn_h = reinterpret_cast<uint8_t*>(pb.xn);
     const bool h_residual = hp && fold && !keep_f32_residual;
     // qkv = LN1(x) Wqkv^T + b        (xn already holds LN1(x))                         mixste.py:65
@@ -643,7 +738,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     if (hp) a.o_h = reinterpret_cast<uint8_t*>(pb.o);
     // the two in one kernel where a head-major image was supplied and the shape has a fused form
     b.fused = false;
-    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && fqa_has(L, C / heads, bf16) && (!fold || bw.qkv_hl)) {
+    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && (bf16 == 4 ? xfqa_has(L, C / heads, heads) : fqa_has(L, C / heads, bf16)) && (!fold || bw.qkv_hl || bf16 == 4)) {
         const int lp = fqa_lp(L, bf16), dp = fqa_dp(C / heads);
         FqaParams& f = b.fqa;
         f.g = g;
@@ -701,7 +796,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     // the two MLP launches as one kernel: the hidden activations stay in registers (hgemm.hpp hmlp_kernel); fc2_hp is the H
     // image of fc2.weight with the columns of each group of 16 in the order the kernel's accumulators hand them over
     b.mlp_fused = false;
-    if (h_residual && bw.fc2_hp && hmlp_has(C, hidden)) {
+    if (h_residual && bf16 == 3 && bw.fc2_hp && hmlp_has(C, hidden)) {
         MlpParams& m = b.mlp;
         m.g = f2;
         m.g.Ah = xn_h, m.g.Wh = (const uint8_t*)bw.fc2_hp;
@@ -779,6 +874,7 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
             PAFUSE_TRACE(bl[i].attn.o, (size_t)g[i].M * bl[i].attn.C * 4, s);
             continue;
         }
+        if (g[i].bf16 == 4) return fail(PAFUSE_E_SHAPE, "bf16x3 on images: this block has no fused qkv + attention form");
         if ((layer_mask & 1) && (rc = gemm_bias(g[i], s))) return rc;
         PAFUSE_TRACE(g[i].out, (size_t)g[i].M * g[i].N * 4, s);
         if (!gemms_only && (rc = attention(bl[i].attn, s))) return rc;
@@ -896,12 +992,13 @@ extern "C" {
 
 const char* pafuse_version(void) {
 #ifdef PAFUSE_NO_PACKED_F32
-    return "pafuse_hip 0.4 (gfx950, f32 MFMA + split bf16x3 / f16x2 MFMA, no packed-fp32 VALU)";
+    return "pafuse_hip 0.5 (gfx950, f32 MFMA + split bf16x3 / f16x2 MFMA, no packed-fp32 VALU)";
 #else
-    return "pafuse_hip 0.4 (gfx950, f32 MFMA + split bf16x3 / f16x2 MFMA, packed-fp32 VALU: 16-bit MFMA modes on one stream)";
+    return "pafuse_hip 0.5 (gfx950, f32 MFMA + split bf16x3 / f16x2 MFMA, packed-fp32 VALU: 16-bit MFMA modes on one stream)";
 #endif
 }
 const char* pafuse_last_error(void) { return g_err; }
+int pafuse_abi_version(void) { return PAFUSE_ABI_VERSION; }
 
 #ifdef PAFUSE_DIAG
 /* diagnostic builds only (not declared in include/pafuse_hip.h): hash every intermediate of the following passes of this
@@ -925,6 +1022,16 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
 
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
 
+int pafuse_mode_supported(int32_t mode, int32_t C, int32_t hidden, int32_t heads, int32_t joints, int32_t frames) {
+    if (mode < 0 || mode > 4 || heads <= 0 || C <= 0 || C % heads) return 0;
+    if (hidden <= 0) hidden = 2 * C;
+    const int d = C / heads;
+    if (!width_supported(C) || d % 4 || d > 48 || joints < 1 || joints > 144 || frames < 1 || frames > 144) return 0;
+    if (mode >= 3 && (!hgemm_width(C) || !hgemm_plain_n(3 * C) || !hgemm_plain_n(hidden) || hidden % 32)) return 0;
+    if (mode == 4 && (!xfqa_has(joints, d, heads) || !xfqa_has(frames, d, heads))) return 0;
+    return 1;
+}
+
 int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights* w) {
     int rc = check_weights(w);
     if (rc) return rc;
@@ -935,7 +1042,9 @@ int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights* w) {
         const pafuse_block_weights* pair[2] = {&w->ste[i], &w->tte[i]};
         const int len[2] = {w->joints, w->frames};
         for (int k = 0; k < 2; ++k)   // the condition of make_block, plus the tile-capacity check it makes
-            if (w->operand_bf16 >= 2 && pair[k]->qkv_hs && pair[k]->qkv_hb && fqa_has(len[k], d, w->operand_bf16) && (!fold || pair[k]->qkv_hl)) {
+            if (w->operand_bf16 >= 2 && pair[k]->qkv_hs && pair[k]->qkv_hb &&
+                (w->operand_bf16 == 4 ? xfqa_has(len[k], d, w->heads) : fqa_has(len[k], d, w->operand_bf16)) &&
+                (!fold || pair[k]->qkv_hl || w->operand_bf16 == 4)) {
                 const int lp = fqa_lp(len[k], w->operand_bf16);
                 n += (fqa_nseq_tile(len[k], lp) * len[k] <= fqa_tile_rows(lp)) ? 1 : 0;
             }
@@ -949,6 +1058,10 @@ int pafuse_split_weights(const float* W, int32_t N, int32_t K, int32_t layout, v
     if (N <= 0 || K <= 0 || K % BK) return fail(PAFUSE_E_SHAPE, "split_weights: N=%d, K=%d (K must be a positive multiple of 32)", N, K);
     const int64_t n = (int64_t)N * (K / 8);
     const dim3 grid((unsigned)((n + 255) / 256));
+    if (layout & PAFUSE_SPLIT_X) {   // the X image (bf16x3 on the LDS-DMA pipeline): one geometry for every layer, no scaling, no tail
+        hipLaunchKernelGGL(xsplit_weights_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, (uint8_t*)out, N, K);
+        return check_launch("xsplit_weights_kernel");
+    }
     if (layout & PAFUSE_SPLIT_F16X2) {   // the f16x2 H image (one geometry for every layer): largest |W| first, then the slices
         hipStream_t st = (hipStream_t)stream;
         uint8_t* const tail = (uint8_t*)out + (size_t)N * K * 4;
@@ -991,6 +1104,27 @@ int pafuse_hsplit_rows(const float* X, int64_t R, int32_t K, void* out, void* st
     if ((n + 255) / 256 > 0x7fffffff) return fail(PAFUSE_E_ARG, "hsplit_rows: grid out of range");
     hipLaunchKernelGGL(hsplit_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, (uint8_t*)out, R, K);
     return check_launch("hsplit_rows_kernel");
+}
+
+int pafuse_xsplit_rows(const float* X, int64_t R, int32_t K, void* out, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!X || !out || R < 0) return fail(PAFUSE_E_ARG, "xsplit_rows: null pointer or negative row count");
+    if (K <= 0 || K % 32) return fail(PAFUSE_E_SHAPE, "xsplit_rows: K=%d must be a positive multiple of 32", K);
+    if (R == 0) return PAFUSE_OK;
+    const int64_t n = R * (K / 8);
+    if ((n + 255) / 256 > 0x7fffffff) return fail(PAFUSE_E_ARG, "xsplit_rows: grid out of range");
+    hipLaunchKernelGGL(xsplit_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, (uint8_t*)out, R, K);
+    return check_launch("xsplit_rows_kernel");
+}
+
+int pafuse_linear_x(const void* Ax, const void* Wx, const float* bias, float* out, void* out_x, int64_t M, int32_t N, int32_t K,
+                    int32_t act, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!Ax || !Wx || !bias || (!out && !out_x) || M < 0) return fail(PAFUSE_E_ARG, "linear_x: null pointer or negative M");
+    GemmParams g{};
+    g.Ah = (const uint8_t*)Ax, g.Wh = (const uint8_t*)Wx, g.bias = bias, g.out = out, g.out_h = (uint8_t*)out_x;
+    g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = 4;
+    return gemm_bias(g, (hipStream_t)stream);
 }
 
 int pafuse_linear_h(const void* Ah, const void* Wh, const float* bias, float* out, void* out_h, int64_t M, int32_t N, int32_t K,
@@ -1039,15 +1173,18 @@ int pafuse_attention(const float* qkv, float* o, int64_t nseq, int32_t L, int32_
     return attention(a, (hipStream_t)stream);
 }
 
-size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C) { return part_buffer_bytes(rows, C, 1); }
+size_t pafuse_block_workspace_bytes(int64_t rows, int32_t C) { return part_buffer_bytes(rows, C, 1, 6); }
 
 int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int32_t L, int32_t C, int32_t heads,
                          int32_t operand_bf16, void* workspace, size_t workspace_bytes, void* stream) {
     StreamDevice on_stream_device(stream);
     if (!w || !x || !workspace || S < 0) return fail(PAFUSE_E_ARG, "block_forward: bad argument");
-    if (operand_bf16 < 0 || operand_bf16 > 3) return fail(PAFUSE_E_ARG, "block_forward: matrix-product mode %d", operand_bf16);
-    if (operand_bf16 == 3 && !hgemm_width(C)) return fail(PAFUSE_E_SHAPE, "block_forward: f16x2 products serve the widths 224 / 256 / 384");
-    if (operand_bf16 >= 2 && (!w->qkv_ws || !w->proj_ws || !w->fc1_ws || !w->fc2_ws))
+    if (operand_bf16 < 0 || operand_bf16 > 4) return fail(PAFUSE_E_ARG, "block_forward: matrix-product mode %d", operand_bf16);
+    if (operand_bf16 >= 3 && !hgemm_width(C)) return fail(PAFUSE_E_SHAPE, "block_forward: the image pipelines serve the widths 224 / 256 / 384");
+    if (operand_bf16 == 4 && (heads <= 0 || C % heads || !w->qkv_hs || !w->qkv_hb || !xfqa_has(L, C / heads, heads)))
+        return fail(PAFUSE_E_ARG, "block_forward: bf16x3 on images needs the head-major qkv image (qkv_hs, qkv_hb) and a sequence length / head "
+                                  "dim with a fused qkv + attention form");
+    if (operand_bf16 >= 2 && ((!w->qkv_ws && operand_bf16 != 4) || !w->proj_ws || !w->fc1_ws || !w->fc2_ws))
         return fail(PAFUSE_E_ARG, "block_forward: split-precision mode needs the pre-split image of every linear weight");
     if (!width_supported(C)) return fail(PAFUSE_E_SHAPE, "channel width %d has no kernel", C);
     if (heads <= 0 || C % heads) return fail(PAFUSE_E_SHAPE, "block_forward: heads %d must divide C %d", heads, C);
@@ -1057,12 +1194,13 @@ int pafuse_block_forward(const pafuse_block_weights* w, float* x, int64_t S, int
     if (M == 0) return PAFUSE_OK;
     hipStream_t s = (hipStream_t)stream;
     PartBuffers pb;
-    carve_part((char*)workspace, M, C, 1, pb);
+    carve_part((char*)workspace, M, C, 1, pb, 6);
     pb.x = x;
-    // f16x2: the qkv GEMM reads the H image of LN1(x) - the fp32 rows pass through `wide` (free until qkv writes it)
-    int rc = pafuse_layernorm(x, w->norm1_w, w->norm1_b, operand_bf16 == 3 ? pb.wide : pb.xn, M, C, 1e-6f, stream);
+    // image pipelines: the qkv GEMM reads the image of LN1(x) - the fp32 rows pass through `wide` (free until qkv writes it)
+    int rc = pafuse_layernorm(x, w->norm1_w, w->norm1_b, operand_bf16 >= 3 ? pb.wide : pb.xn, M, C, 1e-6f, stream);
     if (rc) return rc;
     if (operand_bf16 == 3 && (rc = pafuse_hsplit_rows(pb.wide, M, C, pb.xn, stream))) return rc;
+    if (operand_bf16 == 4 && (rc = pafuse_xsplit_rows(pb.wide, M, C, pb.xn, stream))) return rc;
     BlockTail t{};  // plain Block.forward: no post norm, nothing after
     return run_block(*w, pb, M, C, heads, S, L, 1, L, 0, 1, t, s, false, nullptr, nullptr, operand_bf16);
 }
@@ -1078,7 +1216,7 @@ int pafuse_time_embed(const pafuse_mixste2_weights* w, const int64_t* t, int32_t
 
 size_t pafuse_mixste2_workspace_bytes(const pafuse_mixste2_weights* w, int32_t B, int32_t P) {
     if (!w) return 0;
-    return part_buffer_bytes((int64_t)B * P * w->frames * w->joints, w->channels, B);
+    return part_buffer_bytes((int64_t)B * P * w->frames * w->joints, w->channels, B, image_elem_bytes(w->operand_bf16));
 }
 
 int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, const float* x3d, const int64_t* t,
@@ -1092,7 +1230,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     hipStream_t s = (hipStream_t)stream;
     const int64_t R = (int64_t)B * P, M = R * w->frames * w->joints;
     PartBuffers pb;
-    carve_part((char*)workspace, M, w->channels, B, pb);
+    carve_part((char*)workspace, M, w->channels, B, pb, image_elem_bytes(w->operand_bf16));
     if ((rc = launch_time_embed(w, t, 0, B, pb.temb, pb.wide, s))) return rc;
 #ifdef PAFUSE_DIAG
     if (g_snap) (void)hipMemcpyAsync(g_snap + M * w->channels, pb.temb, (size_t)B * w->channels * 4, hipMemcpyDeviceToDevice, s);
@@ -1102,7 +1240,8 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.pw = w->patch_w, e.pb = w->patch_b, e.pos = w->pos_spatial, e.temb = pb.temb;
     e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
     e.x = pb.x, e.xn = pb.xn, e.stats = ln_folded(w) ? pb.stats : nullptr;
-    e.xh = w->operand_bf16 == 3 ? reinterpret_cast<uint8_t*>(pb.xn) : nullptr;
+    e.xh = w->operand_bf16 >= 3 ? reinterpret_cast<uint8_t*>(pb.xn) : nullptr;
+    e.x_image = w->operand_bf16 == 4;
     if (h_residual_only(w)) e.x = nullptr;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
@@ -1125,7 +1264,7 @@ size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config* cfg, int32_t B, int
     size_t total = align_up((size_t)B * P * cfg->frames * cfg->num_kps * 3 * 4);  // img
     for (int i = 0; i < cfg->num_parts; ++i) {
         const pafuse_mixste2_weights& w = cfg->part[i];
-        total += part_buffer_bytes((int64_t)nflip * B * P * w.frames * w.joints, w.channels, B);
+        total += part_buffer_bytes((int64_t)nflip * B * P * w.frames * w.joints, w.channels, B, image_elem_bytes(w.operand_bf16));
     }
     return total;
 }
@@ -1187,7 +1326,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     base += align_up((size_t)img_elems * 4);
     PartBuffers pb[PAFUSE_MAX_PARTS];
     for (int i = 0; i < NP; ++i)
-        base = carve_part(base, R * F * cfg->part[i].joints, cfg->part[i].channels, B, pb[i]);
+        base = carve_part(base, R * F * cfg->part[i].joints, cfg->part[i].channels, B, pb[i], image_elem_bytes(cfg->part[i].operand_bf16));
 
     // Parts are independent inside a step, and so are hypotheses: with aux streams the work of a step is cut into
     // (part, hypothesis-group) lanes, each a chain of small launches on its own stream, so that the ramp-up and
@@ -1261,7 +1400,8 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.n_w = w->ste[0].norm1_w, e.n_b = w->ste[0].norm1_b, e.n_eps = 1e-6f;
             e.x = pb[i].x, e.xn = pb[i].xn;
             e.stats = ln_folded(w) ? pb[i].stats + row0 * 2 : nullptr;   // where offset_rows puts this group's statistics
-            e.xh = w->operand_bf16 == 3 ? reinterpret_cast<uint8_t*>(pb[i].xn) : nullptr;   // (indexed by the absolute row)
+            e.xh = w->operand_bf16 >= 3 ? reinterpret_cast<uint8_t*>(pb[i].xn) : nullptr;   // (indexed by the absolute row)
+            e.x_image = w->operand_bf16 == 4;
             if (h_residual_only(w)) e.x = nullptr;
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
             e.do_clamp = 1, e.scale = (float)cfg->scale, e.lim = (float)(1.1 * cfg->scale), e.row0 = row0, e.nrows = nrows;
@@ -1414,7 +1554,7 @@ int pafuse_d3dp_replay_layers(const pafuse_d3dp_config* cfg, int32_t B, int32_t 
     const pafuse_mixste2_weights* ws[PAFUSE_MAX_PARTS];
     int64_t Rs[PAFUSE_MAX_PARTS];
     for (int i = 0; i < cfg->num_parts; ++i) {
-        base = carve_part(base, R * cfg->frames * cfg->part[i].joints, cfg->part[i].channels, B, pb[i]);
+        base = carve_part(base, R * cfg->frames * cfg->part[i].joints, cfg->part[i].channels, B, pb[i], image_elem_bytes(cfg->part[i].operand_bf16));
         ws[i] = &cfg->part[i], Rs[i] = R;
     }
     if (parts_groupable(cfg)) {  // the schedule pafuse_d3dp_sample runs: block k of every part in shared grids

@@ -129,18 +129,19 @@ class D3DP(nn.Module):
         #                                 the clip axis (clips are independent, results are bit-identical); bounds the
         #                                 workspace (0.9 GB per 40 rows) and keeps activations cache-resident
         self._graphs = {}
-        # matrix-product mode: the split-precision products (fp32-equivalent: as close to an fp64 evaluation as the
-        # reference's own fp32 arithmetic - tests/test_hip_parity.py, tests/test_hip_fullsize.py for the loop,
-        # tests/test_hip_train.py for the gradients).  Inference of the part-based model: 'f16x2' (three fp16 MFMA products,
-        # the H pipeline of csrc/hgemm.hpp; widths 224 / 256 / 384); the single-model variant (width 288) and training:
-        # 'bf16x3' - training under torch.distributed with more than one rank: 'f32' (see _training_precision);
-        # 'f32' stays selectable everywhere
-        default = "bf16x3" if (is_train or not self.part_based) else "f16x2"
+        # matrix-product mode: 'bf16x3' everywhere - split-precision products whose operands carry all 24 bits of the fp32
+        # numbers they stand for (three bf16 slices each, six bf16 MFMA products, fp32 accumulation: fp32-equivalent, as close
+        # to an fp64 evaluation as the reference's own fp32 arithmetic - tests/test_hip_parity.py, tests/test_hip_fullsize.py
+        # for the loop, tests/test_hip_train.py for the gradients).  Inference of the part-based model runs them on the image
+        # pipeline (round 5, csrc/xgemm.hpp; widths 224 / 256 / 384); the single-model variant (width 288) and training on the
+        # round-3 kernels (MixSTE2.effective_mode) - training under torch.distributed with more than one rank: 'f32' (see
+        # _training_precision).  'f16x2' (three fp16 MFMA products on 22-23-bit operands: faster, an opt-in since round 5),
+        # 'f32' and 'bf16x3_r3' (the round-3 kernels everywhere) stay selectable
         for m in self.denoisers().values():
-            m.operand_bf16 = self.PRECISIONS[default]
+            m.operand_bf16 = self.PRECISIONS["bf16x3"]
         self.allow_split_products_under_ddp = False
 
-    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3_r3": 2, "f16x2": 3, "bf16x3": 4}
 
     def denoisers(self):
         """{name: MixSTE2} in the order of the library's part table: the per-part models, or {'all': the single model}."""
@@ -150,10 +151,12 @@ class D3DP(nn.Module):
     def precision(self):
         """Matrix-product mode of the denoisers' linear layers (everything else, and every tensor in memory, is fp32):
         'f32'    fp32-input matrix cores, a k-ordered fp32 FMA chain per output;
-        'bf16x3' split precision (inference): fp32 operands as three bf16 slices, six bf16 MFMA products, fp32
-                 accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h);
-        'f16x2'  split precision (inference): activations as two fp16 slices, weights as three (power-of-two scaled), THREE
-                 fp16 MFMA products, fp32 accumulation - fp32-equivalent results at 5.3x the matrix rate;
+        'bf16x3' split precision (the default): fp32 operands as three bf16 slices (exact), six bf16 MFMA products, fp32
+                 accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h); on the image pipeline
+                 (mode 4) where it has kernels, else on the round-3 kernels (mode 2);
+        'bf16x3_r3' the same products on the round-3 kernels everywhere (A/B, tests);
+        'f16x2'  opt-in split precision (inference): activations as two fp16 slices (22-23 bits), weights as two stored + one
+                 derived slice (power-of-two scaled), THREE fp16 MFMA products, fp32 accumulation - 5.3x the matrix rate;
         'bf16'   opt-in reduced precision: operands rounded to one bf16 (BASELINE configs[1])."""
         modes = {int(m.operand_bf16) for m in self.denoisers().values()}
         if len(modes) != 1:
@@ -165,7 +168,7 @@ class D3DP(nn.Module):
         if value not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         if self.is_train and value in ("bf16", "f16x2"):
-            raise ValueError("training runs fp32 ('f32') or split-precision ('bf16x3') products")
+            raise ValueError("training runs fp32 ('f32') or split-precision ('bf16x3', 'bf16x3_r3') products")
         for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS[value]
         self._graphs.clear()
@@ -354,7 +357,7 @@ class D3DP(nn.Module):
         kernels, which DistributedDataParallel overlaps with the backward on its own stream, are not ours.  Until a
         multi-GPU soak shows bit-equal gradients, a process group of more than one rank trains on the fp32 matrix cores
         ('f32'; set allow_split_products_under_ddp to keep 'bf16x3' at your own risk)."""
-        if self.allow_split_products_under_ddp or self.precision != "bf16x3":
+        if self.allow_split_products_under_ddp or self.precision not in ("bf16x3", "bf16x3_r3"):
             return
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -105,9 +105,12 @@ class MixSTE2(nn.Module):
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
         self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA,
-        #                                2 split precision "bf16x3", 3 split precision "f16x2" (both fp32-equivalent; 3 is
-        #                                inference only), 1 opt-in bf16 operands
-        self.fold_layernorm = None     # split-precision inference: norm1 / norm2 applied inside the qkv / fc1 GEMMs
+        #                                4 split precision "bf16x3" on the image pipeline (inference; where its kernels do not
+        #                                exist - training, the single-model variant - effective_mode() runs mode 2: the same
+        #                                products on the round-3 kernels), 3 split precision "f16x2" (inference only), 1 opt-in
+        #                                bf16 operands
+        self.fold_layernorm = None     # split-precision inference: norm1 / norm2 applied inside the qkv / fc1 GEMMs (None: on in the
+        #                                image pipelines - modes 3 and 4 -, off in mode 2)
         #                                (pafuse_block_weights.qkv_ls ...: g-scaled weight images + two vectors per layer);
         #                                False = the whole-row kernels write the normalised rows (same function, one more
         #                                [M,C] store and normalise pass per whole-row launch).  None = on in 'f16x2', whose GEMMs
@@ -133,6 +136,16 @@ class MixSTE2(nn.Module):
         self._side_by_device = {}
 
     # ------------------------------------------------------------------------------------------- C structs
+    def effective_mode(self, training=False):
+        """The matrix-product mode the library is handed: the requested one, except that 'bf16x3' on the image pipeline (4)
+        falls back to the same products on the round-3 kernels (2) where the image pipeline has no kernels - training and
+        shapes outside its set (pafuse_mode_supported)."""
+        mode = int(self.operand_bf16)
+        if mode == 4 and (training or not _lib.load().pafuse_mode_supported(4, self.embed_dim, self.mlp_hidden, self.num_heads,
+                                                                           self.num_joints, self.num_frame)):
+            return 2
+        return mode
+
     def weights_struct(self, images=True):
         """pafuse_mixste2_weights pointing at the live parameter storage (cached until a pointer changes).
         images=False (training): no pre-split / folded images - the training entry points split the weight a GEMM is
@@ -142,7 +155,7 @@ class MixSTE2(nn.Module):
             if name.endswith("attn.qkv.bias") and not self.qkv_bias:
                 return self._zero_qkv_bias
             return attrgetter(name)(self)
-        mode = int(self.operand_bf16)
+        mode = self.effective_mode(training=not images)
         key = tuple(get(n).data_ptr() for n in self._param_names) + (self._freqs.data_ptr(), mode, bool(images),
                                                                      bool(self.keep_f32_residual), self.fuse_mlp)
         if not images:
@@ -156,11 +169,12 @@ class MixSTE2(nn.Module):
             w.qk_scale = 0.0 if self.qk_scale is None else self.qk_scale
             self._wcache_by_device[("train", self._freqs.device.index)] = (key, w)
             return w
-        split = mode in (2, 3)
-        fold = split and (mode == 3 if self.fold_layernorm is None else bool(self.fold_layernorm))
+        split = mode in (2, 3, 4)
+        fold = split and (mode in (3, 4) if self.fold_layernorm is None else bool(self.fold_layernorm))
         if split:           # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
-        fuse = split and (mode == 3 if self.fuse_qkv_attention is None else bool(self.fuse_qkv_attention))
+        # (mode 4 has no unfused attention: qkv + attention is one kernel in every block)
+        fuse = split and (mode == 4 or (mode == 3 if self.fuse_qkv_attention is None else bool(self.fuse_qkv_attention)))
         if fold or fuse:    # ... and so are the folded / head-major images and vectors: they also hold LayerNorm and bias values
             key += ("fold", fold, fuse) + tuple(get(n)._version for n in self._param_names if n.endswith(FOLD_SUFFIXES))
         dev = self._freqs.device
@@ -183,7 +197,7 @@ class MixSTE2(nn.Module):
             fuse_mlp = (mode == 3 and fold and not self.keep_f32_residual and self.mlp_hidden == 2 * self.embed_dim
                         and self.embed_dim in FUSED_MLP_WIDTHS
                         and (self.embed_dim in FUSED_MLP_DEFAULT_WIDTHS if self.fuse_mlp is None else bool(self.fuse_mlp)))
-            images = self._split_images(get, fold, fuse, f16=(mode == 3), fuse_mlp=fuse_mlp)
+            images = self._split_images(get, fold, fuse, f16=(mode == 3), fuse_mlp=fuse_mlp, x=(mode == 4))
             stream = torch.cuda.current_stream(dev)
             event = torch.cuda.Event()
             event.record(stream)
@@ -199,22 +213,24 @@ class MixSTE2(nn.Module):
             self._wcache_by_device[dev.index] = (key, w, images, event, stream)   # (images: keeps the storage the struct points into alive)
         return w
 
-    def _split_images(self, get, fold=False, fuse=False, f16=False, fuse_mlp=False):
-        """Pre-split images (bf16x3, or f16x2 with `f16`) of every linear weight, made on the device by pafuse_split_weights:
-        one uint8 tensor per weight, 6 bytes per element, kept until a weight changes (the cache key of weights_struct).
-        `fold`: qkv / fc1 get the image of W (.) g and the two vectors of the folded LayerNorm (norm1 / norm2 of their
-        block, include/pafuse_hip.h pafuse_block_weights.qkv_ls): ls = W g, lt = W beta + b, formed in fp64."""
+    def _split_images(self, get, fold=False, fuse=False, f16=False, fuse_mlp=False, x=False):
+        """Pre-split images (bf16x3; f16x2 with `f16`; X images - bf16x3 on the image pipeline - with `x`) of every linear weight,
+        made on the device by pafuse_split_weights: one uint8 tensor per weight, kept until a weight changes (the cache key of
+        weights_struct).  `fold`: qkv / fc1 get the image of W (.) g and the two vectors of the folded LayerNorm (norm1 / norm2
+        of their block, include/pafuse_hip.h pafuse_block_weights.qkv_ls): ls = W g, lt = W beta + b, formed in fp64."""
         images = {}
         for name in self._param_names:
             if not name.endswith(SPLIT_SUFFIXES):
                 continue
             stem = name[:-len("weight")]
+            # mode 4 multiplies the head-major qkv image only (qkv + attention fused in every block): no plain qkv image
+            plain = not (x and name.endswith("attn.qkv.weight"))
             if fold and name.endswith(tuple(FOLDED_LINEAR)):
-                images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name, f16)
-            else:
-                images[name] = split_image(get(name), image_layout(name), f16)
+                images[name], images[stem + "ls"], images[stem + "lt"] = folded_linear(get, name, f16, x, image=plain)
+            elif plain:
+                images[name] = split_image(get(name), image_layout(name), f16, x)
             if fuse and name.endswith("attn.qkv.weight"):
-                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = head_major_qkv(get, name, self.num_heads, fold, f16)
+                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = head_major_qkv(get, name, self.num_heads, fold, f16, x)
             if fuse_mlp and name.endswith("mlp.fc2.weight"):
                 images[stem + "hp"] = fused_mlp_fc2_image(get(name))
         return images
@@ -233,7 +249,7 @@ class MixSTE2(nn.Module):
                                           "mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
             if self.operand_bf16 in (1, 3):
                 raise NotImplementedError("rounded-bf16 and f16x2 products are inference options; training runs fp32 ('f32') "
-                                          "or split-precision ('bf16x3') products")
+                                          "or split-precision ('bf16x3': modes 4 / 2, the round-3 kernels) products")
             return self._forward_train(x_2d, x_3d, t)
         B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()
@@ -389,8 +405,9 @@ def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, i
         for i in range(depth):
             for field, key in BLOCK_PARAMS:
                 setattr(dst[i], field, _ptr(get(f"{prefix}.{i}.{key}"), f"{prefix}.{i}.{key}"))
-            for field, key in BLOCK_SPLIT:
-                setattr(dst[i], field, split[f"{prefix}.{i}.{key}"].data_ptr() if split is not None else None)
+            for field, key in BLOCK_SPLIT:       # (mode 4 has no plain qkv image: qkv_hs is what it multiplies)
+                img = split.get(f"{prefix}.{i}.{key}") if split is not None else None
+                setattr(dst[i], field, img.data_ptr() if img is not None else None)
             for field, key in BLOCK_FOLD:       # present only when the images were made with the LayerNorm folded in
                 vec = split.get(f"{prefix}.{i}.{key}") if split is not None else None
                 setattr(dst[i], field, vec.data_ptr() if vec is not None else None)
@@ -405,18 +422,20 @@ def image_layout(name):
 
 
 SPLIT_F16X2 = 4      # include/pafuse_hip.h PAFUSE_SPLIT_F16X2: added to the layout, the image is for the f16x2 scheme
+SPLIT_X = 8          # include/pafuse_hip.h PAFUSE_SPLIT_X: the X image of the bf16x3 image pipeline (mode 4)
 
 
-def split_image(weight, layout, f16=False):
+def split_image(weight, layout, f16=False, x=False):
     """The pre-split image of one linear weight [N,K] on its device (pafuse_split_weights): a uint8 tensor of 6 bytes per
-    element + a 256-byte tail; `layout`: 0 mlp.fc1 / the unit op, 1 the whole-row layers (attn.proj, mlp.fc2), 2 attn.qkv;
-    `f16`: the f16x2 scheme's image (three fp16 slices of the power-of-two-scaled weight) instead of bf16x3's."""
+    element; `layout`: 0 mlp.fc1 / the unit op, 1 the whole-row layers (attn.proj, mlp.fc2), 2 attn.qkv (mode 2's three
+    geometries; the image pipelines have one each); `f16`: the f16x2 scheme's H image (two fp16 slices of the power-of-two-scaled
+    weight, 4 bytes per element + a 256-byte tail); `x`: the X image of mode 4 (three bf16 slices, [N][K/32][3][32])."""
     lib = _lib.load()
     N, K = weight.shape
     img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, int(layout) | (SPLIT_F16X2 if f16 else 0),
-                                            img.data_ptr(),
+        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K,
+                                            int(layout) | (SPLIT_F16X2 if f16 else 0) | (SPLIT_X if x else 0), img.data_ptr(),
                                             torch.cuda.current_stream(weight.device).cuda_stream))
     return img
 
@@ -440,7 +459,7 @@ def fused_mlp_fc2_image(weight):
     return split_image(w[:, fused_mlp_column_order(w.shape[1], w.device)].contiguous(), LAYOUT_OF["mlp.fc2.weight"], True)
 
 
-def folded_linear(get, name, f16=False):
+def folded_linear(get, name, f16=False, x=False, image=True):
     """(image, ls, lt) of the linear layer `name` (a state-dict key ending in attn.qkv.weight / mlp.fc1.weight) with the
     LayerNorm in front of it folded in (include/pafuse_hip.h, pafuse_block_weights.qkv_ls): the split image of W (.) g
     (one fp32 rounding per element, then split exactly), ls = W g and lt = W beta + b formed in fp64, rounded once."""
@@ -451,10 +470,10 @@ def folded_linear(get, name, f16=False):
     w64 = weight.double()
     ls = (w64 @ g.double()).float().contiguous()
     lt = (w64 @ beta.double() + bias.double()).float().contiguous()
-    return split_image((weight * g[None, :]).contiguous(), image_layout(name), f16), ls, lt
+    return (split_image((weight * g[None, :]).contiguous(), image_layout(name), f16, x) if image else None), ls, lt
 
 
-def head_major_qkv(get, name, heads, fold, f16=False):
+def head_major_qkv(get, name, heads, fold, f16=False, x=False):
     """(image, hb, hl) for the fused qkv + attention kernel (include/pafuse_hip.h pafuse_block_weights.qkv_hs): the qkv weight
     [3C, C] re-ordered head by head - q_h, k_h, v_h, each zero-padded from d to DP rows (DP = 32 for d <= 32, else 48) - as
     a layout-2 image; hb = the bias in that order; with the LayerNorm folded the image is that of W (.) g, hb = W beta + b
@@ -479,7 +498,7 @@ def head_major_qkv(get, name, heads, fold, f16=False):
         out = t.new_zeros((heads, 3, dp) + tuple(t.shape[3:]))
         out[:, :, :d] = t.transpose(0, 1)
         return out.reshape(heads * 3 * dp, *t.shape[3:]).contiguous()
-    image = split_image(reorder(weight), 2, f16)
+    image = split_image(reorder(weight), 2, f16, x)
     return image, reorder(bias), (reorder(hl) if hl is not None else None)
 
 

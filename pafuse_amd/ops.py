@@ -64,12 +64,13 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
     return o
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3_r3": 2, "f16x2": 3, "bf16x3": 4}       # as pafuse_amd.D3DP.PRECISIONS
 
 
 def block_forward(block_params, x, heads=8, precision="f32"):
     """Block.forward (common/mixste.py:113-116) on [S,L,C]; ``block_params`` is a pafuse_amd.mixste2._BlockParams;
-    ``precision`` the matrix-product mode of its four linear layers ('bf16x3' makes the split images here)."""
+    ``precision`` the matrix-product mode of its four linear layers (the split modes make their weight images here;
+    'bf16x3' runs the image pipeline where it has kernels for the shape, else the round-3 kernels)."""
     lib = _lib.load()
     S, L, Cc = x.shape
     _need(block_params.norm1.weight.numel() == Cc and Cc % heads == 0, f"block: parameters are not for width {Cc}")
@@ -78,15 +79,26 @@ def block_forward(block_params, x, heads=8, precision="f32"):
     w = _lib.BlockWeights()
     fill_block_struct(w, block_params)
     images = []
-    if precision in ("bf16x3", "f16x2"):
+    mode = PRECISIONS[precision]
+    if mode == 4 and not lib.pafuse_mode_supported(4, Cc, 0, heads, L, L):
+        mode = 2
+    if mode >= 2:
         for field, lin, layout in (("qkv_ws", block_params.attn.qkv, 2), ("proj_ws", block_params.attn.proj, 1),
                                    ("fc1_ws", block_params.mlp.fc1, 0), ("fc2_ws", block_params.mlp.fc2, 1)):
-            images.append(split_image(lin.weight, layout, precision == "f16x2"))
+            if mode == 4 and field == "qkv_ws":
+                continue
+            images.append(split_image(lin.weight, layout, mode == 3, mode == 4))
             setattr(w, field, images[-1].data_ptr())
+    if mode == 4:       # qkv + attention is one kernel there: the head-major image (LayerNorm not folded: Block.forward normalises)
+        from .mixste2 import head_major_qkv
+        table = {"b.0.attn.qkv.weight": block_params.attn.qkv.weight, "b.0.attn.qkv.bias": block_params.attn.qkv.bias}
+        hs, hb, _ = head_major_qkv(table.__getitem__, "b.0.attn.qkv.weight", heads, False, False, True)
+        images += [hs, hb]
+        w.qkv_hs, w.qkv_hb = hs.data_ptr(), hb.data_ptr()
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.pafuse_block_forward(C.byref(w), y.data_ptr(), S, L, Cc, heads, PRECISIONS[precision], ws.data_ptr(),
+        _lib.check(lib.pafuse_block_forward(C.byref(w), y.data_ptr(), S, L, Cc, heads, mode, ws.data_ptr(),
                                             nbytes, _stream(x)))
     del images      # (stream-ordered: the caching allocator reuses the blocks only for later work on this stream)
     return y
@@ -194,6 +206,24 @@ def hsplit_rows(x):
     return out
 
 
+def xsplit_rows(x):
+    """The X image of a contiguous fp32 [R,K] tensor (pafuse_xsplit_rows): [R][K/32][3][32 x bf16], the three exact bf16 slices
+    of every element, 6 R K bytes."""
+    lib = _lib.load()
+    _need(x.dim() == 2 and x.shape[1] % 32 == 0, "xsplit_rows: x must be [R, K] with K % 32 == 0")
+    R, K = x.shape
+    out = torch.empty(R * K * 6, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_xsplit_rows(_ptr(x, "x"), R, K, out.data_ptr(), _stream(x)))
+    return out
+
+
+def xjoin_rows(image, R, K):
+    """fp32 [R,K] tensor an X image stands for: s0 + (s1 + s2), exact in fp32."""
+    v = image.view(torch.bfloat16).view(R, K // 32, 3, 32).float()
+    return (v[:, :, 0] + (v[:, :, 1] + v[:, :, 2])).reshape(R, K)
+
+
 def hjoin_rows(image, R, K):
     """fp32 [R,K] tensor an activation H image stands for: hi + 2^-11 lo (exact in fp32)."""
     v = image.view(torch.float16).view(R, K // 8, 2, 8).float()
@@ -223,28 +253,33 @@ def mlp_fused(xc, rstd, fc1_weight, fc1_bias, fc2_weight, fc2_bias, eps=1e-6, in
     return hjoin_rows(out, M, Cw), stats
 
 
+SCHEME_FLAG = {"bf16x3_r3": 0, "f16x2": 4, "bf16x3": 8}      # include/pafuse_hip.h: PAFUSE_SPLIT_F16X2, PAFUSE_SPLIT_X
+
+
 def split_weights(weight, layout=0, scheme="bf16x3"):
     """Pre-split image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights);
-    layout 0: the 32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers;
-    scheme 'bf16x3' (three bf16 slices) or 'f16x2' (the H image: two fp16 slices of the power-of-two-scaled weight, one
-    geometry for every layer)."""
+    scheme 'bf16x3' (the X image of the image pipeline: three bf16 slices, one geometry for every layer), 'f16x2' (the H image:
+    two fp16 slices of the power-of-two-scaled weight) or 'bf16x3_r3' (the round-3 kernels' images; layout 0: the
+    32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers)."""
     lib = _lib.load()
     _need(weight.dim() == 2 and weight.shape[1] % 32 == 0, "split_weights: weight must be [N, K] with K % 32 == 0")
     _need(layout in (0, 2), "split_weights: layout 0 (fc1 kernel) or 2 (qkv kernel)")
-    _need(scheme in ("bf16x3", "f16x2"), "split_weights: scheme 'bf16x3' or 'f16x2'")
+    _need(scheme in SCHEME_FLAG, f"split_weights: scheme must be one of {sorted(SCHEME_FLAG)}")
     N, K = weight.shape
     img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, layout | (4 if scheme == "f16x2" else 0), img.data_ptr(),
+        _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, layout | SCHEME_FLAG[scheme], img.data_ptr(),
                                             _stream(weight)))
     return img
 
 
-def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3"):
-    """nn.Linear (+ exact GELU) with split-precision products, fp32 accumulation: scheme 'bf16x3' - fp32 operands as three
-    bf16 slices each, six bf16 MFMA products per pair; 'f16x2' - two fp16 slices of the activation, three of the scaled
-    weight, three fp16 MFMA products.  ``image`` = split_weights(weight, layout, scheme) to reuse a cached image;
-    ``layout`` picks the kernel: 0 the 32x32x16-MFMA tiles (mlp.fc1), 2 the 16x16x32-MFMA tiles (attn.qkv)."""
+def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3", out_image=False):
+    """nn.Linear (+ exact GELU) with split-precision products, fp32 accumulation: scheme 'bf16x3' / 'bf16x3_r3' - fp32 operands
+    as three bf16 slices each, six bf16 MFMA products per pair (on the image pipeline: both operands as X images; on the
+    round-3 kernels: A split in registers); 'f16x2' - two fp16 slices of the activation, three of the scaled weight, three
+    fp16 MFMA products.  ``image`` = split_weights(weight, layout, scheme) to reuse a cached image; ``layout`` picks the
+    round-3 kernel: 0 the 32x32x16-MFMA tiles (mlp.fc1), 2 the 16x16x32-MFMA tiles (attn.qkv).  ``out_image`` (image schemes):
+    return the image of the output (what a producer hands its consumer) instead of fp32 rows."""
     lib = _lib.load()
     K = x.shape[-1]
     N = weight.shape[0]
@@ -256,10 +291,22 @@ def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3
     if scheme == "f16x2":      # both operands as H images (pafuse_linear_h)
         _need(N % 128 == 0 or N % 224 == 0, "linear_split: f16x2 serves N that is a multiple of 128 or 224")
         ah = hsplit_rows(x2)
+        oh = torch.empty(x2.shape[0] * N * 4, dtype=torch.uint8, device=x.device) if out_image else None
         with torch.cuda.device(x.device):
-            _lib.check(lib.pafuse_linear_h(ah.data_ptr(), img.data_ptr(), _ptr(bias, "bias"), out.data_ptr(), None, x2.shape[0], N, K,
+            _lib.check(lib.pafuse_linear_h(ah.data_ptr(), img.data_ptr(), _ptr(bias, "bias"), None if out_image else out.data_ptr(),
+                                           oh.data_ptr() if out_image else None, x2.shape[0], N, K,
                                            1 if act == "gelu" else 0, _stream(x)))
-        return out.view(*x.shape[:-1], N)
+        return oh if out_image else out.view(*x.shape[:-1], N)
+    if scheme == "bf16x3":     # both operands as X images (pafuse_linear_x)
+        _need(N % 128 == 0 or N % 224 == 0 or N % 96 == 0, "linear_split: the image pipeline serves N that is a multiple of 128, 224 or 96")
+        ax = xsplit_rows(x2)
+        ox = torch.empty(x2.shape[0] * N * 6, dtype=torch.uint8, device=x.device) if out_image else None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.pafuse_linear_x(ax.data_ptr(), img.data_ptr(), _ptr(bias, "bias"), None if out_image else out.data_ptr(),
+                                           ox.data_ptr() if out_image else None, x2.shape[0], N, K,
+                                           1 if act == "gelu" else 0, _stream(x)))
+        return ox if out_image else out.view(*x.shape[:-1], N)
+    _need(not out_image, "linear_split: the round-3 kernels write fp32 rows")
     with torch.cuda.device(x.device):
         _lib.check(lib.pafuse_linear_split(_ptr(x2, "x"), img.data_ptr(), _ptr(bias, "bias"), out.data_ptr(),
                                            x2.shape[0], N, K,

@@ -10,9 +10,8 @@ there is no fallback), with fake-tensor shape functions so the ops trace under `
   pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads, precision)  MixSTE2.forward, eval  common/mixste.py:278-298
   pafuse::ddim_loop(..., precision)                        D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
 
-``precision`` ('f16x2' = the part-based modules' inference default for the model-level ops, 'bf16x3' for pafuse::block, which
-serves every width; 'f32', 'bf16') is the matrix-product mode of the linear
-layers; in the split modes the ops build and cache the pre-split weight images themselves (cached_split_image).
+``precision`` ('bf16x3' = the modules' default; 'bf16x3_r3', 'f16x2', 'f32', 'bf16': pafuse_amd.D3DP.precision) is the
+matrix-product mode of the linear layers; in the split modes the ops build and cache the pre-split weight images themselves (cached_split_image).
 
 ``weights`` lists are in ``named_parameters()`` order of the corresponding module (= the reference's state-dict
 order), so ``list(model.parameters())`` is the argument.  The modules in pafuse_amd call the C ABI directly; these ops
@@ -69,53 +68,53 @@ def _freqs(channels, device):
     return _freq_cache[key]
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3_r3": 2, "f16x2": 3, "bf16x3": 4}     # as pafuse_amd.D3DP.PRECISIONS
 _image_cache = {}        # (data_ptr, _version, device, layout, shape, scheme) of a linear weight -> (its split image, the weight)
 _IMAGE_CACHE_MAX = 2048  # ~ three models' worth of linear weights; the oldest entries go first
 
 
-def cached_split_image(weight, layout, f16=False):
+def cached_split_image(weight, layout, f16=False, x=False):
     """The pre-split image of a linear weight, made once per (storage, version, layout, scheme): the schema'd ops take plain
     parameter tensors, so they build and cache the images the split-precision kernels read (the modules keep theirs per
     module).  layout: pafuse_split_weights' (0 fc1, 1 proj / fc2, 2 qkv).
     An entry keeps a reference to the tensor it was made from: while the entry lives that storage cannot be freed, so no
     other tensor can come to sit at its address with a matching version and shape and hit a stale image (a freed temporary
     such as `w.float()` or `w.detach().clone()` made per call would otherwise do exactly that)."""
-    key = (weight.data_ptr(), weight._version, weight.device, int(layout), tuple(weight.shape), bool(f16))
+    key = (weight.data_ptr(), weight._version, weight.device, int(layout), tuple(weight.shape), bool(f16), bool(x))
     hit = _image_cache.get(key)
     if hit is None:
         while len(_image_cache) >= _IMAGE_CACHE_MAX:
             _image_cache.pop(next(iter(_image_cache)))
-        hit = _image_cache[key] = (split_image(weight, layout, f16), weight)
+        hit = _image_cache[key] = (split_image(weight, layout, f16, x), weight)
     return hit[0]
 
 
-def cached_folded_linear(table, name, f16=False):
+def cached_folded_linear(table, name, f16=False, x=False, image=True):
     """(image, ls, lt) of a qkv / fc1 layer with its LayerNorm folded in (mixste2.folded_linear), made once per version of
     the four tensors it is built from - the modules' own default in the split modes, so the ops return the modules' bits.
     The entry pins its four source tensors (see cached_split_image)."""
     block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
     parts = (table[name], table[f"{block}.{norm}.weight"], table[f"{block}.{norm}.bias"], table[name[:-len("weight")] + "bias"])
-    key = ("fold", bool(f16)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
+    key = ("fold", bool(f16), bool(x), bool(image)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
     hit = _image_cache.get(key)
     if hit is None:
         while len(_image_cache) >= _IMAGE_CACHE_MAX:
             _image_cache.pop(next(iter(_image_cache)))
-        hit = _image_cache[key] = (folded_linear(table.__getitem__, name, f16), parts)
+        hit = _image_cache[key] = (folded_linear(table.__getitem__, name, f16, x, image), parts)
     return hit[0]
 
 
-def cached_head_major_qkv(table, name, heads, f16=False):
+def cached_head_major_qkv(table, name, heads, f16=False, x=False):
     """(image, hb, hl) of a qkv layer for the fused qkv + attention kernel (mixste2.head_major_qkv, LayerNorm folded), made once
     per version of the four tensors it is built from; the entry pins them (see cached_split_image)."""
     block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
     parts = (table[name], table[f"{block}.{norm}.weight"], table[f"{block}.{norm}.bias"], table[name[:-len("weight")] + "bias"])
-    key = ("head-major", bool(f16), int(heads)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
+    key = ("head-major", bool(f16), bool(x), int(heads)) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in parts) + (parts[0].device,)
     hit = _image_cache.get(key)
     if hit is None:
         while len(_image_cache) >= _IMAGE_CACHE_MAX:
             _image_cache.pop(next(iter(_image_cache)))
-        hit = _image_cache[key] = (head_major_qkv(table.__getitem__, name, heads, True, f16), parts)
+        hit = _image_cache[key] = (head_major_qkv(table.__getitem__, name, heads, True, f16, x), parts)
     return hit[0]
 
 
@@ -141,6 +140,8 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
     """pafuse_mixste2_weights from a flat parameter list; returns (struct, keep-alive)."""
     mode = _mode(precision)
     channels = weights[0].shape[-1]                           # Spatial_pos_embed [1,J,C] comes first
+    if mode == 4 and not _lib.load().pafuse_mode_supported(4, channels, 0, heads, joints, frames):
+        mode = 2                                              # as MixSTE2.effective_mode: the same products on the round-3 kernels
     names = mixste_param_names(frames, joints, channels, depth, heads)
     if len(weights) != len(names):
         raise _lib.PafuseError(f"expected {len(names)} weight tensors (named_parameters() order), got {len(weights)}")
@@ -151,16 +152,20 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
     fr = _freqs(channels, weights[0].device)
     w = _lib.MixSTE2Weights()
     images = None
-    if mode in (2, 3):
+    if mode in (2, 3, 4):
         images = {}
+        f16, x = mode == 3, mode == 4
         for n, t in table.items():
-            if mode == 3 and n.endswith(tuple(FOLDED_LINEAR)):    # the modules' defaults: LayerNorm folded in 'f16x2' only
-                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, True)
+            plain = not (x and n.endswith("attn.qkv.weight"))      # mode 4 multiplies the head-major qkv image only
+            if mode >= 3 and n.endswith(tuple(FOLDED_LINEAR)):    # the modules' defaults: LayerNorm folded in the image pipelines only
+                images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, f16, x, plain)
+                if not plain:
+                    del images[n]
             elif n.endswith(SPLIT_SUFFIXES):
-                images[n] = cached_split_image(t, image_layout(n), mode == 3)
-            if mode == 3 and n.endswith("attn.qkv.weight"):     # the modules' default in 'f16x2': qkv + attention in one kernel
+                images[n] = cached_split_image(t, image_layout(n), f16, x)
+            if mode >= 3 and n.endswith("attn.qkv.weight"):     # the modules' default there: qkv + attention in one kernel
                 stem = n[:-len("weight")]
-                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = cached_head_major_qkv(table, n, heads, True)
+                images[stem + "hs"], images[stem + "hb"], images[stem + "hl"] = cached_head_major_qkv(table, n, heads, f16, x)
             if mode == 3 and n.endswith("mlp.fc2.weight") and channels in FUSED_MLP_DEFAULT_WIDTHS and t.shape[1] == 2 * channels:
                 images[n[:-len("weight")] + "hp"] = cached_fused_mlp_fc2(t)    # ... and the MLP in one kernel where the modules do
     fill_weights_struct(w, table.__getitem__, fr, frames, joints, channels, depth, heads, 5, mode, images)
@@ -245,10 +250,19 @@ def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int, precision: s
     for field, t, name in zip(_lib.BLOCK_FIELDS, weights, BLOCK_KEYS):
         setattr(w, field, _ptr(t, name))
     images = []
-    if mode in (2, 3):
+    if mode == 4 and not lib.pafuse_mode_supported(4, Cc, 0, heads, L, L):
+        mode = 2
+    if mode in (2, 3, 4):
         for field, idx, layout in (("qkv_ws", 2, 2), ("proj_ws", 4, 1), ("fc1_ws", 8, 0), ("fc2_ws", 10, 1)):
-            images.append(cached_split_image(weights[idx], layout, mode == 3))
+            if mode == 4 and field == "qkv_ws":
+                continue
+            images.append(cached_split_image(weights[idx], layout, mode == 3, mode == 4))
             setattr(w, field, images[-1].data_ptr())
+    if mode == 4:       # qkv + attention is one kernel there: the head-major image (LayerNorm not folded: Block.forward normalises)
+        table = {"b.0.attn.qkv.weight": weights[2], "b.0.attn.qkv.bias": weights[3]}
+        hs, hb, _ = head_major_qkv(table.__getitem__, "b.0.attn.qkv.weight", heads, False, False, True)
+        images += [hs, hb]
+        w.qkv_hs, w.qkv_hb = hs.data_ptr(), hb.data_ptr()
     nbytes = lib.pafuse_block_workspace_bytes(S * L, Cc)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     _lib.check(lib.pafuse_block_forward(C.byref(w), _ptr(y, "x"), S, L, Cc, heads, mode, ws.data_ptr(), nbytes, _stream(x)))
@@ -263,7 +277,7 @@ def _(x, weights, heads, precision="bf16x3"):
 # ------------------------------------------------------------------------------------------- model-level ops
 @torch.library.custom_op("pafuse::mixste_eval", mutates_args=(), device_types="cuda")
 def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: List[torch.Tensor], depth: int,
-                heads: int, precision: str = "f16x2") -> torch.Tensor:
+                heads: int, precision: str = "bf16x3") -> torch.Tensor:
     lib = _lib.load()
     _need(x3d.dim() == 5 and x3d.shape[-1] == 3, "mixste_eval: x3d must be [B,P,F,J,3]")
     B, P, F, J, _ = x3d.shape
@@ -279,14 +293,14 @@ def mixste_eval(x2d: torch.Tensor, x3d: torch.Tensor, t: torch.Tensor, weights: 
 
 
 @mixste_eval.register_fake
-def _(x2d, x3d, t, weights, depth, heads, precision="f16x2"):
+def _(x2d, x3d, t, weights, depth, heads, precision="bf16x3"):
     return torch.empty_like(x3d)
 
 
 @torch.library.custom_op("pafuse::ddim_loop", mutates_args=(), device_types="cuda")
 def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, weights: List[torch.Tensor],
               part_joints: List[torch.Tensor], flip_perm: torch.Tensor, depth: int, heads: int, times: List[int],
-              sched: List[float], flip: bool, scale: float, precision: str = "f16x2") -> torch.Tensor:
+              sched: List[float], flip: bool, scale: float, precision: str = "bf16x3") -> torch.Tensor:
     """The whole sampler.  noise [n_draws,B,P,F,J,3] in the reference's draw order; weights = the per-part
     parameter lists concatenated in part order; part_joints[i] int32 joint indices of part i; flip_perm int32 [J];
     times[k] the k-th timestep (the last one is the step whose time_next < 0); sched 5 doubles per step:
@@ -345,7 +359,7 @@ def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, we
 
 
 @ddim_loop.register_fake
-def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale, precision="f16x2"):
+def _(x2d, x2d_flip, noise, weights, part_joints, flip_perm, depth, heads, times, sched, flip, scale, precision="bf16x3"):
     n_draws, B, P, F, J, _ = noise.shape
     return noise.new_empty(B, len(times), P, F, J, 3)
 

@@ -391,7 +391,7 @@ def test_grouped_launches_equal_part_by_part_launches():
     schedule state) gives the same bits."""
     from __graft_entry__ import make_model
     model, _ = make_model(20, 2, seed=52)
-    model.precision = "bf16x3"          # (the shared grids are this scheme's single-stream schedule)
+    model.precision = "bf16x3_r3"       # (the shared grids are the single-stream schedule of the round-3 kernels)
     model.n_aux_streams = 0
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=20, n=2, seed=7)
@@ -402,7 +402,7 @@ def test_grouped_launches_equal_part_by_part_launches():
     assert torch.equal(grouped, part_by_part)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_r3", "f32", "f16x2"])
 def test_side_streams_return_the_single_stream_bits(precision):
     """The default schedule runs the three parts on three HIP streams (queues).  In round 2 that was wrong now and then
     in the bf16-MFMA modes; the cause - packed-fp32 VALU instructions beside v_mfma_f32_32x32x16_bf16 waves of another
