@@ -11,22 +11,30 @@ Inputs, weights and noise are resident in HBM before the timed region.  With N >
 sharded (weak scaling: P = 20*N, 20 per rank) and every step ends with the single RCCL all-gather of the
 per-rank predictions.  Rank 0 prints ONE JSON line.
 
+`value` is the default product mode, 'bf16x3': every GEMM operand carries all 24 bits of the fp32 number it stands for (three
+bf16 slices, six bf16 MFMA products, fp32 accumulation).  The same run (N = 1) also times the two opt-in modes and reports them
+as named secondary objects, never as `value`: `value_f16x2` (three fp16 MFMA products on 22 - 23-bit operands: faster, narrower
+than the reference's arithmetic) and `value_bf16x3_images` (the exact products on round 5's image pipeline).
+
 Extra objects in the line:
-  roofline      the dominant kernel family, the linear-layer launches - default (f16x2): `hfqa_kernel` (qkv + attention),
-                `hgemm_kernel` (proj; the body's fc1 and fc2), `hmlp_kernel` (fc1 + fc2 of the face and the hands in one kernel):
-                160 launches per flip-TTA denoiser pass; bf16x3: `gemm16_kernel` / `gemm_kernel` / `gemm_dma_kernel` (192, or the
-                single-stream schedule's shared grids with --streams 0); f32: `gemm_kernel`.  Algorithmic FLOPs (2 M N K per
-                linear layer) of those launches divided by their HIP-event time, launched back to back on the stream torch
-                uses, against 833.3 TFLOP/s (fp16 matrix peak / 3 products), 416.7 (bf16 / 6) or the 157.3 TFLOP/s f32 matrix
-                peak.  The timed loop runs
-                the three parts on three streams (queues), where a kernel's own duration is not observable (kernels
-                of different queues share the CUs); the replay runs the SAME kernels of the SAME launches one after
-                the other, which is the kernel-quality number, and `roofline_loop` is what the overlap makes of it.
+  roofline      the dominant kernel family, the linear-layer launches of one flip-TTA denoiser pass - bf16x3: `gemm16_kernel`
+                (qkv), `gemm_kernel` (fc1), `gemm_dma_kernel` (proj, fc2), or the shared grids of the single-stream schedule
+                with --streams 0; bf16x3_images: `xfqa_kernel` (qkv + attention), `xgemm_kernel`; f16x2: `hfqa_kernel`,
+                `hgemm_kernel`, `hmlp_kernel`; f32: `gemm_kernel`.  Algorithmic FLOPs (2 M N K per linear layer) of those
+                launches divided by their HIP-event time, launched back to back on the stream torch uses, against 416.7
+                TFLOP/s (bf16 matrix peak / 6 products), 833.3 (fp16 / 3) or the 157.3 TFLOP/s f32 matrix peak.  The timed
+                loop runs the three parts on three streams (queues), where a kernel's own duration is not observable (kernels
+                of different queues share the CUs); the replay runs the SAME kernels of the SAME launches one after the
+                other, which is the kernel-quality number, and `roofline_loop` is what the overlap makes of it.
                 `by_layer`: each of the four layer kinds replayed alone (pafuse_d3dp_replay_layers), so the line shows
                 which kernel of the family sits where (qkv / proj+LN / fc1+GELU / fc2+LN).
   roofline_loop the same fraction for the whole timed loop (2*T*69.38 GFLOP per hypothesis, everything included).
   cpu_baseline  the CPU oracle (a port of the reference's ATen path, oracle/) timed on the host cores of this box
                 on a bounded sample of the same workload.
+
+N > 1: `python bench.py --gpus N` started WITHOUT torch.distributed's environment starts the N ranks itself - a child
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, before this process touches the GPU - relays
+rank 0's line and exits with the children's status; started under torch.distributed.run it is one of the ranks.
 """
 import argparse
 import json
@@ -37,14 +45,56 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DEFAULT_DTYPE = "bf16x3"   # split-precision products on operands that carry all 24 bits of the fp32 numbers (three bf16 slices each),
-#                            on the image pipeline of round 5 (pafuse_amd.D3DP's default)
+DEFAULT_DTYPE = "bf16x3"   # split-precision products on operands that carry all 24 bits of the fp32 numbers (three bf16 slices each):
+#                            pafuse_amd.D3DP's default
 GFLOP_PER_HYP_PASS = 69.384706048          # SURVEY.md section 2b / BASELINE.md section 3 (one denoiser pass)
 PEAK_F32_MFMA_TFLOPS = 157.3               # MI355X_MICROARCH.md: dense f32-input matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # dense bf16 matrix peak (opt-in --dtype bf16 runs are priced against this)
 PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6   # bf16x3: six bf16 MFMA products per fp32-equivalent product = 416.7
 PEAK_F16X2_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3   # f16x2: three fp16 MFMA products per fp32-equivalent product = 833.3
-SPLIT_DTYPES = ("bf16x3", "bf16x3_r3", "f16x2")   # the split-precision modes
+SPLIT_DTYPES = ("bf16x3", "bf16x3_images", "f16x2")   # the split-precision modes
+SECONDARY_DTYPES = ("f16x2", "bf16x3_images")          # timed in the same run as the default: value_<mode> objects, never `value`
+_F32_NOTE = f"; the same FLOPs against the f32-input matrix peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak"
+MODES = {   # ceiling of the arithmetic scheme (TFLOP/s of fp32-equivalent work), matrix instructions per useful product, texts
+    "f32": {"peak": PEAK_F32_MFMA_TFLOPS, "products": 1, "mfma": "v_mfma_f32_32x32x2_f32", "family": "gemm_kernel",
+            "label": "f32 (fp32-input matrix cores: a k-ordered fp32 FMA chain per output)", "peak_note": "dense f32-input matrix peak"},
+    "bf16x3": {"peak": PEAK_SPLIT_TFLOPS, "products": 6, "mfma": "v_mfma_f32_32x32x16_bf16; the qkv layers v_mfma_f32_16x16x32_bf16",
+               "family": "gemm16_kernel, gemm_kernel, gemm_dma_kernel",
+               "label": "bf16x3 (every fp32 GEMM operand as the exact sum of three bf16 slices, six bf16 MFMA products per fp32-equivalent "
+                        "product, fp32 accumulate; activations, LayerNorm, softmax, attention and everything in memory fp32; the residual "
+                        "stream stored centred on its row means)",
+               "peak_note": "dense bf16 matrix peak 2500 / 6 products" + _F32_NOTE},
+    "bf16x3_images": {"peak": PEAK_SPLIT_TFLOPS, "products": 6, "mfma": "v_mfma_f32_32x32x16_bf16",
+                      "family": "xfqa_kernel (whose attention phase is inside the timed launches), xgemm_kernel",
+                      "label": "bf16x3 on the image pipeline (the six-product scheme with both GEMM operands pre-split by their producers: "
+                               "activations between kernels live as three-bf16-slice images, 6 bytes per element, exact; qkv + attention "
+                               "fused; LayerNorm, softmax and attention arithmetic fp32)",
+                      "peak_note": "dense bf16 matrix peak 2500 / 6 products" + _F32_NOTE},
+    "f16x2": {"peak": PEAK_F16X2_TFLOPS, "products": 3, "mfma": "v_mfma_f32_32x32x16_f16; the fused qkv projection v_mfma_f32_16x16x32_f16",
+              "family": "hgemm_kernel, hfqa_kernel (whose attention phase is inside the timed launches), hmlp_kernel",
+              "label": "f16x2 (OPT-IN, narrower than the reference's fp32 operands: activations as two fp16 slices = 22 - 23 significant "
+                       "bits, weights as two stored fp16 slices of the power-of-two-scaled tensor + one derived, three fp16 MFMA products "
+                       "per product, fp32 accumulate; the residual stream, the attention output and the MLP hidden live in memory only "
+                       "as two-slice images; LayerNorm, softmax and attention arithmetic fp32)",
+              "peak_note": "dense fp16 matrix peak 2500 / 3 products" + _F32_NOTE},
+    "bf16": {"peak": PEAK_BF16_MFMA_TFLOPS, "products": 1, "mfma": "v_mfma_f32_32x32x16_bf16", "family": "gemm_kernel",
+             "label": "bf16 operands, f32 accumulate (opt-in, not the parity path)", "peak_note": "dense bf16 matrix peak"},
+}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torch.distributed's environment: start the N ranks as a child torch.distributed.run (a
+    fresh process tree - this process has not touched the GPU and never will), relay its output, exit with its status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting", n, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -57,28 +107,28 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="clips per forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the value_f16x2 / value_bf16x3_images legs of the default line")
     ap.add_argument("--streams", type=int, default=2, help="aux HIP streams the three parts are spread over")
     ap.add_argument("--graph", action="store_true", help="replay the loop as one captured hipGraph")
     ap.add_argument("--fuse-qkv-attention", choices=("auto", "on", "off"), default="auto",
                     help="A/B: the fused qkv + attention kernel (pafuse_amd.MixSTE2.fuse_qkv_attention) where it exists; auto = "
-                         "the modules' default: on in f16x2, off in bf16x3")
+                         "the modules' default: on in f16x2, always on in bf16x3_images, off in bf16x3")
     ap.add_argument("--fuse-mlp", choices=("auto", "on", "off"), default="auto",
                     help="A/B (f16x2): fc1 -> GELU -> fc2 of a block in one kernel (pafuse_amd.MixSTE2.fuse_mlp); auto = on where it exists")
     ap.add_argument("--fuse-mlp-parts", default="body,face,hands", help="A/B: the parts --fuse-mlp on applies to")
     ap.add_argument("--f32-residual", action="store_true",
-                    help="A/B (f16x2): keep the residual stream between the blocks as fp32 rows beside its H image "
+                    help="A/B (image pipelines): keep the residual stream between the blocks as fp32 rows beside its image "
                          "(pafuse_amd.MixSTE2.keep_f32_residual)")
-    ap.add_argument("--ln-fold", action="store_true", help="A/B (bf16x3): fold norm1 / norm2 into the qkv / fc1 GEMMs (the default only in f16x2)")
     ap.add_argument("--no-ln-fold", action="store_true",
                     help="A/B: the whole-row kernels write the normalised rows instead of folding norm1 / norm2 into the "
                          "qkv / fc1 GEMMs (pafuse_amd.MixSTE2.fold_layernorm)")
-    ap.add_argument("--dtype", choices=("f32", "bf16x3", "bf16x3_r3", "f16x2", "bf16"), default=DEFAULT_DTYPE,
-                    help="matrix-product mode of the linear layers: f32 = fp32-input matrix cores; bf16x3 = split "
-                         "precision (fp32 operands as three bf16 slices, six bf16 MFMA products, fp32 accumulate: "
-                         "fp32-equivalent results, same parity bounds); f16x2 = split precision on the fp16 matrix cores "
-                         "(activations as two fp16 slices, scaled weights as three, three MFMA products: fp32-equivalent, "
-                         "same parity bounds); bf16 = opt-in reduced precision (operands "
-                         "rounded to one bf16) - never the contract's line")
+    ap.add_argument("--dtype", choices=("f32", "bf16x3", "bf16x3_images", "f16x2", "bf16"), default=DEFAULT_DTYPE,
+                    help="matrix-product mode of the linear layers.  bf16x3 (default) = split precision at the reference's operand "
+                         "width: fp32 operands as three bf16 slices (exact), six bf16 MFMA products, fp32 accumulate; bf16x3_images = "
+                         "the same products on round 5's image pipeline (operands pre-split by their producers, qkv + attention fused); "
+                         "f32 = fp32-input matrix cores; f16x2 = OPT-IN split precision on the fp16 matrix cores (activations as two "
+                         "fp16 slices = 22 - 23 bits, three MFMA products): faster, NOT the reference's operand width, its own parity "
+                         "bounds; bf16 = opt-in reduced precision (operands rounded to one bf16) - never the contract's line")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the contract's line); gloo only for "
                          "rehearsing the N > 1 code path on a box with fewer GPUs than ranks (with --single-device)")
@@ -95,6 +145,8 @@ def main():
                     help="time training steps instead (SURVEY 8f n2: fwd + bwd + AdamW, DDP over RCCL for N > 1); "
                          "--batch is then clips per GPU (default 37 = 1024 // 27, main_h3wb.py:781)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)            # (does not return; nothing above has initialised the GPU)
 
     import torch
     import torch.distributed as dist
@@ -104,8 +156,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but torch.distributed's environment says WORLD_SIZE={world}")
     if args.single_device:
         if args.backend != "gloo":
             raise SystemExit("--single-device shares one GPU between the ranks: RCCL cannot, use --backend gloo")
@@ -129,23 +181,8 @@ def main():
 
     B, T, P_local = args.batch, args.timesteps, args.proposals
     P_total = P_local * world
-    model, sd = ge.make_model(P_total, T, seed=51, device=dev)
-    model.n_aux_streams = args.streams
-    model.use_graph = args.graph
-    model.precision = args.dtype
-    for part_name, m in model.denoisers().items():
-        if args.no_ln_fold or args.ln_fold:
-            m.fold_layernorm = not args.no_ln_fold
-        m.fuse_qkv_attention = {"auto": None, "on": True, "off": False}[args.fuse_qkv_attention]
-        m.keep_f32_residual = bool(args.f32_residual)
-        m.fuse_mlp = {"auto": None, "on": part_name in args.fuse_mlp_parts.split(","), "off": False}[args.fuse_mlp]
-    sampler = ShardedSampler(model)
     x2d, x2f = gu.synthetic_inputs_2d(B=B)
     x2d, x2f = x2d.to(dev), x2f.to(dev)
-    torch.manual_seed(1234)                  # identical on every rank: each draws the full-P noise, keeps its slice
-
-    def step():
-        return sampler(x2d, None, input_2d_flip=x2f)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -153,20 +190,104 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert out.shape == (B, T, P_total, 27, 134, 3) and bool(torch.isfinite(out).all())
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    sec_per_step = elapsed / args.steps
+    def make(dtype):
+        model, sd = ge.make_model(P_total, T, seed=51, device=dev)
+        model.n_aux_streams = args.streams
+        model.use_graph = args.graph
+        model.precision = dtype
+        for part_name, m in model.denoisers().items():
+            if args.no_ln_fold:
+                m.fold_layernorm = False
+            m.fuse_qkv_attention = {"auto": None, "on": True, "off": False}[args.fuse_qkv_attention]
+            m.keep_f32_residual = bool(args.f32_residual)
+            m.fuse_mlp = {"auto": None, "on": part_name in args.fuse_mlp_parts.split(","), "off": False}[args.fuse_mlp]
+        return model, sd
+
+    def timed(model, steps, warmup):
+        """W untimed + exactly K timed forward calls between fences -> (seconds per step, last output)"""
+        sampler = ShardedSampler(model)
+        torch.manual_seed(1234)              # identical on every rank: each draws the full-P noise, keeps its slice
+        for _ in range(warmup):
+            out = sampler(x2d, None, input_2d_flip=x2f)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = sampler(x2d, None, input_2d_flip=x2f)
+        fence()
+        elapsed = time.perf_counter() - t0
+        assert out.shape == (B, T, P_total, 27, 134, 3) and bool(torch.isfinite(out).all())
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed / steps, out
+
+    def family_replay(model, dtype, lanes, by_layer=True):
+        """the linear-layer launches of one flip-TTA denoiser pass replayed back to back on torch's stream, HIP-event timed"""
+        lib = _lib.load()
+        mode = MODES[dtype]
+        cfg = model.config_struct(True)
+        nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P_local)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        reps = 3
+        # the replay launches what the timed loop launched: part by part when the loop ran on side streams, the shared
+        # grids of the single-stream bf16x3 schedule otherwise (pafuse_d3dp_config.part_by_part_launches, per call)
+        per_part = lanes > 1 or dtype != "bf16x3"
+        cfg.part_by_part_launches = int(per_part)
+
+        def replay(mask):
+            fl = C.c_double(0.0)
+            nl = _lib.check(lib.pafuse_d3dp_replay_layers(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes, stream.cuda_stream, mask, C.byref(fl)))  # warm-up
+            fl = C.c_double(0.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                _lib.check(lib.pafuse_d3dp_replay_layers(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes, stream.cuda_stream, mask, C.byref(fl)))
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            return nl, fl.value, e0.elapsed_time(e1)
+
+        launches, flops, ms = replay(15)
+        n = launches * reps
+        achieved = flops / (ms * 1e-3) / 1e12
+        obj = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {mode['family'] if per_part or dtype != 'bf16x3' else 'gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel'} ({mode['mfma']})",
+               "schedule": (f"timed loop: {lanes} streams, one body-part denoiser per stream; this object: the same launches replayed one "
+                            "after the other on one stream" if lanes > 1 else "timed loop and this replay: one stream"),
+               "achieved": round(achieved, 2), "peak": mode["peak"], "unit": "TFLOP/s", "frac": round(achieved / mode["peak"], 4),
+               "peak_note": mode["peak_note"], "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+               # the same launches seen two more ways: the useful FLOPs / the executed matrix work against the dense peak of the
+               # instruction that runs
+               "frac_of_bf16_dense_peak": None if dtype == "f32" else round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
+               "mfma_pipe_frac": round(achieved * mode["products"] / (PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
+               "mfma_pipe_note": "executed matrix FLOPs (useful x 6 products in bf16x3, x 3 in f16x2) / dense peak of the instruction",
+               "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "flops_per_launch": round(flops / n / 1e9, 3),
+               "flops_unit": "GFLOP (algorithmic 2*M*N*K)"}
+        if by_layer:
+            layer_kernel = {"f16x2": {1: "hfqa_kernel: qkv projection + attention in one kernel (every block of every part)",
+                                      2: "hgemm_kernel<..EPI_ROWLN> (one launch per part)",
+                                      4: "hmlp_kernel: fc1 + GELU + fc2 + residual + LayerNorms in one kernel (face, hands; its FLOPs are both "
+                                         "layers'); hgemm_kernel<..EPI_BIAS> (body)",
+                                      8: "hgemm_kernel<..EPI_ROWLN> (the body only: fc2 of the face and the hands is inside the fused MLP launch)"},
+                            "bf16x3_images": {1: "xfqa_kernel: qkv projection + attention in one kernel (every block of every part)",
+                                              2: "xgemm_kernel<..EPI_ROWLN>", 4: "xgemm_kernel<..EPI_BIAS> (+ GELU, image out)", 8: "xgemm_kernel<..EPI_ROWLN>"},
+                            "bf16x3": ({1: "gemm16_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
+                                        4: "gemm_kernel (one launch per part)", 8: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)"} if per_part else
+                                       {1: "gemm16_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel", 8: "grouped_rowln_kernel"}),
+                            }.get(dtype, {1: "gemm_kernel", 2: "gemm_kernel<..EPI_ROWLN>", 4: "gemm_kernel", 8: "gemm_kernel<..EPI_ROWLN>"})
+            obj["by_layer"] = {}
+            for bit, name in ((1, "qkv"), (2, "proj+LN"), (4, "fc1+GELU"), (8, "fc2+LN")):
+                nl, fl, t = replay(bit)
+                if nl == 0:     # fc2 lives inside the fused MLP kernel, which the fc1 replay runs
+                    obj["by_layer"][name] = {"kernel": "(inside the fused MLP kernel: see fc1+GELU)", "launches": 0}
+                    continue
+                obj["by_layer"][name] = {"kernel": layer_kernel[bit], "launches": nl * reps, "avg_launch_us": round(t * 1e3 / (nl * reps), 2),
+                                         "achieved": round(fl / (t * 1e-3) / 1e12, 2), "frac": round(fl / (t * 1e-3) / 1e12 / mode["peak"], 4)}
+            obj["by_layer_note"] = "each layer kind of the pass replayed alone (same tiles, HIP events); achieved in TFLOP/s, frac against `peak`"
+        return obj, launches, ms / reps
+
+    model, sd = make(args.dtype)
+    sec_per_step, out = timed(model, args.steps, args.warmup)
     # what the collective layer saw (one all-gather of (rank, local hypothesis count)) and the all-gather's own cost
     lo, hi = shard_range(P_total, rank, world)
     census = rank_census(hi - lo)
@@ -197,185 +318,97 @@ def main():
     value = B * P_total / sec_per_step
     # HIP streams (hardware queues) the library spread one rank's loop over
     lanes = _lib.check(_lib.load().pafuse_d3dp_lanes(C.byref(model.config_struct(True)), B, P_local, args.streams))
-    loop_tflops = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / sec_per_step / world      # per GPU
-    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16x3": PEAK_SPLIT_TFLOPS, "bf16x3_r3": PEAK_SPLIT_TFLOPS, "f16x2": PEAK_F16X2_TFLOPS,
-            "bf16": PEAK_BF16_MFMA_TFLOPS}[args.dtype]
-    dtype_label = {"f32": "f32", "bf16x3_r3": "bf16x3 on the round-3 kernels",
-                   "bf16x3": "bf16x3 (fp32 operands split into three bf16 slices, six bf16 MFMA products per fp32-"
-                             "equivalent product, fp32 accumulate; activations and everything in memory fp32)",
-                   "f16x2": "f16x2 (fp32 activations split into two fp16 slices, power-of-two-scaled fp32 weights into three, "
-                            "three fp16 MFMA products per fp32-equivalent product, fp32 accumulate; activations and everything "
-                            "in memory fp32)",
-                   "bf16": "bf16 operands, f32 accumulate (opt-in, not the parity path)"}[args.dtype]
+    flop_per_step = B * P_total * 2 * T * GFLOP_PER_HYP_PASS / 1e3 / world      # TFLOP per GPU and step
 
+    def loop_roofline(dtype, sec):
+        tf, peak = flop_per_step / sec, MODES[dtype]["peak"]
+        return {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                "frac_of_f32_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"}
+
+    folded = args.dtype in SPLIT_DTYPES and not args.no_ln_fold
     line = {
         "metric": "hypotheses/sec through DDIM loop (H3WB 133-kp, P=20, T=10)",
         "value": round(value, 3), "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": dtype_label,
+        "dtype": MODES[args.dtype]["label"],
         "data": "synthetic",
         "config": {"workload": f"D3DP.forward flip-TTA DDIM loop, H3WB 27x134 clips, B={B}, P={P_local}/GPU "
                                f"(P={P_total} total), T={T}, part-based MixSTE2 body/face/hands 384/224/256 ch, depth 8",
-                   "B": B, "P_per_gpu": P_local, "P_total": P_total, "T": T, "flip_tta": True,
+                   "B": B, "P_per_gpu": P_local, "P_total": P_total, "T": T, "flip_tta": True, "precision": args.dtype,
                    "parallelism": f"hypothesis-sharded x{world} + 1 all-gather" if world > 1 else "single GPU",
                    "collective_backend": (("nccl (RCCL)" if args.backend == "nccl" else "gloo (REHEARSAL, not a "
                                            "performance number)") if world > 1 else None),
                    "single_device_rehearsal": bool(args.single_device),
                    "weights": "seeded synthetic (no checkpoint offline)", "noise": "torch.randn on device (Philox)"},
         "kernel_source_sha256": _lib.kernel_source_digest(),
-        "streams": lanes, "layernorm_folded_into_gemms": bool(args.dtype in SPLIT_DTYPES and not args.no_ln_fold and (args.dtype == "f16x2" or args.ln_fold)),
-        "residual_stream_in_memory": ("H image only (two fp16 slices, 22-23 significant bits)" if args.dtype == "f16x2" and not args.no_ln_fold
-                                      and not args.f32_residual else "fp32 rows"),
+        "streams": lanes, "layernorm_folded_into_gemms": bool(folded),
+        "residual_stream_in_memory": ("fp32 rows" if not folded or args.f32_residual or args.dtype == "bf16x3" else
+                                      "H image only (two fp16 slices, 22-23 significant bits)" if args.dtype == "f16x2" else
+                                      "X image only (three bf16 slices: the fp32 number exactly)") + (", centred on the row means" if folded else ""),
         "qkv_attention_fused_blocks": {name: _lib.check(_lib.load().pafuse_mixste2_fused_blocks(C.byref(m.weights_struct())))
                                        for name, m in model.denoisers().items()} if args.dtype in SPLIT_DTYPES else None,
         "ranks_seen": census["ranks_seen"], "P_local_per_rank": census["P_local"],
         "allgather_ms": gather_ms, "allgather_ms_note": "collective + the one layout pass, max over ranks", "gather_copy_ms": copy_ms,
-        "roofline_loop": {"bound": "mfma", "achieved": round(loop_tflops, 2), "peak": peak,
-                          "unit": "TFLOP/s", "frac": round(loop_tflops / peak, 4),
-                          "frac_of_f32_peak": round(loop_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                          "note": "whole timed loop per GPU: B*P*2*T*69.3847 GFLOP / step time"},
+        "roofline_loop": loop_roofline(args.dtype, sec_per_step),
     }
 
     # ---- dominant kernel family: the linear-layer GEMM launches of one flip-TTA denoiser pass, HIP-event timed ----
     if not args.no_roofline and rank == 0:
-        lib = _lib.load()
-        cfg = model.config_struct(True)
-        nbytes = lib.pafuse_d3dp_workspace_bytes(C.byref(cfg), B, P_local)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        stream = torch.cuda.current_stream(dev)
-        reps = 3
-        # the replay launches what the timed loop launched: part by part when the loop ran on side streams, the shared
-        # grids of the single-stream bf16x3 schedule otherwise (pafuse_d3dp_config.part_by_part_launches, per call)
-        per_part = lanes > 1 or args.dtype != "bf16x3"
-        cfg.part_by_part_launches = int(per_part)
-        flops = C.c_double(0.0)
-        launches = _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
-                                                           stream.cuda_stream, C.byref(flops)))       # warm-up
-        torch.cuda.synchronize(dev)
-        flops = C.c_double(0.0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(reps):
-            _lib.check(lib.pafuse_d3dp_replay_gemms(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
-                                                    stream.cuda_stream, C.byref(flops)))
-        e1.record(stream)
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1)
-        n = launches * reps
-        achieved = flops.value / (ms * 1e-3) / 1e12
-        # the same for each layer kind alone (pafuse_d3dp_replay_layers): which kernels of the family are how far from peak
-        by_layer = {}
-        layer_kernel = ({1: "hfqa_kernel: qkv projection + attention in one kernel (every block of every part)",
-                         2: "hgemm_kernel<..EPI_ROWLN> (one launch per part)",
-                         4: "hmlp_kernel: fc1 + GELU + fc2 + residual + LayerNorms in one kernel (face, hands; its FLOPs are both layers'); "
-                            "hgemm_kernel<..EPI_BIAS> (body)",
-                         8: "hgemm_kernel<..EPI_ROWLN> (the body only: fc2 of the face and the hands is inside the fused MLP launch)"}
-                        if args.dtype == "f16x2" else
-                        {1: "gemm16_kernel (one launch per part)", 2: "grouped_rowln_kernel", 4: "grouped_bias_kernel",
-                         8: "grouped_rowln_kernel"} if not per_part else
-                        {1: "gemm16_kernel (one launch per part)", 2: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)",
-                         4: "gemm_kernel (one launch per part)", 8: "gemm_dma_kernel<..EPI_ROWLN> (one launch per part)"}
-                        if args.dtype in SPLIT_DTYPES else
-                        {1: "gemm_kernel", 2: "gemm_kernel<..EPI_ROWLN>", 4: "gemm_kernel", 8: "gemm_kernel<..EPI_ROWLN>"})
-        for bit, name in ((1, "qkv"), (2, "proj+LN"), (4, "fc1+GELU"), (8, "fc2+LN")):
-            fl = C.c_double(0.0)
-            nl = _lib.check(lib.pafuse_d3dp_replay_layers(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
-                                                          stream.cuda_stream, bit, C.byref(fl)))          # warm-up
-            fl = C.c_double(0.0)
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record(stream)
-            for _ in range(reps):
-                _lib.check(lib.pafuse_d3dp_replay_layers(C.byref(cfg), B, P_local, ws.data_ptr(), nbytes,
-                                                         stream.cuda_stream, bit, C.byref(fl)))
-            a1.record(stream)
-            torch.cuda.synchronize(dev)
-            t = a0.elapsed_time(a1)
-            if nl == 0:     # fc2 lives inside the fused MLP kernel, which the fc1 replay runs
-                by_layer[name] = {"kernel": "(inside the fused MLP kernel: see fc1+GELU)", "launches": 0}
-                continue
-            by_layer[name] = {"kernel": layer_kernel[bit], "launches": nl * reps, "avg_launch_us": round(t * 1e3 / (nl * reps), 2),
-                              "achieved": round(fl.value / (t * 1e-3) / 1e12, 2),
-                              "frac": round(fl.value / (t * 1e-3) / 1e12 / peak, 4)}
-        # HBM bytes per gemm_kernel launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside
-        # the benchmark): the committed summary is quoted only when it was taken on THIS tree's kernel sources.
+        obj, launches, pass_ms = family_replay(model, args.dtype, lanes)
+        n, ms = obj["launches"], obj["avg_launch_us"] * obj["launches"] / 1e3
+        # HBM bytes per launch come from rocprofv3 PMC passes of this same command (rocprof cannot run inside the benchmark):
+        # the committed summary is quoted only when it was taken on THIS tree's kernel sources and in this mode.
         traffic, traffic_info = None, {"traffic_source": None}
-        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
         if os.path.exists(tpath) and (B, P_local, T) == (1, 20, 10):
             tj = json.load(open(tpath))
-            if tj.get("dtype", "bf16x3") != args.dtype:
-                traffic_info = {"traffic_source": f"profiles/r04_pmc_traffic.json was collected in {tj.get('dtype', 'bf16x3')} mode: not quoted"}
+            if tj.get("dtype") != args.dtype:
+                traffic_info = {"traffic_source": f"profiles/r05_pmc_traffic.json was collected in {tj.get('dtype')} mode: not quoted"}
             elif tj.get("kernel_source_sha256") == _lib.kernel_source_digest():
                 traffic = round(tj["traffic_bytes_per_launch"])
-                traffic_info = {"traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                traffic_info = {"traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                                   "FETCH doubled per the gfx950 correction)",
                                 "hbm_GBps_dominant_kernel": round(traffic / (ms * 1e-3 / n) / 1e9, 1),
                                 "hbm_GBps_by_kernel_family": tj.get("hbm_GBps_by_kernel_family")}
             else:
-                traffic_info = {"traffic_source": "profiles/r04_pmc_traffic.json is from other kernel sources "
+                traffic_info = {"traffic_source": "profiles/r05_pmc_traffic.json is from other kernel sources "
                                                   "(kernel_source_sha256 differs): not quoted"}
-        # algorithmic bytes per launch, two ways: (i) this design's launch boundaries (every GEMM reads A and W and
-        # writes its outputs; whole-row kernels also read the residual and write x and xn); (ii) SURVEY 8(d)'s fused
-        # figure - weights once per pass + one read and one write of the residual stream per block:
-        # 140 MB + 2*16*sum(M*C)*4 B per flip-TTA pass, over the pass' GEMM launches
+        # algorithmic bytes per launch, two ways: (i) this design's launch boundaries in the fp32-activation modes (every GEMM
+        # reads A and W and writes its outputs; whole-row kernels also read the residual and write x; per token and block, in
+        # floats of C: qkv reads 1 writes 3; attention reads 3 writes 1; proj reads o, x writes x; fc1 reads 1 writes 2; fc2
+        # reads 2, x writes x = 14 with the LayerNorm folded (8 B of statistics per row instead of xn), 16 without; + the 139.8 MB
+        # of weights once); (ii) SURVEY 8(d)'s fused figure - weights once per pass + one read and one write of the residual stream
+        # per block: 140 MB + 2*16*sum(M*C)*4 B per flip-TTA pass - both over the pass' launches
         rows = 2 * B * P_local * 27
         mc = rows * (24 * 384 + 68 * 224 + 42 * 256)
-        # (i) per token and block: qkv reads C writes 3C; proj reads o, x writes x, xn; fc1 reads C writes 2C; fc2 reads
-        #     2C, x writes x, xn = 16 C floats (14 with the LayerNorm folded into qkv / fc1: no xn, 8 B of statistics per
-        #     row instead); 16 blocks per pass; + the 139.8 MB of weights once
-        per_token = 14 if (args.dtype in SPLIT_DTYPES and not args.no_ln_fold and (args.dtype == "f16x2" or args.ln_fold)) else 16
+        per_token = 14 if folded else 16
         alg_unfused = (mc * 4 * per_token * 16 + 139.8e6) / launches
-        if args.dtype == "f16x2" and not (args.no_ln_fold or args.f32_residual or args.fuse_qkv_attention == "off"):
-            # round 4's launch boundaries (4 bytes per element everywhere: fp32 or the two-slice image).  Per token and block, in
-            # units of C: qkv + attention reads x, writes o (2); proj reads o and the residual, writes x (3); the MLP as one
-            # kernel reads x (operand and residual: once from memory) and writes x (2) - as two launches it also writes and
-            # reads the 2C hidden and re-reads the residual (7)
-            fused_mlp = {"body": args.fuse_mlp == "on" and "body" in args.fuse_mlp_parts.split(","),
-                         "face": args.fuse_mlp == "auto" or (args.fuse_mlp == "on" and "face" in args.fuse_mlp_parts.split(",")),
-                         "hands": args.fuse_mlp == "auto" or (args.fuse_mlp == "on" and "hands" in args.fuse_mlp_parts.split(","))}
-            units = {k: 2 + 3 + (2 if v else 7) for k, v in fused_mlp.items()}
-            alg_unfused = (rows * 4 * 16 * (24 * 384 * units["body"] + 68 * 224 * units["face"] + 42 * 256 * units["hands"]) + 139.8e6) / launches
         alg_fused = (139.8e6 + 2 * 16 * mc * 4) / launches
-        mfma = ("v_mfma_f32_32x32x2_f32" if args.dtype == "f32" else
-                "v_mfma_f32_32x32x16_bf16; the qkv layers v_mfma_f32_16x16x32_bf16" if args.dtype == "bf16x3" else
-                "v_mfma_f32_32x32x16_f16; the qkv layers v_mfma_f32_16x16x32_f16" if args.dtype == "f16x2" else "v_mfma_f32_32x32x16_bf16")
-        peak_note = {"f32": "dense f32-input matrix peak",
-                     "bf16x3": "dense bf16 matrix peak 2500 / 6 products; the same FLOPs against the f32-input matrix "
-                               f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
-                     "f16x2": "dense fp16 matrix peak 2500 / 3 products; the same FLOPs against the f32-input matrix "
-                              f"peak {PEAK_F32_MFMA_TFLOPS}: frac_of_f32_peak",
-                     "bf16": "dense bf16 matrix peak"}[args.dtype]
-        products = {"bf16x3": 6, "f16x2": 3}.get(args.dtype, 1)          # matrix instructions executed per useful product
-        family = ("hgemm_kernel, hfqa_kernel (whose attention phase is inside the timed launches), hmlp_kernel" if args.dtype == "f16x2" else
-                  ("gemm16_kernel, gemm_kernel, gemm_dma_kernel" if per_part else
-                   "gemm16_kernel, grouped_bias_kernel, grouped_rowln_kernel") if args.dtype == "bf16x3" else "gemm_kernel")
-        line["roofline"] = {"bound": "mfma", "kernel": f"pafuse linear-layer GEMM family: {family} ({mfma})",
-                            "schedule": (f"timed loop: {lanes} streams, one body-part denoiser per stream; this object: the same "
-                                         "launches replayed one after the other on one stream" if lanes > 1 else
-                                         "timed loop and this replay: one stream"),
-                            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                            "frac": round(achieved / peak, 4), "peak_note": peak_note,
-                            "frac_of_f32_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                            # the same launches seen three ways: `frac` above prices the useful FLOPs against the
-                            # ceiling of the arithmetic scheme; these two price them / the executed matrix work against the
-                            # dense peak of the instruction that runs
-                            "frac_of_bf16_dense_peak": None if args.dtype == "f32" else round(achieved / PEAK_BF16_MFMA_TFLOPS, 4),
-                            "mfma_pipe_frac": round(achieved * products / (PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS), 4),
-                            "mfma_pipe_note": "executed matrix FLOPs (useful x 6 products in bf16x3, x 3 in f16x2) / dense peak of the instruction; "
-                                              "SQ_VALU_MFMA_BUSY_CYCLES of the same launches: profiles/r04_pmc_mfma_util.json",
-                            "traffic": traffic,
-                            "traffic_unit": "HBM bytes per launch",
-                            "algorithmic_bytes_per_launch": {"this_design_launch_boundaries": round(alg_unfused),
-                                                             "survey_8d_fused_blocks": round(alg_fused)},
-                            "traffic_over_algorithmic": None if traffic is None else {
-                                "vs_this_design": round(traffic / alg_unfused, 2), "vs_survey_8d": round(traffic / alg_fused, 2)},
-                            **traffic_info,
-                            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2),
-                            "flops_per_launch": round(flops.value / n / 1e9, 3),
-                            "flops_unit": "GFLOP (algorithmic 2*M*N*K)",
-                            "by_layer": by_layer,
-                            "by_layer_note": "each layer kind of the pass replayed alone (same tiles, HIP events); "
-                                             "achieved in TFLOP/s, frac against `peak`"}
+        obj.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                    "algorithmic_bytes_per_launch": {"this_design_launch_boundaries_fp32_activations": round(alg_unfused),
+                                                     "survey_8d_fused_blocks": round(alg_fused)},
+                    "traffic_over_algorithmic": None if traffic is None else {
+                        "vs_this_design": round(traffic / alg_unfused, 2), "vs_survey_8d": round(traffic / alg_fused, 2)},
+                    **traffic_info})
+        line["roofline"] = obj
+
+    # ---- the opt-in product modes, timed in the same run (N = 1, default invocation only): named objects, never `value` ----
+    if world == 1 and args.dtype == DEFAULT_DTYPE and not args.no_secondary:
+        del model
+        for dtype in SECONDARY_DTYPES:
+            m2, _ = make(dtype)
+            sec2, _ = timed(m2, args.steps, max(args.warmup, 1))
+            lanes2 = _lib.check(_lib.load().pafuse_d3dp_lanes(C.byref(m2.config_struct(True)), B, P_local, args.streams))
+            sub = {"value": round(B * P_total / sec2, 3), "unit": "hypotheses/s", "ms_per_step": round(sec2 * 1e3, 3), "steps": args.steps,
+                   "dtype": MODES[dtype]["label"], "roofline_loop": loop_roofline(dtype, sec2),
+                   "note": "opt-in mode, timed in this run after the default; NOT the headline" +
+                           (": its operands are narrower than the reference's fp32 (22 - 23 bits)" if dtype == "f16x2" else
+                            ": the same arithmetic as `value` on the image pipeline")}
+            if not args.no_roofline:
+                sub["roofline"], _, _ = family_replay(m2, dtype, lanes2, by_layer=False)
+            line[f"value_{dtype}"] = sub
+            del m2
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample ---------------------------------------------
     if not args.no_cpu_baseline and rank == 0:

@@ -40,6 +40,7 @@ extern "C" {
 #define PAFUSE_E_SHAPE (-2)     /* a width this build has no kernel for */
 #define PAFUSE_E_WORKSPACE (-3) /* workspace too small */
 #define PAFUSE_E_HIP (-4)       /* a HIP launch failed */
+#define PAFUSE_E_RANGE (-5)     /* pafuse_d3dp_check_range: a denoiser output was not finite ('f16x2': an activation left the fp16 range) */
 
 #define PAFUSE_MAX_DEPTH 16
 #define PAFUSE_MAX_PARTS 4
@@ -297,6 +298,16 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config *cfg, const pafuse_ddim_step *st
                        const float *x2d, const float *x2d_flip, const float *noise, int32_t n_draws, int32_t B,
                        int32_t P, float *out, void *workspace, size_t workspace_bytes, void *stream,
                        void *const *aux_streams, int32_t n_aux);
+
+/* Loud failure through the loop.  pafuse_d3dp_sample keeps one int32 in its workspace (byte offset pafuse_d3dp_range_flag_offset,
+ * zeroed at the start of every call) that the output stage of every step sets when a denoiser prediction is not finite.  The
+ * values themselves flow on as NaN - the clamps of the loop keep a NaN a NaN, exactly as torch.clamp does
+ * (common/diffusionpose.py:193,216-217) - so an 'f32' / 'bf16x3' run returns what the reference returns.  In 'f16x2' a non-finite
+ * prediction is how an activation beyond the fp16 range shows (|a| >= 65504: its high slice is inf): callers of that mode ask
+ * pafuse_d3dp_check_range after the call - the ONE entry point of this library that synchronises (`stream`) - and get
+ * PAFUSE_E_RANGE; pafuse_amd.D3DP raises.  (Inside a stream capture, read the word yourself after the replay.) */
+size_t pafuse_d3dp_range_flag_offset(const pafuse_d3dp_config *cfg, int32_t B, int32_t P);
+int pafuse_d3dp_check_range(const pafuse_d3dp_config *cfg, int32_t B, int32_t P, const void *workspace, void *stream);
 
 /* Number of distinct HIP streams pafuse_d3dp_sample will launch on when handed `n_aux` aux streams (the caller's
  * stream + the first (result - 1) aux streams).  A caller that forks its aux streams into a stream capture must fork

@@ -91,6 +91,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32]),
     "pafuse_d3dp_lanes": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_int32]),
+    "pafuse_d3dp_range_flag_offset": (C.c_size_t, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32]),
+    "pafuse_d3dp_check_range": (C.c_int, [C.POINTER(D3DPConfig), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pafuse_embed": (C.c_int, [C.c_void_p] * 11 + [C.c_float] + [C.c_int32] * 8 + [C.c_double, C.c_void_p, C.c_void_p,
                                                                                     C.c_void_p]),
     "pafuse_ddim_finalize": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32] + [C.c_void_p] * 6 +

@@ -78,14 +78,14 @@ __global__ void __launch_bounds__(256) hsplit_weights_kernel(const float* W, uin
 // cost 30 000 line transactions: 62 000 cycles of epilogue against 35 000 of K loop (tools/hgemm_bench.hip stamps).  Through
 // the slab a wave instruction moves 1 KiB in 8 lines (4 rows x 256 B).
 // LDS (the dead ring): [7 BM WN floats: cross-wave partial sums][5 BN floats: per-column vectors][NW slabs of 32 x (32 NTH + 4)].
-// SL = 3: the X pipeline (xgemm.hpp) - images are X images (three bf16 slices, 6 bytes per element, exact), ws = 1
-template <int WN, int NT, int BM, int NW, int NTH, bool HRES, int SL = 2>   // HRES: the residual is the centred image of x (p.resid_h)
+// NSLICE = 3: the X pipeline (xgemm.hpp) - images are X images (three bf16 slices, 6 bytes per element, exact), ws = 1
+template <int WN, int NT, int BM, int NW, int NTH, bool HRES, int NSLICE = 2>   // HRES: the residual is the centred image of x (p.resid_h)
 __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0, const int wm,
                                                 const int wn, const int r, const int h, const int wave, const int lane, float* smem,
                                                 const float ws) {
-    static_assert(SL == 2 || SL == 3, "H image (two fp16 slices) or X image (three bf16 slices)");
-    constexpr int SEG = (HRES && SL == 3) ? 48 : 32;   // floats of a slab row per 32-column block: a row segment of the X image is 192 bytes
-    constexpr int EB = (HRES && SL == 3) ? 6 : 4;      // bytes per element of the residual's storage
+    static_assert(NSLICE == 2 || NSLICE == 3, "H image (two fp16 slices) or X image (three bf16 slices)");
+    constexpr int SEG = (HRES && NSLICE == 3) ? 48 : 32;   // floats of a slab row per 32-column block: a row segment of the X image is 192 bytes
+    constexpr int EB = (HRES && NSLICE == 3) ? 6 : 4;      // bytes per element of the residual's storage
     constexpr int BNV = WN * NT * 32, VEC = (7 * BM * WN + 3) / 4 * 4, SLAB0 = VEC + 5 * BNV, ST = SEG * NTH + 4;
     constexpr int NPASS = (NT + NTH - 1) / NTH;
     float* const red = smem;
@@ -181,7 +181,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                     const int nt = ps * NTH + j;
                     const f32x4 b4 = vec4(0, nb + 32 * nt + 8 * q);
                     f32x4 r4;
-                    if constexpr (HRES && SL == 3) {   // chunk j of the slab row: slice planes at + 0, + 64, + 128 bytes; sub-block q, this lane's half 4 h
+                    if constexpr (HRES && NSLICE == 3) {   // chunk j of the slab row: slice planes at + 0, + 64, + 128 bytes; sub-block q, this lane's half 4 h
                         const uint8_t* sbk = reinterpret_cast<const uint8_t*>(slab + r * ST + SEG * j) + 16 * q + 8 * h;
                         r4 = xjoin4(*reinterpret_cast<const u32x2*>(sbk), *reinterpret_cast<const u32x2*>(sbk + 64),
                                     *reinterpret_cast<const u32x2*>(sbk + 128));   // exact: the fp32 number that was split
@@ -250,7 +250,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
 #pragma unroll
                             for (int e = 0; e < 4; ++e) c0[e] -= mu, c1[e] -= mu;
                         }
-                        if constexpr (SL == 3) {
+                        if constexpr (NSLICE == 3) {
                             xsplit_store8(dsth + (size_t)(mw + row) * p.N * 6, ncol0 + 8 * sb, c0, c1);
                         } else {
                             const f16x8x2 sp = split2h(c0, c1);
@@ -647,8 +647,8 @@ __device__ __forceinline__ int hfqa_swizzle(int row) { return (((row >> 1) & 3) 
 // phase 3 of the fused qkv + attention kernels (hfqa_kernel here, xfqa_kernel in xgemm.hpp): attention per (sequence of the tile,
 // 16-query tile) from the q | k | v tiles in LDS ([ROWS][DP + 4] fp32 each, token i of tile sequence s at row s L + i) -
 // attn_kernel's arithmetic per item on v_mfma_f32_16x16x4_f32 - and o written once, as the image the proj GEMM reads
-// (SL = 2: H image, SL = 3: X image).  Lane (c, qd) = (lane & 15, lane >> 4).
-template <int LP, int DP, int NWV, int ROWS, int SL, class TokenOf>
+// (NSLICE = 2: H image, 3: X image).  Lane (c, qd) = (lane & 15, lane >> 4).
+template <int LP, int DP, int NWV, int ROWS, int NSLICE, class TokenOf>
 __device__ __forceinline__ void fqa_attention_from_lds(const FqaParams& fp, float* smem, const int64_t seq0, const int head, const int wave,
                                                        const int c, const int qd, TokenOf token_of) {
     constexpr int LDV = DP + 4;
@@ -766,12 +766,12 @@ __device__ __forceinline__ void fqa_attention_from_lds(const FqaParams& fp, floa
         for (int u = 0; u < U; ++u) {
             const int q = qt[u] * 16 + l15;
             if (valid[u] && q < L) {   // channel ch = head d + 16 ct + 4 g4 (a multiple of 4): sub-block ch / 8, its second half when ch & 4
-                uint8_t* const hrow = reinterpret_cast<uint8_t*>(fp.o) + (size_t)token_of(rb[u] + q) * fp.C * (SL == 3 ? 6 : 4);
+                uint8_t* const hrow = reinterpret_cast<uint8_t*>(fp.o) + (size_t)token_of(rb[u] + q) * fp.C * (NSLICE == 3 ? 6 : 4);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     if (ct * 16 + 4 * g4 < fp.d) {
                         const int ch = head * fp.d + ct * 16 + 4 * g4;
-                        if constexpr (SL == 3) xsplit_store4(hrow, ch, oc[u][ct]);
+                        if constexpr (NSLICE == 3) xsplit_store4(hrow, ch, oc[u][ct]);
                         else hsplit_store4(hrow + (ch >> 3) * 32, ch & 4, oc[u][ct]);
                     }
             }

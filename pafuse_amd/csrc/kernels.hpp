@@ -259,6 +259,10 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint
     *reinterpret_cast<bf16x8*>(dst + 32) = s.s2;
 }
 
+// torch.clamp(x, -lim, lim): a NaN stays a NaN (common/diffusionpose.py:193,216-217) - fminf(fmaxf(x, -lim), lim) would turn it into
+// -lim, a finite wrong pose.  Both comparisons are false for a NaN.
+__device__ __forceinline__ float clamp_keep_nan(float x, float lim) { return x < -lim ? -lim : (x > lim ? lim : x); }
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // nn.GELU() default (approximate='none'): x * 0.5 * (1 + erf(x / sqrt(2)))   (common/mixste.py:25,32)
     // erf(z) = sign(z) (1 - 2^(a Q(a))), a = min(|z|, 4): ONE branch-free form for every z instead of libm's two
@@ -438,14 +442,9 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
     const int64_t mo = (live ? m : p.M - 1) * p.N;
     const int nb = n0 + wn * NT * 32 + 4 * h;  // + 32*nt + 8*q
     if constexpr (EPI == EPI_BIAS) {
-        // folded LayerNorm (ln_in): out = rstd * acc + (-rstd * mean) * S[n] + T[n]; the lane owns the row
-        float rstd = 1.0f, nmr = 0.0f;
-        if (p.ln_in) {
-            const int64_t mm = live ? m : p.M - 1;
-            const float mean = p.ln_in[2 * mm];
-            rstd = p.ln_in[2 * mm + 1];
-            nmr = -mean * rstd;
-        }
+        // folded LayerNorm (ln_in): A is the CENTRED row x - mean(x), so out = rstd * acc + T[n]; the lane owns the row
+        float rstd = 1.0f;
+        if (p.ln_in) rstd = p.ln_in[2 * (live ? m : p.M - 1) + 1];
         rstd *= ws;   // (exact: a power of two)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -455,9 +454,8 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
                 f32x4 v;
                 if (p.ln_in) {
-                    const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[nt][4 * q + e], fmaf(nmr, s4[e], b4[e]));
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[nt][4 * q + e], b4[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[nt][4 * q + e], ws, b4[e]);   // ws = 1: acc + b, same bits
@@ -554,21 +552,25 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                     for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] += pe[e];
                 }
         }
-        if (p.out_x && live) {
+        const bool folded = p.next_w && p.ln_stats;
+        auto store_x = [&](const float mean) {   // out_x = z - mean (mean = 0: z itself)
+            if (p.out_x && live) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v;
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e];
-                    *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
-                    // the same values as the H image the next qkv / fc1 reads: columns nb + 32 nt + 8 q .. + 3 are the half
-                    // 4 h of the sub-block that starts at column (nb - 4 h) + 32 nt + 8 q
-                    if (p.out_xh) hsplit_store4(p.out_xh + 4 * (mo + (nb - 4 * h) + 32 * nt + 8 * q), 4 * h, v);
-                }
-        }
-        if (p.next_w && p.ln_stats) {
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nt][4 * q + e] - mean;
+                        *reinterpret_cast<f32x4*>(p.out_x + mo + nb + 32 * nt + 8 * q) = v;
+                        // the same values as the H image the next qkv / fc1 reads: columns nb + 32 nt + 8 q .. + 3 are the half
+                        // 4 h of the sub-block that starts at column (nb - 4 h) + 32 nt + 8 q
+                        if (p.out_xh) hsplit_store4(p.out_xh + 4 * (mo + (nb - 4 * h) + 32 * nt + 8 * q), 4 * h, v);
+                    }
+            }
+        };
+        if (!folded) store_x(0.0f);
+        if (folded) {
             // the next LayerNorm is folded into the GEMM that consumes it: emit the row's statistics only (the same two
             // fixed-order reductions layer_norm makes), no normalise pass, no out_n
             float s = 0.f;
@@ -590,6 +592,11 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                 p.ln_stats[2 * m] = mean;
                 p.ln_stats[2 * m + 1] = rstd;
             }
+            // The residual stream is stored CENTRED on the row mean (round 5; the image pipelines of hgemm.hpp / xgemm.hpp do the
+            // same): the consumer GEMM then multiplies x - mean and its folded LayerNorm is rstd acc + lt - no mean (W g) term, so
+            // nothing cancels however large a row's mean is.  The mean itself is carried nowhere: every reader of the stream is
+            // a LayerNorm or the residual add that feeds one, and LayerNorm does not see a row's mean.
+            store_x(mean);
         } else if (p.next_w) {
             layer_norm(p.next_w, p.next_b, p.next_eps, 2, 3);
             if (p.out_nh && live) {
@@ -848,15 +855,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
         constexpr int ST = 32 * NTH + 4;
         float* slab = smem + wave * 32 * ST;
         const int64_t mw = m0 + wm * 32;
-        // folded LayerNorm (ln_in): lane i < 32 fetches the statistics of the strip's row i now and parks (rstd, -mean rstd)
-        // in the slab's 4 pad columns behind the first barrier below, where phase 2 reads them from LDS
-        float st_a = 1.0f, st_b = 0.0f;
-        if (p.ln_in && lane < 32) {
-            const int64_t mm = mw + lane < p.M ? mw + lane : p.M - 1;
-            const float mean = p.ln_in[2 * mm];
-            st_a = p.ln_in[2 * mm + 1];
-            st_b = -mean * st_a;
-        }
+        // folded LayerNorm (ln_in; A is the centred row): lane i < 32 fetches rstd of the strip's row i now and parks it in the
+        // slab's pad columns behind the first barrier below, where phase 2 reads it from LDS
+        float st_a = 1.0f;
+        if (p.ln_in && lane < 32) st_a = p.ln_in[2 * (mw + lane < p.M ? mw + lane : p.M - 1) + 1];
 #pragma unroll
         for (int nt0 = 0; nt0 < NT; nt0 += NTH) {
             const int nth = (NT - nt0) < NTH ? (NT - nt0) : NTH;  // compile-time after unrolling
@@ -864,11 +866,8 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
             const int rpi = 64 / c4n;
             const int row_in = lane / c4n, c4 = lane % c4n;
             const int ncol = n0 + (wn * NT + nt0) * 32 + c4 * 4;
-            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, t4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.ln_in && c4 < 8 * nth) {   // this lane's column vectors of phase 2, in flight during phase 1
-                s4 = *reinterpret_cast<const f32x4*>(p.ln_s + ncol);
-                t4 = *reinterpret_cast<const f32x4*>(p.bias + ncol);
-            }
+            f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.ln_in && c4 < 8 * nth) t4 = *reinterpret_cast<const f32x4*>(p.bias + ncol);   // this lane's column vector of phase 2, in flight during phase 1
 #pragma unroll
             for (int q = 0; q < NTH; ++q) {
                 if (q < nth) {
@@ -887,10 +886,7 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
                     }
                 }
             }
-            if (nt0 == 0 && p.ln_in && lane < 32) {
-                slab[lane * ST + 32 * NTH] = st_a;
-                slab[lane * ST + 32 * NTH + 1] = st_b;
-            }
+            if (nt0 == 0 && p.ln_in && lane < 32) slab[lane * ST + 32 * NTH] = st_a;
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 32 * 8 * NTH / 64; ++i) {
@@ -898,10 +894,10 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
                 if (row < 32 && c4 < 8 * nth && mw + row < p.M) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * ST + c4 * 4);
                     if (p.ln_in) {
-                        const float rstd = slab[row * ST + 32 * NTH], nmr = slab[row * ST + 32 * NTH + 1];
+                        const float rstd = slab[row * ST + 32 * NTH];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = fmaf(rstd, v[e], fmaf(nmr, s4[e], t4[e]));
+                            v[e] = fmaf(rstd, v[e], t4[e]);
                             if (p.act) v[e] = gelu_erf(v[e]);
                         }
                     }
@@ -1053,21 +1049,16 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
     for (int g = 0; g < 2; ++g) {
         const int64_t m = m0 + 32 * wave + 16 * g + c;
         if (m >= p.M) continue;
-        float rstd = 1.0f, nmr = 0.0f;
-        if (p.ln_in) {   // folded LayerNorm: the lane owns the token
-            const float mean = p.ln_in[2 * m];
-            rstd = p.ln_in[2 * m + 1];
-            nmr = -mean * rstd;
-        }
+        float rstd = 1.0f;
+        if (p.ln_in) rstd = p.ln_in[2 * m + 1];   // folded LayerNorm (A is the centred row): the lane owns the token
         float* const orow = p.out + m * p.N + n0 + 4 * qd;
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
             f32x4 v;
             if (p.ln_in) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + 16 * n + 4 * qd);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
@@ -1908,22 +1899,16 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int r = 32 * wave + 16 * g + c;
-        float rstd = 1.0f, nmr = 0.0f;
-        if (p.ln_in) {
-            const int64_t m = token_of(r);
-            const float mean = p.ln_in[2 * m];
-            rstd = p.ln_in[2 * m + 1];
-            nmr = -mean * rstd;
-        }
+        float rstd = 1.0f;
+        if (p.ln_in) rstd = p.ln_in[2 * token_of(r) + 1];   // (A is the centred row)
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const int col = 16 * n + 4 * qd;   // 0 .. 3 DP - 1: part = col / DP (a 16-column block never straddles parts)
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + col);
             f32x4 v;
             if (p.ln_in) {
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.ln_s + n0 + col);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], fmaf(nmr, s4[e], b4[e]));
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
@@ -2126,6 +2111,7 @@ struct EmbedParams {
     uint8_t* xh;    // f16x2 H pipeline: the H image [M,C] the first qkv hgemm reads - of x - mean(row) when `stats` is set
     //                 (LayerNorm folded), else of the normalised row (then xn is not written)
     int x_image;    // xh is an X image (bf16x3 on the LDS-DMA pipeline, xgemm.hpp: 6 bytes per element) instead of an H image
+    int centre_x;   // with `stats`: the fp32 rows `x` are stored centred, x - mean(row) (mode 2's folded LayerNorm, as the images are)
     float* stats;   // folded LayerNorm (GemmParams::ln_in of the first qkv GEMM): (mean, rstd) of row row0 + i at stats[2 i]
     //                 instead of xn; null = write xn
     int B, P, F, J, J3, C, nflip;
@@ -2159,7 +2145,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
     if (p.do_clamp) {
         const float lim = p.lim;
 #pragma unroll
-        for (int i = 2; i < 5; ++i) in[i] = fminf(fmaxf(in[i], -lim), lim) / p.scale;
+        for (int i = 2; i < 5; ++i) in[i] = clamp_keep_nan(in[i], lim) / p.scale;
     }
     if (fl) in[2] = -in[2];
     const int NQ = p.C / 4;
@@ -2191,7 +2177,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
                 v[i][e] = a;
                 s += a;
             }
-            if (live && p.x) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
+            if (live && p.x && !(p.stats && p.centre_x)) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = v[i];
 
         }
     }
@@ -2213,7 +2199,7 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
             p.stats[2 * local] = mean;
             p.stats[2 * local + 1] = rstd;
         }
-        if (p.xh && live) {   // f16x2: the H image of x, CENTRED on the row mean (hgemm.hpp epilogue_rows_h)
+        if ((p.xh || (p.centre_x && p.x)) && live) {   // the image of x (and, mode 2, its fp32 rows), CENTRED on the row mean
 #pragma unroll
             for (int i = 0; i < EMBED_NV; ++i) {
                 const int c4 = li + 32 * i;
@@ -2221,6 +2207,8 @@ __global__ void __launch_bounds__(256) embed_kernel(const EmbedParams p) {
                     f32x4 cv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) cv[e] = v[i][e] - mean;
+                    if (p.centre_x && p.x) *reinterpret_cast<f32x4*>(p.x + row * p.C + 4 * c4) = cv;
+                    if (!p.xh) continue;
                     if (p.x_image) xsplit_store4(p.xh + (size_t)row * p.C * 6, 4 * c4, cv);
                     else hsplit_store4(p.xh + (row * p.C + 8 * (c4 >> 1)) * 4, 4 * (c4 & 1), cv);
                 }
@@ -2261,6 +2249,9 @@ struct FinalizeParams {
     float scale, lim;  // (float)scale and (float)(1.1 * scale) (fp64 product), see EmbedParams
     double sr, srm1, c;
     float an_f, c_f, sigma_f;
+    int32_t* range_flag;   // device word (or null): set to 1 when a denoiser output of this step is not finite - in 'f16x2' the loud
+    //                        form of an activation beyond the fp16 range (|a| >= 65504 -> inf -> NaN); the values themselves flow on as
+    //                        NaN, as the reference's would (no clamp hides them)
 };
 
 __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
@@ -2276,19 +2267,22 @@ __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
     const int part = p.joint_part[j], lj = p.joint_local[j];
     const float* a = p.pred[part] + ((bp * p.F + f) * p.Jp[part] + lj) * 3;
     float x0[3] = {a[0], a[1], a[2]};
+    bool finite = isfinite(x0[0]) && isfinite(x0[1]) && isfinite(x0[2]);
     if (p.flip) {
         const int js = p.perm[j];
         const int part2 = p.joint_part[js], lj2 = p.joint_local[js];
         const float* u = p.pred[part2] + ((((int64_t)p.B * p.P + bp) * p.F + f) * p.Jp[part2] + lj2) * 3;
+        finite = finite && isfinite(u[0]) && isfinite(u[1]) && isfinite(u[2]);
         x0[0] = __fdiv_rn(__fadd_rn(x0[0], -u[0]), 2.0f);
         x0[1] = __fdiv_rn(__fadd_rn(x0[1], u[1]), 2.0f);
         x0[2] = __fdiv_rn(__fadd_rn(x0[2], u[2]), 2.0f);
     }
+    if (!finite && p.range_flag) *p.range_flag = 1;   // (every writer stores the same word: no atomic needed)
     const float lim = p.lim;
     float* o = p.out + ((((int64_t)b * p.T + p.step) * p.P + pp) * p.F + f) * p.J * 3 + j * 3;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        x0[k] = fminf(fmaxf(__fmul_rn(x0[k], p.scale), -lim), lim);
+        x0[k] = clamp_keep_nan(__fmul_rn(x0[k], p.scale), lim);
         o[k] = x0[k];
     }
     float* im = p.img + e * 3;

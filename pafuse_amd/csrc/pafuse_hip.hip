@@ -335,12 +335,14 @@ int launch_xgemm(const GemmParams& p, hipStream_t s) {
     return check_launch("xgemm_kernel");
 }
 
-// tile choice per shape (tools/hgemm_bench.hip -DX): six products per k make these layers matrix-bound again, so the tiles are
-// the H pipeline's with the ring re-cut for 6 bytes per element: 16-deep chunks throughout, two workgroups per CU where the
-// ring allows it (the epilogue of one tile under the K loop of the other)
+// tile choice per shape: tools/xgemm_bench.hip (profiles/r05_xgemm_bench.log).  With six products per k the K loops of these
+// tiles are balanced between the matrix pipe and the L2 -> LDS stream (a 128 x 128 tile asks for 24 KB per 768 matrix cycles,
+// the stream gives 25 - 32 B per cycle and CU; in-kernel stamps: 70 - 80 % matrix-pipe use inside the loops).  What is left is per
+// tile - first-chunk latency, epilogue, the last partial round of a launch -, so the winners are the tiles that keep MORE
+// workgroups per CU in different phases (four-wave tiles on two-stage rings of 16-deep chunks: three per CU).
 int xgemm_bias(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
-    if (p.N % 128 == 0) return launch_xgemm<4, 2, 2, EPI_BIAS, 3, 16, 2>(p, s);   // 128 x 128, eight waves, 72 KB ring: two per CU
+    if (p.N % 128 == 0) return launch_xgemm<4, 1, 4, EPI_BIAS, 2, 16, 3>(p, s);   // 128 x 128, four waves, 48 KB ring: three per CU
     if (p.N % 224 == 0) return launch_xgemm<4, 1, 7, EPI_BIAS, 2, 16, 2>(p, s);   // 128 x 224 (the face: 448 = 2 x 224), 66 KB: two per CU
     if (p.N % 96 == 0) return launch_xgemm<4, 1, 3, EPI_BIAS, 3, 16, 2>(p, s);    // 128 x 96 (unit tests: 672, 96)
     return fail(PAFUSE_E_SHAPE, "bf16x3 image linear: N=%d must be a multiple of 128, 224 or 96", p.N);
@@ -351,8 +353,9 @@ int xgemm_rowln(const GemmParams& p, hipStream_t s) {
     if (p.resid_h)   // the residual stream as its (centred) X image: the default of the folded-LayerNorm pipeline
         switch (p.N) {
             case 384: return launch_xgemm<4, 2, 6, EPI_ROWLN, 3, 16, 1, true>(p, s);   // 128 rows, eight waves, 144 KB ring: one per CU
-            case 256: return launch_xgemm<2, 2, 4, EPI_ROWLN, 2, 16, 2, true>(p, s);   // 64 rows, four waves, 60 KB: two per CU
-            case 224: return launch_xgemm<4, 1, 7, EPI_ROWLN, 2, 16, 2, true>(p, s);   // 128 rows, four waves, 66 KB: two per CU
+            case 256: return launch_xgemm<3, 2, 4, EPI_ROWLN, 3, 16, 1, true>(p, s);   // 96 rows, six waves, 99 KB: one per CU (473 tiles: 1.85 rounds)
+            case 224: return p.K <= 256 ? launch_xgemm<3, 1, 7, EPI_ROWLN, 2, 16, 2, true>(p, s)     // proj: 96 rows, three waves, 60 KB: two per CU
+                                        : launch_xgemm<3, 1, 7, EPI_ROWLN, 3, 16, 2, true>(p, s);    // fc2 (K = 448): a three-stage ring, one per CU
             default: break;
         }
     switch (p.N) {
@@ -588,6 +591,8 @@ int attention(const AttnParams& p, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------------------- per-part activations
+constexpr size_t RANGE_FLAG_BYTES = 256;   // behind pafuse_d3dp_sample's workspace: [0] int32, set when a denoiser output is not finite
+
 struct PartBuffers {
     float *x, *xn, *o, *wide;  // [M,C], [M,C], [M,C], [M,3C] (qkv, then the MLP hidden [M,2C])
     //                            f16x2 mode: xn, o and (as the hidden) wide hold H images of those tensors - same bytes;
@@ -730,7 +735,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws, g.wlayout = 2;   // qkv images are in the M16 layout (include/pafuse_hip.h)
     if (fold) g.A = pb.x, g.ln_in = stats, g.ln_s = bw.qkv_ls, g.bias = bw.qkv_lt;
     if (hp) g.Ah = xn_h, g.Wh = (const uint8_t*)bw.qkv_ws;
-    if (hp && fold) g.ln_s = nullptr;   // the H image of x is centred on the row mean: rstd acc + lt, no mean term
+    if (fold) g.ln_s = nullptr;   // x (its image; mode 2: its fp32 rows) is stored centred on the row mean: rstd acc + lt, no mean term
     AttnParams& a = b.attn;
     a.qkv = pb.wide, a.o = pb.o, a.nseq = nseq, a.L = L, a.C = C, a.heads = heads, a.d = C / heads;
     a.group = group, a.group_stride = group_stride, a.seq_stride = seq_stride, a.tok_stride = tok_stride;
@@ -742,7 +747,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
         const int lp = fqa_lp(L, bf16), dp = fqa_dp(C / heads);
         FqaParams& f = b.fqa;
         f.g = g;
-        f.g.Wsplit = (const uint8_t*)bw.qkv_hs, f.g.bias = bw.qkv_hb, f.g.ln_s = fold ? bw.qkv_hl : nullptr;
+        f.g.Wsplit = (const uint8_t*)bw.qkv_hs, f.g.bias = bw.qkv_hb, f.g.ln_s = nullptr;
         if (hp) f.g.Wh = (const uint8_t*)bw.qkv_hs, f.g.ln_s = nullptr;   // (Ah is the qkv launch's: centred; o is written as an H image)
         f.g.N = heads * 3 * dp;
         f.o = pb.o, f.nseq = nseq, f.L = L, f.C = C, f.heads = heads, f.d = C / heads;
@@ -772,7 +777,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
     if (fold) f1.A = pb.x, f1.ln_in = stats, f1.ln_s = bw.fc1_ls, f1.bias = bw.fc1_lt;
     if (hp) f1.Ah = xn_h, f1.Wh = (const uint8_t*)bw.fc1_ws, f1.out_h = reinterpret_cast<uint8_t*>(pb.wide);
-    if (hp && fold) f1.ln_s = nullptr;
+    if (fold) f1.ln_s = nullptr;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
     GemmParams& f2 = b.fc2;
     f2.A = pb.wide, f2.W = bw.fc2_w, f2.bias = bw.fc2_b, f2.M = M, f2.N = C, f2.K = hidden;
@@ -1242,6 +1247,7 @@ int pafuse_mixste2_forward(const pafuse_mixste2_weights* w, const float* x2d, co
     e.x = pb.x, e.xn = pb.xn, e.stats = ln_folded(w) ? pb.stats : nullptr;
     e.xh = w->operand_bf16 >= 3 ? reinterpret_cast<uint8_t*>(pb.xn) : nullptr;
     e.x_image = w->operand_bf16 == 4;
+    e.centre_x = w->operand_bf16 == 2 && ln_folded(w);
     if (h_residual_only(w)) e.x = nullptr;
     e.B = B, e.P = P, e.F = w->frames, e.J = w->joints, e.J3 = w->joints, e.C = w->channels, e.nflip = 1;
     e.do_clamp = 0, e.scale = 1.f, e.lim = 1.1f, e.row0 = 0, e.nrows = M;
@@ -1266,7 +1272,26 @@ size_t pafuse_d3dp_workspace_bytes(const pafuse_d3dp_config* cfg, int32_t B, int
         const pafuse_mixste2_weights& w = cfg->part[i];
         total += part_buffer_bytes((int64_t)nflip * B * P * w.frames * w.joints, w.channels, B, image_elem_bytes(w.operand_bf16));
     }
-    return total;
+    return total + RANGE_FLAG_BYTES;   // the range flag word sits behind everything else
+}
+
+size_t pafuse_d3dp_range_flag_offset(const pafuse_d3dp_config* cfg, int32_t B, int32_t P) {
+    const size_t total = pafuse_d3dp_workspace_bytes(cfg, B, P);
+    return total ? total - RANGE_FLAG_BYTES : 0;
+}
+
+int pafuse_d3dp_check_range(const pafuse_d3dp_config* cfg, int32_t B, int32_t P, const void* workspace, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!cfg || !workspace || B <= 0 || P <= 0) return fail(PAFUSE_E_ARG, "d3dp_check_range: bad argument");
+    int32_t flag = 0;
+    const char* at = (const char*)workspace + pafuse_d3dp_range_flag_offset(cfg, B, P);
+    hipError_t e = hipMemcpyAsync(&flag, at, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return fail(PAFUSE_E_HIP, "d3dp_check_range: %s", hipGetErrorString(e));
+    if (flag)
+        return fail(PAFUSE_E_RANGE, "a denoiser output was not finite: in 'f16x2' an activation left the fp16 range (|a| >= 65504 makes "
+                                    "its high slice inf); run this model in 'bf16x3' or 'f32' (the predictions of the affected rows are NaN)");
+    return PAFUSE_OK;
 }
 
 // Side streams beside the split-precision kernels need a library WITHOUT packed-fp32 VALU instructions: on MI355X a
@@ -1327,6 +1352,8 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
     PartBuffers pb[PAFUSE_MAX_PARTS];
     for (int i = 0; i < NP; ++i)
         base = carve_part(base, R * F * cfg->part[i].joints, cfg->part[i].channels, B, pb[i], image_elem_bytes(cfg->part[i].operand_bf16));
+    int32_t* const range_flag = reinterpret_cast<int32_t*>((char*)workspace + pafuse_d3dp_range_flag_offset(cfg, B, P));
+    if (hipMemsetAsync(range_flag, 0, sizeof(int32_t), s0) != hipSuccess) return fail(PAFUSE_E_HIP, "d3dp_sample: memset failed");
 
     // Parts are independent inside a step, and so are hypotheses: with aux streams the work of a step is cut into
     // (part, hypothesis-group) lanes, each a chain of small launches on its own stream, so that the ramp-up and
@@ -1402,6 +1429,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
             e.stats = ln_folded(w) ? pb[i].stats + row0 * 2 : nullptr;   // where offset_rows puts this group's statistics
             e.xh = w->operand_bf16 >= 3 ? reinterpret_cast<uint8_t*>(pb[i].xn) : nullptr;   // (indexed by the absolute row)
             e.x_image = w->operand_bf16 == 4;
+            e.centre_x = w->operand_bf16 == 2 && ln_folded(w);
             if (h_residual_only(w)) e.x = nullptr;
             e.B = B, e.P = P, e.F = F, e.J = w->joints, e.J3 = J, e.C = w->channels, e.nflip = nflip;
             e.do_clamp = 1, e.scale = (float)cfg->scale, e.lim = (float)(1.1 * cfg->scale), e.row0 = row0, e.nrows = nrows;
@@ -1431,6 +1459,7 @@ int pafuse_d3dp_sample(const pafuse_d3dp_config* cfg, const pafuse_ddim_step* st
         f.B = B, f.P = P, f.F = F, f.J = J, f.T = nsteps, f.step = k, f.flip = cfg->flip, f.last = st.last;
         f.scale = (float)cfg->scale, f.lim = (float)(1.1 * cfg->scale), f.sr = st.sqrt_recip_acp, f.srm1 = st.sqrt_recipm1_acp, f.c = st.c;
         f.an_f = (float)st.sqrt_alpha_next, f.c_f = (float)st.c, f.sigma_f = (float)st.sigma;
+        f.range_flag = range_flag;
         const int64_t n = (int64_t)B * P * F * J;
         hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s0, f);
         rc = check_launch("finalize_kernel");

@@ -20,7 +20,7 @@
 //     (w0 a2, w2 a0, w1 a1, w0 a1, w1 a0, w0 a0), the next fragments and the refill DMA pieces issued in their shadow; the ring,
 //     its counted vmcnt waits and the one raw s_barrier per chunk are hgemm_tile's.
 // Kernels: xgemm_kernel (one linear layer: plain with bias / folded LayerNorm / GELU, or whole-row with residual + LayerNorms,
-// the epilogue shared with the H pipeline: hgemm.hpp epilogue_rows_h<.., SL = 3>) and xfqa_kernel (qkv projection + attention
+// the epilogue shared with the H pipeline: hgemm.hpp epilogue_rows_h<.., NSLICE = 3>) and xfqa_kernel (qkv projection + attention
 // of whole sequences x 1 - 2 heads; the projection is the same K loop on gathered rows).
 #pragma once
 #include "hgemm.hpp"
@@ -91,6 +91,9 @@ __device__ __forceinline__ void xgemm_mainloop(f32x16 (&acc)[NT], ARow a_row, co
         src[j] = (is_a ? a_row(row) : Wrows + (size_t)row * K * 6) + plane * 64 + sb * 16;
     }
     auto issue_piece = [&](int kc, int st, int j) {
+#if defined(PAFUSE_X_ABL) && (PAFUSE_X_ABL & 1)   // diagnostic builds of tools/xgemm_bench.hip: no operand stream (results wrong by design)
+        return;
+#endif
         int i = wave + j * NW;  // wave-uniform
         i = i < IA + IW ? i : IA + IW - 1;
         // chunk kc of a row: BKC = 32: the 192-byte chunk kc; BKC = 16: the sub-blocks 2 (kc & 1), + 1 of chunk kc >> 1
@@ -119,6 +122,11 @@ __device__ __forceinline__ void xgemm_mainloop(f32x16 (&acc)[NT], ARow a_row, co
         }
 
 #define PAFUSE_PIN_ACC(A) asm volatile("" : "+v"(A))
+#if defined(PAFUSE_X_ABL) && (PAFUSE_X_ABL & 2)   // diagnostic: no MFMAs (the stream, the fragment reads and the barriers alone)
+#define PAFUSE_X_MFMA(W, A, ACC) asm volatile("" : "+v"(ACC) : "v"(W), "v"(A))
+#else
+#define PAFUSE_X_MFMA(W, A, ACC) ACC = mfma_bf16_k16(W, A, ACC)
+#endif
     for (int kc = 0; kc < nk; ++kc) {
         if (kc + NSTAGE - 2 < nk)
             wait_vmcnt<CNT*(NSTAGE - 2)>();   // chunk kc of this wave has landed (the younger chunks may still fly)
@@ -165,7 +173,7 @@ __device__ __forceinline__ void xgemm_mainloop(f32x16 (&acc)[NT], ARow a_row, co
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[s2 & 1][0]), a1 = __builtin_bit_cast(bf16x8, af[s2 & 1][1]),
                          a2 = __builtin_bit_cast(bf16x8, af[s2 & 1][2]);
             PAFUSE_PIN_ACC(acc[nt]);
-            acc[nt] = mfma_bf16_k16(w0, a2, acc[nt]);   // small terms first, the leading product last
+            PAFUSE_X_MFMA(w0, a2, acc[nt]);   // small terms first, the leading product last
             {   // this group's share of the refill DMA, in the shadow of the MFMA just issued
                 constexpr int PER = (CNT + NG - 1) / NG, j0 = g * PER, j1 = (g + 1) * PER < CNT ? (g + 1) * PER : CNT;
                 if constexpr (j0 < j1) {
@@ -178,19 +186,20 @@ __device__ __forceinline__ void xgemm_mainloop(f32x16 (&acc)[NT], ARow a_row, co
                 }
             }
             PAFUSE_PIN_ACC(acc[nt]);
-            acc[nt] = mfma_bf16_k16(w2, a0, acc[nt]);
+            PAFUSE_X_MFMA(w2, a0, acc[nt]);
             PAFUSE_PIN_ACC(acc[nt]);
-            acc[nt] = mfma_bf16_k16(w1, a1, acc[nt]);
+            PAFUSE_X_MFMA(w1, a1, acc[nt]);
             PAFUSE_PIN_ACC(acc[nt]);
-            acc[nt] = mfma_bf16_k16(w0, a1, acc[nt]);
+            PAFUSE_X_MFMA(w0, a1, acc[nt]);
             PAFUSE_PIN_ACC(acc[nt]);
-            acc[nt] = mfma_bf16_k16(w1, a0, acc[nt]);
+            PAFUSE_X_MFMA(w1, a0, acc[nt]);
             PAFUSE_PIN_ACC(acc[nt]);
-            acc[nt] = mfma_bf16_k16(w0, a0, acc[nt]);
+            PAFUSE_X_MFMA(w0, a0, acc[nt]);
         });
         __builtin_amdgcn_s_setprio(0);
     }
 #undef PAFUSE_PIN_ACC
+#undef PAFUSE_X_MFMA
 }
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int BKC, bool HRES = false>
@@ -345,7 +354,7 @@ struct XfqaTile {
     static_assert(BIAS_OFF % 16 == 0, "alignment of the bias vector");
 };
 
-// phase 3 of the fused kernels (the attention from the LDS tiles) lives in hgemm.hpp: fqa_attention_from_lds<LP, DP, SL>
+// phase 3 of the fused kernels (the attention from the LDS tiles) lives in hgemm.hpp: fqa_attention_from_lds<.., NSLICE>
 
 template <int LP, int DP, int HPW>
 __global__ void __launch_bounds__((XfqaTile<LP, DP, HPW>::NTHR), 2) xfqa_kernel(const FqaParams fp) {

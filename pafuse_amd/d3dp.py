@@ -132,16 +132,17 @@ class D3DP(nn.Module):
         # matrix-product mode: 'bf16x3' everywhere - split-precision products whose operands carry all 24 bits of the fp32
         # numbers they stand for (three bf16 slices each, six bf16 MFMA products, fp32 accumulation: fp32-equivalent, as close
         # to an fp64 evaluation as the reference's own fp32 arithmetic - tests/test_hip_parity.py, tests/test_hip_fullsize.py
-        # for the loop, tests/test_hip_train.py for the gradients).  Inference of the part-based model runs them on the image
-        # pipeline (round 5, csrc/xgemm.hpp; widths 224 / 256 / 384); the single-model variant (width 288) and training on the
-        # round-3 kernels (MixSTE2.effective_mode) - training under torch.distributed with more than one rank: 'f32' (see
-        # _training_precision).  'f16x2' (three fp16 MFMA products on 22-23-bit operands: faster, an opt-in since round 5),
-        # 'f32' and 'bf16x3_r3' (the round-3 kernels everywhere) stay selectable
+        # for the loop, tests/test_hip_train.py for the gradients), with the LayerNorms folded into the GEMMs that consume
+        # them and the residual stream stored centred on its row means (round 5).  Opt-in: 'bf16x3_images' (the same products on
+        # the image pipeline of round 5, csrc/xgemm.hpp: qkv + attention in one kernel, every operand pre-split; measured
+        # slower at P = 20), 'f16x2' (three fp16 MFMA products on 22 - 23-bit operands: 1.5 x faster, not
+        # the reference's operand width), 'f32'.  Training under torch.distributed with more than one rank: 'f32' (see
+        # _training_precision)
         for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS["bf16x3"]
         self.allow_split_products_under_ddp = False
 
-    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3_r3": 2, "f16x2": 3, "bf16x3": 4}
+    PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3, "bf16x3_images": 4}
 
     def denoisers(self):
         """{name: MixSTE2} in the order of the library's part table: the per-part models, or {'all': the single model}."""
@@ -152,9 +153,9 @@ class D3DP(nn.Module):
         """Matrix-product mode of the denoisers' linear layers (everything else, and every tensor in memory, is fp32):
         'f32'    fp32-input matrix cores, a k-ordered fp32 FMA chain per output;
         'bf16x3' split precision (the default): fp32 operands as three bf16 slices (exact), six bf16 MFMA products, fp32
-                 accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h); on the image pipeline
-                 (mode 4) where it has kernels, else on the round-3 kernels (mode 2);
-        'bf16x3_r3' the same products on the round-3 kernels everywhere (A/B, tests);
+                 accumulation - fp32-equivalent results at 2.7x the matrix rate (include/pafuse_hip.h, mode 2);
+        'bf16x3_images' the same products on the image pipeline (mode 4: both GEMM operands pre-split, qkv + attention fused in every
+                 block; where it has no kernels - training, the single-model variant - mode 2 runs);
         'f16x2'  opt-in split precision (inference): activations as two fp16 slices (22-23 bits), weights as two stored + one
                  derived slice (power-of-two scaled), THREE fp16 MFMA products, fp32 accumulation - 5.3x the matrix rate;
         'bf16'   opt-in reduced precision: operands rounded to one bf16 (BASELINE configs[1])."""
@@ -168,7 +169,7 @@ class D3DP(nn.Module):
         if value not in self.PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
         if self.is_train and value in ("bf16", "f16x2"):
-            raise ValueError("training runs fp32 ('f32') or split-precision ('bf16x3', 'bf16x3_r3') products")
+            raise ValueError("training runs fp32 ('f32') or split-precision ('bf16x3') products")
         for m in self.denoisers().values():
             m.operand_bf16 = self.PRECISIONS[value]
         self._graphs.clear()
@@ -326,6 +327,7 @@ class D3DP(nn.Module):
             graph, st = g
             st["x2d"].copy_(x2d), st["x2f"].copy_(x2f), st["noise"].copy_(noise)
             graph.replay()
+            self._check_range(lib, cfg, B, P, st["ws"], stream)
             return st["out"].clone()
 
         out = torch.empty(B, len(steps), P, self.frames, self.num_kps, 3, device=dev, dtype=torch.float32)
@@ -334,7 +336,17 @@ class D3DP(nn.Module):
         for t in (ws, noise, x2d, x2f):
             for s in aux:
                 t.record_stream(s)
+        self._check_range(lib, cfg, B, P, ws, stream)
         return out
+
+    def _check_range(self, lib, cfg, B, P, ws, stream):
+        """'f16x2' only: an activation beyond the fp16 range (|a| >= 65504) shows as non-finite predictions; the output stage of
+        every DDIM step flags them in the workspace and this check (the library's one synchronising call) raises instead of
+        returning NaN poses.  The exact-width modes return what the reference returns (NaN in, NaN out) without a check."""
+        if self.precision != "f16x2":
+            return
+        with torch.cuda.device(ws.device):
+            _lib.check(lib.pafuse_d3dp_check_range(C.byref(cfg), B, P, ws.data_ptr(), stream.cuda_stream))
 
     def ddim_sample_flip(self, inputs_2d, inputs_3d, clip_denoised=True, do_postprocess=True, input_2d_flip=None,
                          wb_preds=True):
@@ -357,7 +369,7 @@ class D3DP(nn.Module):
         kernels, which DistributedDataParallel overlaps with the backward on its own stream, are not ours.  Until a
         multi-GPU soak shows bit-equal gradients, a process group of more than one rank trains on the fp32 matrix cores
         ('f32'; set allow_split_products_under_ddp to keep 'bf16x3' at your own risk)."""
-        if self.allow_split_products_under_ddp or self.precision not in ("bf16x3", "bf16x3_r3"):
+        if self.allow_split_products_under_ddp or self.precision not in ("bf16x3_images", "bf16x3"):
             return
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -104,23 +104,20 @@ class MixSTE2(nn.Module):
         self.split_generation = {}     # device index -> how many times the split images were (re)made (graph caches key on it)
         self._param_names = tuple(n for n, _ in self.named_parameters())
         self.drop_fn = None            # tests: callable(block, branch, nseq, rate) -> DropPath factors [nseq] or None
-        self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA,
-        #                                4 split precision "bf16x3" on the image pipeline (inference; where its kernels do not
-        #                                exist - training, the single-model variant - effective_mode() runs mode 2: the same
-        #                                products on the round-3 kernels), 3 split precision "f16x2" (inference only), 1 opt-in
-        #                                bf16 operands
-        self.fold_layernorm = None     # split-precision inference: norm1 / norm2 applied inside the qkv / fc1 GEMMs (None: on in the
-        #                                image pipelines - modes 3 and 4 -, off in mode 2)
-        #                                (pafuse_block_weights.qkv_ls ...: g-scaled weight images + two vectors per layer);
-        #                                False = the whole-row kernels write the normalised rows (same function, one more
-        #                                [M,C] store and normalise pass per whole-row launch).  None = on in 'f16x2', whose GEMMs
-        #                                multiply x - mean(row) (nothing cancels whatever the row means are), off in 'bf16x3',
-        #                                whose three-term form rstd (acc - mean ls) + lt loses accuracy on rows with |mean| >> std
-        #                                (2 x the reference's error at mean / std = 10, tests/test_hip_parity.py) - opt in there
+        self.operand_bf16 = 0          # matrix-product mode of the linear layers (include/pafuse_hip.h): 0 fp32 MFMA, 2 split precision
+        #                                "bf16x3" (the D3DP default), 4 the same products on the image pipeline ('bf16x3_images',
+        #                                inference; where its kernels do not exist - training, the single-model variant -
+        #                                effective_mode() runs mode 2), 3 split precision "f16x2" (inference only), 1 opt-in bf16 operands
+        self.fold_layernorm = None     # split-precision inference: norm1 / norm2 applied inside the qkv / fc1 GEMMs
+        #                                (pafuse_block_weights.qkv_lt ...: g-scaled weight images + a vector per layer) - the producing
+        #                                whole-row kernel stores the residual stream CENTRED on its row means and emits (mean, rstd), the
+        #                                consumer's epilogue is rstd acc + lt: nothing cancels whatever the row means are (round 5 in mode
+        #                                2; the image pipelines since round 4).  None = on; False = the whole-row kernels write the
+        #                                normalised rows (same function, one more [M,C] store and normalise pass per whole-row launch)
         self.fuse_qkv_attention = None   # split-precision inference: qkv projection + attention of a block in ONE kernel where the
         #                                sequence length has a fused form (include/pafuse_hip.h pafuse_block_weights.qkv_hs): q, k, v
-        #                                never reach memory.  None = on in 'f16x2' (that pipeline is bound by the bytes it moves:
-        #                                +7 % on the loop), off in 'bf16x3' (matrix-bound: equal in time)
+        #                                never reach memory.  None = on in 'f16x2' (+7 % on the loop), always on in 'bf16x3_images' (its
+        #                                only form), off in 'bf16x3' (mode 2: equal in time)
         self.fuse_mlp = None           # 'f16x2' with the LayerNorm folded and the residual stream as its image only: fc1 -> GELU -> fc2
         #                                of a block in ONE kernel, the hidden activations [M, 2C] stay in registers (include/pafuse_hip.h
         #                                pafuse_block_weights.fc2_hp).  None = on at the widths where it wins in the loop (224 and 256: the face and
@@ -137,7 +134,7 @@ class MixSTE2(nn.Module):
 
     # ------------------------------------------------------------------------------------------- C structs
     def effective_mode(self, training=False):
-        """The matrix-product mode the library is handed: the requested one, except that 'bf16x3' on the image pipeline (4)
+        """The matrix-product mode the library is handed: the requested one, except that 'bf16x3_images' on the image pipeline (4)
         falls back to the same products on the round-3 kernels (2) where the image pipeline has no kernels - training and
         shapes outside its set (pafuse_mode_supported)."""
         mode = int(self.operand_bf16)
@@ -170,7 +167,7 @@ class MixSTE2(nn.Module):
             self._wcache_by_device[("train", self._freqs.device.index)] = (key, w)
             return w
         split = mode in (2, 3, 4)
-        fold = split and (mode in (3, 4) if self.fold_layernorm is None else bool(self.fold_layernorm))
+        fold = split and (True if self.fold_layernorm is None else bool(self.fold_layernorm))
         if split:           # the split images are values, not views: an in-place update of a weight must remake them
             key += tuple(get(n)._version for n in self._param_names if n.endswith(SPLIT_SUFFIXES))
         # (mode 4 has no unfused attention: qkv + attention is one kernel in every block)
@@ -249,7 +246,7 @@ class MixSTE2(nn.Module):
                                           "mlp_ratio=2, no dropout (common/diffusionpose.py:144-147)")
             if self.operand_bf16 in (1, 3):
                 raise NotImplementedError("rounded-bf16 and f16x2 products are inference options; training runs fp32 ('f32') "
-                                          "or split-precision ('bf16x3': modes 4 / 2, the round-3 kernels) products")
+                                          "or split-precision ('bf16x3') products")
             return self._forward_train(x_2d, x_3d, t)
         B, P, F, J = self._check_inputs(x_2d, x_3d, t, 5)
         x_2d = x_2d.contiguous().float()

@@ -64,13 +64,13 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
     return o
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3_r3": 2, "f16x2": 3, "bf16x3": 4}       # as pafuse_amd.D3DP.PRECISIONS
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3, "bf16x3_images": 4}       # as pafuse_amd.D3DP.PRECISIONS
 
 
 def block_forward(block_params, x, heads=8, precision="f32"):
     """Block.forward (common/mixste.py:113-116) on [S,L,C]; ``block_params`` is a pafuse_amd.mixste2._BlockParams;
     ``precision`` the matrix-product mode of its four linear layers (the split modes make their weight images here;
-    'bf16x3' runs the image pipeline where it has kernels for the shape, else the round-3 kernels)."""
+    'bf16x3_images' runs the image pipeline where it has kernels for the shape, else the round-3 kernels)."""
     lib = _lib.load()
     S, L, Cc = x.shape
     _need(block_params.norm1.weight.numel() == Cc and Cc % heads == 0, f"block: parameters are not for width {Cc}")
@@ -253,13 +253,13 @@ def mlp_fused(xc, rstd, fc1_weight, fc1_bias, fc2_weight, fc2_bias, eps=1e-6, in
     return hjoin_rows(out, M, Cw), stats
 
 
-SCHEME_FLAG = {"bf16x3_r3": 0, "f16x2": 4, "bf16x3": 8}      # include/pafuse_hip.h: PAFUSE_SPLIT_F16X2, PAFUSE_SPLIT_X
+SCHEME_FLAG = {"bf16x3": 0, "f16x2": 4, "bf16x3_images": 8}      # include/pafuse_hip.h: PAFUSE_SPLIT_F16X2, PAFUSE_SPLIT_X
 
 
 def split_weights(weight, layout=0, scheme="bf16x3"):
     """Pre-split image of a [N,K] fp32 weight for the split-precision products (pafuse_split_weights);
-    scheme 'bf16x3' (the X image of the image pipeline: three bf16 slices, one geometry for every layer), 'f16x2' (the H image:
-    two fp16 slices of the power-of-two-scaled weight) or 'bf16x3_r3' (the round-3 kernels' images; layout 0: the
+    scheme 'bf16x3_images' (the X image of the image pipeline: three bf16 slices, one geometry for every layer), 'f16x2' (the H image:
+    two fp16 slices of the power-of-two-scaled weight) or 'bf16x3' (the round-3 kernels' images; layout 0: the
     32x32x16-MFMA plain kernel (mlp.fc1), 2: the 16x16x32-MFMA kernel of the qkv layers)."""
     lib = _lib.load()
     _need(weight.dim() == 2 and weight.shape[1] % 32 == 0, "split_weights: weight must be [N, K] with K % 32 == 0")
@@ -274,7 +274,7 @@ def split_weights(weight, layout=0, scheme="bf16x3"):
 
 
 def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3", out_image=False):
-    """nn.Linear (+ exact GELU) with split-precision products, fp32 accumulation: scheme 'bf16x3' / 'bf16x3_r3' - fp32 operands
+    """nn.Linear (+ exact GELU) with split-precision products, fp32 accumulation: scheme 'bf16x3_images' / 'bf16x3' - fp32 operands
     as three bf16 slices each, six bf16 MFMA products per pair (on the image pipeline: both operands as X images; on the
     round-3 kernels: A split in registers); 'f16x2' - two fp16 slices of the activation, three of the scaled weight, three
     fp16 MFMA products.  ``image`` = split_weights(weight, layout, scheme) to reuse a cached image; ``layout`` picks the
@@ -297,7 +297,7 @@ def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3
                                            oh.data_ptr() if out_image else None, x2.shape[0], N, K,
                                            1 if act == "gelu" else 0, _stream(x)))
         return oh if out_image else out.view(*x.shape[:-1], N)
-    if scheme == "bf16x3":     # both operands as X images (pafuse_linear_x)
+    if scheme == "bf16x3_images":     # both operands as X images (pafuse_linear_x)
         _need(N % 128 == 0 or N % 224 == 0 or N % 96 == 0, "linear_split: the image pipeline serves N that is a multiple of 128, 224 or 96")
         ax = xsplit_rows(x2)
         ox = torch.empty(x2.shape[0] * N * 6, dtype=torch.uint8, device=x.device) if out_image else None

@@ -10,7 +10,7 @@ there is no fallback), with fake-tensor shape functions so the ops trace under `
   pafuse::mixste_eval(x2d, x3d, t, weights, depth, heads, precision)  MixSTE2.forward, eval  common/mixste.py:278-298
   pafuse::ddim_loop(..., precision)                        D3DP.ddim_sample[_flip]        common/diffusionpose.py:227-316
 
-``precision`` ('bf16x3' = the modules' default; 'bf16x3_r3', 'f16x2', 'f32', 'bf16': pafuse_amd.D3DP.precision) is the
+``precision`` ('bf16x3' = the modules' default; 'bf16x3_images', 'f16x2', 'f32', 'bf16': pafuse_amd.D3DP.precision) is the
 matrix-product mode of the linear layers; in the split modes the ops build and cache the pre-split weight images themselves (cached_split_image).
 
 ``weights`` lists are in ``named_parameters()`` order of the corresponding module (= the reference's state-dict
@@ -68,7 +68,7 @@ def _freqs(channels, device):
     return _freq_cache[key]
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3_r3": 2, "f16x2": 3, "bf16x3": 4}     # as pafuse_amd.D3DP.PRECISIONS
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3, "bf16x3_images": 4}     # as pafuse_amd.D3DP.PRECISIONS
 _image_cache = {}        # (data_ptr, _version, device, layout, shape, scheme) of a linear weight -> (its split image, the weight)
 _IMAGE_CACHE_MAX = 2048  # ~ three models' worth of linear weights; the oldest entries go first
 
@@ -157,7 +157,7 @@ def mixste_struct(weights, frames, joints, depth, heads, precision="f32"):
         f16, x = mode == 3, mode == 4
         for n, t in table.items():
             plain = not (x and n.endswith("attn.qkv.weight"))      # mode 4 multiplies the head-major qkv image only
-            if mode >= 3 and n.endswith(tuple(FOLDED_LINEAR)):    # the modules' defaults: LayerNorm folded in the image pipelines only
+            if n.endswith(tuple(FOLDED_LINEAR)):    # the modules' default in every split mode: LayerNorm folded into qkv / fc1
                 images[n], images[n[:-len("weight")] + "ls"], images[n[:-len("weight")] + "lt"] = cached_folded_linear(table, n, f16, x, plain)
                 if not plain:
                     del images[n]

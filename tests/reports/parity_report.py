@@ -53,10 +53,10 @@ def main(argv):
         out_path, argv = argv[1], argv[2:]
     if argv and argv[0] == "--no-fullsize":
         fullsize, argv = False, argv[1:]
-    extra = [(1, 20, 10, "bf16x3"), (1, 20, 10, "f32"), (1, 20, 10, "f16x2"), (1, 5, 5, "bf16")]
+    extra = [(1, 20, 10, "bf16x3_images"), (1, 20, 10, "f32"), (1, 20, 10, "f16x2"), (1, 5, 5, "bf16")]
     for spec in argv:
         f = spec.split(",")
-        extra.append((int(f[2]) if len(f) > 2 else 1, int(f[0]), int(f[1]), f[3] if len(f) > 3 else "bf16x3"))
+        extra.append((int(f[2]) if len(f) > 2 else 1, int(f[0]), int(f[1]), f[3] if len(f) > 3 else "bf16x3_images"))
     try:
         sha = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
@@ -69,7 +69,7 @@ def main(argv):
 
     done = set()
     for (B, P, T) in LOOP_CASES:
-        for prec in ("f32", "bf16x3", "f16x2"):
+        for prec in ("f32", "bf16x3_images", "f16x2"):
             t0 = time.time()
             name, out, ref, target, x2d = loop_case(B, P, T, prec)
             emit(measure(name, out, ref, target, x2d, prec, time.time() - t0))
@@ -89,11 +89,11 @@ def main(argv):
         out, ref = fs["out"][:, :, list(CHECKED)].cpu(), fs["ref"]
         target = orc.center_pose_parts(gu.synthetic_target_3d(1))
         for name, sel in FULLSIZE_SELECTIONS.items():
-            emit(measure(name, out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, fs["x2d"], "bf16x3", time.time() - t0))
+            emit(measure(name, out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, fs["x2d"], "bf16x3_images", time.time() - t0))
         # the metric's own configuration against the REFERENCE's run of it (golden G19): all 20 hypotheses, every step
         z = load_golden("g19_metric_config.npz")
-        for prec in ("bf16x3", "f32", "f16x2"):
-            if prec == "bf16x3":
+        for prec in ("bf16x3_images", "f32", "f16x2"):
+            if prec == "bf16x3_images":
                 out20 = fs["out"][:, :, :20].cpu()
             else:
                 model, _ = make_model(20, T_FULL, seed=51)

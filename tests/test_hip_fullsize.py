@@ -27,12 +27,12 @@ CHECKED = tuple(range(20)) + (83, 159)   # hypotheses the oracle re-computes liv
 #                                          against the reference's own output (golden G19, test_g19_metric_config_vs_reference)
 
 
-def fullsize_case():
+def fullsize_case(precision="bf16x3"):
     """ONE P=160, T=10, B=1 run (configs[3]'s hypothesis count on one GPU) + the oracle on 22 of its hypotheses, all ten
     steps (about a minute of host CPU at 16 threads).  Shared by the tests below and tests/reports/parity_report.py."""
     from __graft_entry__ import make_model
     model, sd = make_model(160, T_FULL, seed=51)
-    model.precision = "bf16x3"        # the committed full-size cases are this scheme's; f16x2 has its own tests below
+    model.precision = precision       # the committed full-size cases are bf16x3's; f16x2 has its own tests below
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=160, n=T_FULL, seed=160)
     model.noise_fn = lambda k, shape, device: noises[k]
@@ -71,7 +71,7 @@ def test_p160_in_eight_p20_shards_equals_single_run(full160):
         m.proposal_shard = None
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
 def test_p20_t10_equals_its_halves_and_the_p160_prefix(full160, precision):
     """configs[2], the metric's own configuration (B=1, P=20, T=10): the run equals the concatenation of its
     proposal_shard halves, and - same noise, same product scheme - the first 20 hypotheses of the P=160 run."""
@@ -109,23 +109,24 @@ def test_full_size_trajectories_vs_oracle(full160):
         _assert_mpjpe_parity(out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, full160["x2d"], case)
 
 
-def test_full_size_f16x2_vs_oracle(full160):
-    """the metric's configuration (P=20, T=10) with the f16x2 products against the oracle on all 20 hypotheses, all ten steps:
-    pointwise 1e-5 and the four MPJPE protocols within the bounds committed for bf16x3 (tests/test_hip_parity.py
-    parity_bounds: an f16x2 case is held to the bf16x3 entry of the same name)."""
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3_images"])
+def test_full_size_opt_in_modes_vs_oracle(full160, precision):
+    """the metric's configuration (P=20, T=10) with the opt-in product modes - f16x2, and bf16x3 on the image pipeline - against
+    the oracle on all 20 hypotheses, all ten steps: pointwise 1e-5 and the four MPJPE protocols within the frozen bounds of the
+    case (tests/parity_bounds.json)."""
     from __graft_entry__ import make_model
     model, _ = make_model(20, T_FULL, seed=51)
-    model.precision = "f16x2"
+    model.precision = precision
     noises = [n[:, :20].contiguous() for n in full160["noises"]]
     model.noise_fn = lambda k, shape, device: noises[k]
     out = model(full160["x2d"].to(DEV), None, input_2d_flip=full160["x2f"].to(DEV)).cpu()
     ref = full160["ref"][:, :, :20].contiguous()
     assert float((out - ref).abs().max()) <= 1e-5
     target = orc.center_pose_parts(gu.synthetic_target_3d(1))
-    _assert_mpjpe_parity(out, ref, target, full160["x2d"], "fullsize_20of20_T10_f16x2")
+    _assert_mpjpe_parity(out, ref, target, full160["x2d"], f"fullsize_20of20_T10_{precision}")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
 def test_metric_config_vs_fp64_truth(full160, precision):
     """hypotheses {0, 7, 19} of the metric's configuration (P=20, T=10) through all ten steps against the
     oracle evaluated in fp64 - per protocol the HIP path is not further from exact arithmetic than the reference's own fp32
@@ -167,7 +168,7 @@ def g19_compare(out20, z, x2d):
     return pt, diffs, d, float(flipped.double().mean()), worst
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "f32", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f32", "f16x2"])
 def test_g19_metric_config_vs_reference(full160, precision):
     """BASELINE configs[2] - the configuration the metric is quoted on (B=1, P=20, T=10, flip-TTA) - against the output
     of the REFERENCE itself on the same weights, inputs and noise (golden G19, made by tests/golden/make_golden.py from
@@ -391,7 +392,7 @@ def test_grouped_launches_equal_part_by_part_launches():
     schedule state) gives the same bits."""
     from __graft_entry__ import make_model
     model, _ = make_model(20, 2, seed=52)
-    model.precision = "bf16x3_r3"       # (the shared grids are the single-stream schedule of the round-3 kernels)
+    model.precision = "bf16x3"       # (the shared grids are the single-stream schedule of the round-3 kernels)
     model.n_aux_streams = 0
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=20, n=2, seed=7)
@@ -402,7 +403,7 @@ def test_grouped_launches_equal_part_by_part_launches():
     assert torch.equal(grouped, part_by_part)
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_r3", "f32", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3_images", "bf16x3", "f32", "f16x2"])
 def test_side_streams_return_the_single_stream_bits(precision):
     """The default schedule runs the three parts on three HIP streams (queues).  In round 2 that was wrong now and then
     in the bf16-MFMA modes; the cause - packed-fp32 VALU instructions beside v_mfma_f32_32x32x16_bf16 waves of another
@@ -431,7 +432,8 @@ def test_side_streams_return_the_single_stream_bits(precision):
 
 def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     """bench.py's N > 1 code path (rank census, hypothesis sharding, the all-gather and its timing, max-over-ranks
-    clock) run as two real ranks under torch.distributed.run - sharing this box's single GPU over gloo, which is a
+    clock) run as two real ranks, started the way the driver starts a scaling run (`python bench.py --gpus 2`: the parent spawns
+    torch.distributed.run before it touches the GPU and relays rank 0's line) - sharing this box's single GPU over gloo, which is a
     rehearsal of the code path, never a performance number (the line says so).  The gathered predictions of the last
     step must EQUAL, bit for bit, what ONE process computes for all P hypotheses from the same seed: every rank draws
     the full-P noise and keeps its slice, the gather puts the slices back in hypothesis order."""
@@ -446,8 +448,8 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     dump = str(tmp_path / "gathered.pt")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+    # the driver's own spelling: `python bench.py --gpus N ...` - bench.py starts its ranks itself (a child torch.distributed.run)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
            "--single-device", "--steps", "1", "--warmup", "1", "--proposals", "2", "--timesteps", "2",
            "--no-cpu-baseline", "--no-roofline", "--dump-output", dump]
     res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)

@@ -127,7 +127,7 @@ def test_linear_exact_integers():
                                    (129, 448, 224), (64, 768, 256), (1, 512, 256), (50, 96, 64), (33, 32, 32)])
 @pytest.mark.parametrize("act", [None, "gelu"])
 @pytest.mark.parametrize("layout", [0, 2])
-@pytest.mark.parametrize("scheme", ["bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("scheme", ["bf16x3", "bf16x3_images", "f16x2"])
 def test_linear_split(M, N, K, act, layout, scheme):
     """split-precision products against fp64: the same bound as the fp32 FMA chain of test_linear, and closer to exact
     arithmetic than that chain on average.  bf16x3: the six kept terms carry every operand bit above 2^-24 relative,
@@ -138,7 +138,7 @@ def test_linear_split(M, N, K, act, layout, scheme):
     from functools import partial
     if scheme == "f16x2" and (layout != 0 or not (N % 128 == 0 or N % 224 == 0)):
         pytest.skip("f16x2: one image geometry, column tiles of 128 or 224")
-    if scheme == "bf16x3" and (layout != 0 or not (N % 128 == 0 or N % 224 == 0 or N % 96 == 0)):
+    if scheme == "bf16x3_images" and (layout != 0 or not (N % 128 == 0 or N % 224 == 0 or N % 96 == 0)):
         pytest.skip("bf16x3 on images: one image geometry, column tiles of 128, 224 or 96")
     ops = type("ops", (), {"linear": staticmethod(ops.linear),
                            "linear_split": staticmethod(partial(ops.linear_split, layout=layout, scheme=scheme))})
@@ -163,7 +163,7 @@ def test_linear_split_exact_integers_and_slices(layout, M, N, K):
     from pafuse_amd import ops
     from functools import partial
     # layout 'x': the same products on the image pipeline (both operands as X images; one geometry, xgemm_kernel)
-    lin = partial(ops.linear_split, layout=0, scheme="bf16x3") if layout == "x" else partial(ops.linear_split, layout=layout, scheme="bf16x3_r3")
+    lin = partial(ops.linear_split, layout=0, scheme="bf16x3_images") if layout == "x" else partial(ops.linear_split, layout=layout, scheme="bf16x3")
     ops = type("ops", (), {"linear_split": staticmethod(lin)})
     g = torch.Generator().manual_seed(5)
     x = torch.randint(-3, 4, (M, K), generator=g).float()
@@ -253,8 +253,8 @@ def test_x_images_are_the_fp32_tensor():
     assert not torch.isfinite(back[0, 3]) and torch.isnan(back[0, 9]) and torch.equal(back[0, :3], bad[0, :3])
     for M, N, Kk, act in ((200, 768, 384, "gelu"), (131, 448, 224, None), (70, 96, 64, None)):
         a, w, b = _seeded((M, Kk), 1), _seeded((N, Kk), 2, Kk ** -0.5), _seeded((N,), 3, 0.1)
-        rows = ops.linear_split(a.to(DEV), w.to(DEV), b.to(DEV), act, scheme="bf16x3")
-        image = ops.linear_split(a.to(DEV), w.to(DEV), b.to(DEV), act, scheme="bf16x3", out_image=True)
+        rows = ops.linear_split(a.to(DEV), w.to(DEV), b.to(DEV), act, scheme="bf16x3_images")
+        image = ops.linear_split(a.to(DEV), w.to(DEV), b.to(DEV), act, scheme="bf16x3_images", out_image=True)
         assert torch.equal(ops.xjoin_rows(image, M, N), rows), (M, N, Kk)
 
 
@@ -315,7 +315,7 @@ def test_g3_time_embed_golden():
         assert torch.allclose(out, z[f"{part}.out"], rtol=0, atol=5e-6), (part, (out - z[f"{part}.out"]).abs().max())
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
 def test_g4_blocks_golden(precision):
     """golden G4 (one real-width block per part, spatial and temporal, outputs of the reference) through pafuse_block_forward in
     both fp32-grade product modes.  (G3, the timestep MLP, has no product mode: time_embed_kernel is fp32 VALU arithmetic.)"""
@@ -355,7 +355,7 @@ def test_g5_part_denoisers_golden(g5):
         assert torch.allclose(out, ref, rtol=0, atol=1e-5), (part, (out - ref).abs().max())
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
 def test_g5_flip_loop_golden(g5, precision):
     """the reference's own output (golden G5: flip loop P=2, T=2), in both fp32-grade product modes"""
     z, model, sd = g5
@@ -371,7 +371,7 @@ def test_g5_flip_loop_golden(g5, precision):
     assert torch.allclose(out, z["flip_out"], rtol=0, atol=1e-5), (out - z["flip_out"]).abs().max()
 
 
-@pytest.mark.parametrize("precision", ["bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
 def test_split_images_follow_in_place_weight_updates(precision):
     """the pre-split weight images are a cache: an in-place change of a weight (optimizer step, load_state_dict) must
     remake them - the split-precision result after the change equals a freshly built model's, bit for bit."""
@@ -391,7 +391,7 @@ def test_split_images_follow_in_place_weight_updates(precision):
     assert torch.equal(after, other(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)))
 
 
-@pytest.mark.parametrize("precision", ["bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
 def test_folded_layernorm_is_the_same_function(precision):
     """Split-precision default: norm1 / norm2 are applied INSIDE the qkv / fc1 GEMMs (weight image of W (.) g, two vectors
     per layer, row statistics from the producing whole-row kernel; include/pafuse_hip.h pafuse_block_weights.qkv_ls).
@@ -429,19 +429,19 @@ def test_folded_layernorm_is_the_same_function(precision):
     assert float((changed - ref2).abs().max()) <= 1e-5, float((changed - ref2).abs().max())
 
 
-@pytest.mark.parametrize("precision", ["bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
 @pytest.mark.parametrize("fold", [True, False])
 def test_fused_qkv_attention_kernel_is_the_same_function(fold, precision):
     """The opt-in fused kernel (fqa_kernel: qkv projection + attention of one head per workgroup, q / k / v never written;
     MixSTE2.fuse_qkv_attention) against the default two kernels, with and without the folded LayerNorm: same products
     (six bf16 MFMA terms per pair), same attention arithmetic - rounding-level differences (the K sum rounds per 32 k in
     both), both within 1e-5 of the oracle.  Body / hands blocks and the temporal face blocks run fused; the spatial face
-    blocks (68 tokens) have a fused form in the image pipelines only ('bf16x3_r3' keeps the two kernels there) - B = 2 and
-    P = 3 give ragged last tiles.  'bf16x3' on the image pipeline has ONLY the fused form (xfqa_kernel): it is held against
-    the two kernels of 'bf16x3_r3' - the same six products per pair."""
+    blocks (68 tokens) have a fused form in the image pipelines only ('bf16x3' keeps the two kernels there) - B = 2 and
+    P = 3 give ragged last tiles.  'bf16x3_images' on the image pipeline has ONLY the fused form (xfqa_kernel): it is held against
+    the two kernels of 'bf16x3' - the same six products per pair."""
     from __graft_entry__ import make_model
     model, sd = make_model(3, 2, seed=57)
-    model.precision = "bf16x3_r3" if precision == "bf16x3" else precision
+    model.precision = "bf16x3" if precision == "bf16x3_images" else precision
     x2d, x2f = gu.synthetic_inputs_2d(B=2)
     noises = gu.synthetic_noises(B=2, P=3, n=2, seed=6)
     model.noise_fn = lambda k, shape, device: noises[k]
@@ -459,7 +459,7 @@ def test_fused_qkv_attention_kernel_is_the_same_function(fold, precision):
     model.precision = precision
     # body (24 joints) and hands (42): all 16 blocks; face: the 8 temporal blocks (27 frames) and - image pipelines only, whose
     # kernels have an 80-token form on five waves - the 8 spatial ones (68 joints: two sequences per 160-row tile)
-    assert {name: count(m) for name, m in model.denoisers().items()} == {"body": 16, "face": 8 if precision == "bf16x3_r3" else 16, "hands": 16}
+    assert {name: count(m) for name, m in model.denoisers().items()} == {"body": 16, "face": 8 if precision == "bf16x3" else 16, "hands": 16}
     fused = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     ref = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
     assert float((fused - two).abs().max()) <= 4e-6, float((fused - two).abs().max())
@@ -632,7 +632,7 @@ LOOP_CASES = [(1, 5, 5), (2, 3, 2)]
 _LOOP_ORACLE = {}
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
 @pytest.mark.parametrize("B,P,T", LOOP_CASES)
 def test_loop_vs_oracle_mpjpe(B, P, T, precision):
     """BASELINE configs[1] shape (P=5, T=5) and a B>1 case: pointwise and MPJPE parity, for the fp32 matrix cores and
@@ -695,7 +695,7 @@ def assert_not_further_from_fp64(case, out, ref32, truth, target, x2d):
                         f"; pointwise mean |d| m: hip {pw_h:.2e} / oracle32 {pw_o:.2e}")
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
 def test_loop_vs_fp64_truth(precision):
     """BASELINE configs[1]'s shape (P=5, T=5, flip-TTA) through all five steps against an fp64 evaluation of the same
     loop: the tolerance that does not depend on which host ran the fp32 reference (profiles/r03_host_variation.json)."""
@@ -704,7 +704,7 @@ def test_loop_vs_fp64_truth(precision):
     assert_not_further_from_fp64(case, out, ref32, loop_truth(B, P, T), target, x2d)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3_r3", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
 def test_accuracy_equivalent_to_reference_fp32(precision):
     """Against an fp64 evaluation of the same function (same fp32 weights and inputs), the HIP denoiser is at most
     1.5x as far as the reference's fp32 CPU arithmetic (the oracle, bit-identical to the reference here) - in both
@@ -724,6 +724,88 @@ def test_accuracy_equivalent_to_reference_fp32(precision):
         e_ref, e_hip = (ref32.double() - truth).abs(), (hip.double() - truth).abs()
         assert e_hip.mean() <= 1.5 * e_ref.mean(), (part, e_hip.mean(), e_ref.mean())
         assert e_hip.max() <= 2.0 * e_ref.max(), (part, e_hip.max(), e_ref.max())
+
+
+def _trained_like(sd, gain=300.0, mean=50.0):
+    """seeded weights pushed towards what trained checkpoints show: one outlier channel per part (the post-norm gains of a
+    channel x 300) and residual rows far from zero mean (post-norm biases + 50: what every block hands to the next)"""
+    sd = {k: v.clone() for k, v in sd.items()}
+    for part in ("body", "face", "hands"):
+        for norm in ("Spatial_norm", "Temporal_norm"):
+            sd[f"pose_estimator.{part}.{norm}.bias"] += mean
+            sd[f"pose_estimator.{part}.{norm}.weight"][7] *= gain
+    return sd
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
+def test_loop_vs_fp64_truth_on_trained_like_weights(precision):
+    """the loop on weights with an outlier channel (x 300) and residual rows at mean 50 - the regime where a
+    LayerNorm folded into its GEMM without centring cancels large numbers and where a 22-bit residual stream would round at the
+    magnitude of the mean.  Every mode stores the stream centred (or, 'f32', normalises before the GEMM): against the fp64
+    evaluation of the same loop the HIP path stays within 1.5 x the reference's own fp32 arithmetic, pointwise and per protocol."""
+    from __graft_entry__ import make_model
+    B, P, T = 1, 2, 2
+    model, sd0 = make_model(P, T, seed=58)
+    sd = _trained_like(sd0)
+    model.load_state_dict(sd)
+    model.precision = precision
+    x2d, x2f = gu.synthetic_inputs_2d(B=B, seed=1234)
+    noises = gu.synthetic_noises(B=B, P=P, n=T, seed=8)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    assert bool(torch.isfinite(out).all())
+    ref32 = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    truth = fp64_truth(sd, x2d, x2f, noises, T)
+    e_hip, e_ref = (out.double() - truth).abs(), (ref32.double() - truth).abs()
+    assert float(e_hip.mean()) <= 1.5 * float(e_ref.mean()), (precision, float(e_hip.mean()), float(e_ref.mean()))
+    assert float(e_hip.max()) <= 3.0 * float(e_ref.max()), (precision, float(e_hip.max()), float(e_ref.max()))
+    target = orc.center_pose_parts(gu.synthetic_target_3d(B))
+    got, o32, t64 = (_mpjpe_report(v, target, x2d) for v in (out, ref32, truth.float()))
+    for k in ("J-Best", "P-Best", "P-Agg"):
+        dh, do = (got[k] - t64[k]).abs(), (o32[k] - t64[k]).abs()
+        assert float(dh.mean()) <= 1.5 * float(do.mean()) + FP64_FLOOR_MM, (precision, k, dh.tolist(), do.tolist())
+
+
+def test_failure_is_loud_through_the_loop():
+    """VERDICT r4 item 2.  (i) 'f16x2': a LayerNorm gain scaled until a row of the residual stream leaves the fp16 range
+    (|a| >= 65504) - the loop must not return a plausible pose: the predictions of the affected rows are NaN, the output stage
+    flags them and D3DP raises (PAFUSE_E_RANGE); the same weights run finite in the exact-width modes and match the oracle.
+    (ii) a NaN stays a NaN: the clamps of the loop are torch.clamp's (common/diffusionpose.py:193,216-217), so with a NaN in
+    one hypothesis' noise and in one clip's 2-D input the 'f32' output has NaNs exactly where the oracle's has and equals it
+    elsewhere (hypotheses and clips are independent)."""
+    from __graft_entry__ import make_model
+    from pafuse_amd._lib import PafuseError
+    B, P, T = 2, 2, 2
+    model, sd0 = make_model(P, T, seed=59)
+    x2d, x2f = gu.synthetic_inputs_2d(B=B, seed=1234)
+    noises = gu.synthetic_noises(B=B, P=P, n=T, seed=9)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    sd = {k: v.clone() for k, v in sd0.items()}
+    sd["pose_estimator.hands.Spatial_norm.weight"] *= 3e5          # rows of the hands' residual stream at |x| ~ 1e5 .. 1e6
+    model.load_state_dict(sd)
+    model.precision = "f16x2"
+    with pytest.raises(PafuseError, match="fp16 range"):
+        model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV))
+    ref = orc.ddim_sample(sd, x2d, noises, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    for precision in ("bf16x3_images", "bf16x3", "f32"):               # no range limit beyond fp32's: finite, and the oracle's numbers
+        model.precision = precision
+        out = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+        assert bool(torch.isfinite(out).all()) and torch.allclose(out, ref, rtol=0, atol=2e-4), (precision, float((out - ref).abs().max()))
+    # (ii) NaN in, NaN out - where and only where the reference has them
+    model.load_state_dict(sd0)
+    bad2d, bad2f = x2d.clone(), x2f.clone()
+    bad2d[1, 5, 7, 0] = float("nan")                                  # clip 1: every hypothesis of it
+    badn = [n.clone() for n in noises]
+    badn[0][0, 1, 3, 9, 2] = float("nan")                             # clip 0, hypothesis 1: only that trajectory
+    model.noise_fn = lambda k, shape, device: badn[k]
+    ref = orc.ddim_sample(sd0, bad2d, badn, T, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=bad2f)
+    assert bool(torch.isfinite(ref[0, :, 0]).all()) and bool(torch.isnan(ref[1]).any()) and bool(torch.isnan(ref[0, :, 1]).any())
+    for precision in ("f32", "bf16x3_images"):
+        model.precision = precision
+        out = model(bad2d.to(DEV), None, input_2d_flip=bad2f.to(DEV)).cpu()
+        assert torch.equal(torch.isnan(out), torch.isnan(ref)), precision
+        ok = ~torch.isnan(ref)
+        assert torch.allclose(out[ok], ref[ok], rtol=0, atol=1e-5), precision
 
 
 def test_noflip_multistep_vs_oracle():
@@ -943,9 +1025,9 @@ def test_torch_custom_ops_equal_the_modules():
     i2d, i2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=3, n=2, seed=12)
     model.noise_fn = lambda k, shape, device: noises[k]
-    assert model.precision == "bf16x3"          # the model-level ops' default precision is the modules' inference default
+    assert model.precision == "bf16x3"                 # the model-level ops' default precision is the modules' inference default
     assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads), body(x2d, x3d, t))
-    for precision in ("f16x2", "bf16x3", "bf16x3_r3", "f32"):   # the split-precision schemes / kernel sets and the fp32 matrix cores
+    for precision in ("f16x2", "bf16x3_images", "bf16x3", "f32"):   # the split-precision schemes / kernel sets and the fp32 matrix cores
         model.precision = precision
         assert torch.equal(ops.mixste_eval(x2d, x3d, t, list(body.parameters()), body.block_depth, body.num_heads, precision),
                            body(x2d, x3d, t)), precision
@@ -1028,17 +1110,17 @@ def test_image_caches_do_not_outlive_their_tensors():
     assert not torch.equal(outs[0][0], outs[1][0])
 
 
-@pytest.mark.parametrize("precision,fold,factor", [("f16x2", None, 1.5), ("bf16x3", None, 1.5), ("bf16x3_r3", None, 2.0), ("bf16x3_r3", True, 3.0)])
+@pytest.mark.parametrize("precision,fold,factor", [("f16x2", None, 1.5), ("bf16x3_images", None, 1.5), ("bf16x3", None, 1.5), ("bf16x3", False, 2.0)])
 def test_folded_layernorm_with_large_row_means(precision, fold, factor):
     """The folded LayerNorm multiplies un-normalised rows: with |mean| >> std (outlier channels of a trained residual
-    stream) a three-term form rstd (acc - mean ls) + lt cancels large numbers.  'f16x2' stores x - mean(row)
-    (the image is centred; the mean itself is dead information to a stack of LayerNorms and is dropped), so nothing
-    cancels, and the fold is its default; 'bf16x3' keeps the three-term form and therefore folds only on request (measured
-    2.1 x the reference's error here: the last case documents it, bounded at 3 x).  Against an fp64 evaluation of one denoiser pass whose post-norm biases (Spatial_norm, Temporal_norm: what every
-    block hands to the next) put every row of the residual stream at mean 10 with std ~ 1: not further from exact
-    arithmetic than 1.5 x the reference's own fp32 arithmetic (whose LayerNorms see the same rows).  'bf16x3' without the
-    fold (its default: fp32 LayerNorm statistics of rows at mean 10, as the reference computes them) measures 1.1 - 1.6 x per
-    part - the face 1.6 x against a host oracle that is itself 8.0e-7 from exact - and is held to 2 x."""
+    stream) a three-term form rstd (acc - mean ls) + lt cancels large numbers (round 3's fold, gone since round 5).
+    Every split mode now stores x - mean(row) (the stream is centred; the mean itself is dead information to a stack of
+    LayerNorms and is dropped), so nothing cancels, and the fold is the default everywhere.  Against an fp64 evaluation of one
+    denoiser pass whose post-norm biases (Spatial_norm, Temporal_norm: what every block hands to the next) put every row of
+    the residual stream at mean 10 with std ~ 1: not further from exact arithmetic than 1.5 x the reference's own fp32
+    arithmetic (whose LayerNorms see the same rows).  'bf16x3' without the fold (fp32 LayerNorm statistics of rows at mean 10,
+    as the reference computes them) measures 1.1 - 1.6 x per part - the face 1.6 x against a host oracle that is itself 8.0e-7
+    from exact - and is held to 2 x."""
     from __graft_entry__ import make_model
     model, sd = make_model(2, 2, seed=95)
     for part in model.pose_estimator:
