@@ -757,7 +757,10 @@ __device__ __forceinline__ void fqa_attention_from_lds(const FqaParams& fp, floa
             for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const float* vrow = Vs + (rb[u] + kt * 16 + 4 * g4 + reg) * LDV + l15;
+                    // (a masked key - beyond the sequence's L tokens - carries weight 0, but its row of the tile belongs to the NEXT
+                    // sequence: 0 x NaN would hand a neighbour's NaN to this sequence, so masked keys read the sequence's own last row)
+                    const int key = kt * 16 + 4 * g4 + reg;
+                    const float* vrow = Vs + (rb[u] + (key < L ? key : L - 1)) * LDV + l15;
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
                         oc[u][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ct * 16], sc[u][kt][reg], oc[u][ct], 0, 0, 0);

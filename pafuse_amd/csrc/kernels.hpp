@@ -1990,7 +1990,8 @@ __global__ void __launch_bounds__(256, 2) fqa_kernel(const FqaParams fp) {
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float* vrow = Vb + (kt * 16 + 4 * g4 + reg) * LDV + l15;
+                const int key = kt * 16 + 4 * g4 + reg;      // (masked keys read the sequence's own last row: see hgemm.hpp)
+                const float* vrow = Vb + (key < L ? key : L - 1) * LDV + l15;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
                     oc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vrow[ct * 16], sc[kt][reg], oc[ct], 0, 0, 0);
