@@ -508,6 +508,7 @@ def train_bench(args, rank, local_rank, world, dev):
     model.n_aux_streams = args.streams
     train_dtype = args.train_dtype     # 'bf16x3' (default): split products in qkv / fc1 / every dX GEMM; 'f32': fp32 MFMA everywhere
     model.precision = train_dtype
+    effective = model.prepare_for_ddp()      # N > 1: 'f32' products beside RCCL's kernels (pafuse_amd.D3DP.prepare_for_ddp); reported below
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
     x2d, _ = gu.synthetic_inputs_2d(B=B, seed=1234 + rank)
     target = gu.synthetic_target_3d(B=B, seed=1235 + rank).to(dev)
@@ -572,7 +573,7 @@ def train_bench(args, rank, local_rank, world, dev):
             "metric": "training clips/sec (H3WB 27x134 clips, fwd+bwd+AdamW)", "value": round(B * world / sec, 3),
             "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": round(sec * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": train_dtype, "data": "synthetic",
+            "dtype": effective, "dtype_requested": train_dtype, "data": "synthetic",
             "config": {"workload": f"D3DP train step, B={B} clips/GPU, per-part MixSTE2 384/224/256 ch depth 8, "
                                    f"DropPath 0.1, AdamW", "B_per_gpu": B,
                        "parallelism": f"DDP x{world} (RCCL all-reduce of 35 M fp32 grads)" if world > 1 else "single GPU",

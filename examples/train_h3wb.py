@@ -61,6 +61,7 @@ def main():
 
     model = pafuse_amd.D3DP(args, joints_left, joints_right, dataset=dataset, is_train=True).to(dev).train()
     log("INFO: Trainable parameter count:", sum(p.numel() for p in model.parameters()) / 1e6, "Million")
+    model.prepare_for_ddp()               # N > 1: 'f32' products beside RCCL's kernels (decided once, here; see D3DP.prepare_for_ddp)
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
     lr = args.model.learning_rate
     optimizer = torch.optim.AdamW(net.parameters(), lr=lr, weight_decay=0.1)

@@ -190,6 +190,9 @@ int pafuse_linear(const float *A, const float *W, const float *bias, float *out,
  * (common/mixste.py:38-42,65,80). */
 #define PAFUSE_LINEAR_QKV_IMAGE 2
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K);
+/* the bytes pafuse_split_weights writes for `layout` (the layout bits + PAFUSE_SPLIT_F16X2 / PAFUSE_SPLIT_X): 6 N K for the
+ * bf16x3 images, 4 N K + 256 for the f16x2 H image; pafuse_split_weights_bytes (6 N K) is large enough for every layout */
+size_t pafuse_split_image_bytes(int64_t N, int64_t K, int32_t layout);
 int pafuse_split_weights(const float *W, int32_t N, int32_t K, int32_t layout, void *out, void *stream);
 int pafuse_linear_split(const float *A, const void *Wsplit, const float *bias, float *out, int64_t M, int32_t N,
                         int32_t K, int32_t act, void *stream);
@@ -232,6 +235,18 @@ int pafuse_linear_x(const void *Ax, const void *Wx, const float *bias, float *ou
 int pafuse_hsplit_rows(const float *X, int64_t R, int32_t K, void *out, void *stream);
 int pafuse_linear_h(const void *Ah, const void *Wh, const float *bias, float *out, void *out_h, int64_t M, int32_t N, int32_t K,
                     int32_t act, void *stream);
+
+/* qkv projection + attention of whole sequences in ONE kernel on operand images - the unit entry of hfqa_kernel (scheme
+ * PAFUSE_SPLIT_F16X2: H images) and xfqa_kernel (PAFUSE_SPLIT_X: X images); common/mixste.py:65-79:
+ *   (q | k | v)[m] = rstd_m * (x[m] W^T) + b   (rstd_m = stats[2 m + 1], stats NULL: 1 - with stats the image is the CENTRED row and
+ *   W is W (.) g, b = W beta + b: the folded LayerNorm);   o[sequence, head] = softmax(q k^T * scale) v
+ * x_img: the image of x [M,C]; qkv_hs / qkv_hb: the head-major weight image [heads * 3 * DP, C] and bias of
+ * pafuse_block_weights.qkv_hs / qkv_hb; o_img: the image of o [M,C] (rows no sequence touches are left alone).  Sequence map as
+ * pafuse_attention; qk_scale 0 = head_dim^-0.5.  Shapes with a fused form only (sequence length <= 80 at head dim <= 32, <= 32
+ * at head dim <= 48; PAFUSE_SPLIT_X at head dim > 32: an even number of heads). */
+int pafuse_qkv_attention_image(int32_t scheme, const void *x_img, const float *stats, const void *qkv_hs, const float *qkv_hb,
+                               void *o_img, int64_t M, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group,
+                               int64_t group_stride, int64_t seq_stride, int64_t tok_stride, float qk_scale, void *stream);
 
 /* The MLP of a block on H images in one kernel (the unit entry of hmlp_kernel; common/mixste.py:37-43,115 with norm2 folded):
  *   y = xc + GELU(rstd * (xc W1^T) + bias1) W2^T + bias2,   xc = the rows of `xh` (the CENTRED image of the residual stream),

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pafuse_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "pafuse_split_weights_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "pafuse_split_image_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
     "pafuse_split_weights": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pafuse_linear_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_void_p]),
@@ -70,6 +71,8 @@ SIGNATURES = {
                                   C.c_int32, C.c_void_p]),
     "pafuse_linear_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "pafuse_qkv_attention_image": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                             C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.c_void_p]),
     "pafuse_mlp_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "pafuse_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_float,

@@ -1026,6 +1026,10 @@ int pafuse_linear(const float* A, const float* W, const float* bias, float* out,
 }
 
 size_t pafuse_split_weights_bytes(int64_t N, int64_t K) { return (N > 0 && K > 0) ? wsplit_bytes(N, K) : 0; }
+size_t pafuse_split_image_bytes(int64_t N, int64_t K, int32_t layout) {
+    if (N <= 0 || K <= 0) return 0;
+    return (layout & PAFUSE_SPLIT_F16X2) && !(layout & PAFUSE_SPLIT_X) ? hsplit_bytes(N, K) : wsplit_bytes(N, K);
+}
 
 int pafuse_mode_supported(int32_t mode, int32_t C, int32_t hidden, int32_t heads, int32_t joints, int32_t frames) {
     if (mode < 0 || mode > 4 || heads <= 0 || C <= 0 || C % heads) return 0;
@@ -1140,6 +1144,29 @@ int pafuse_linear_h(const void* Ah, const void* Wh, const float* bias, float* ou
     g.Ah = (const uint8_t*)Ah, g.Wh = (const uint8_t*)Wh, g.bias = bias, g.out = out, g.out_h = (uint8_t*)out_h;
     g.M = M, g.N = N, g.K = K, g.act = act & 1, g.bf16 = 3;
     return gemm_bias(g, (hipStream_t)stream);
+}
+
+int pafuse_qkv_attention_image(int32_t scheme, const void* x_img, const float* stats, const void* qkv_hs, const float* qkv_hb, void* o_img,
+                               int64_t M, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group, int64_t group_stride,
+                               int64_t seq_stride, int64_t tok_stride, float qk_scale, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!x_img || !qkv_hs || !qkv_hb || !o_img || M < 0 || nseq < 0 || group <= 0) return fail(PAFUSE_E_ARG, "qkv_attention_image: bad argument");
+    if (scheme != PAFUSE_SPLIT_F16X2 && scheme != PAFUSE_SPLIT_X) return fail(PAFUSE_E_ARG, "qkv_attention_image: scheme must be PAFUSE_SPLIT_F16X2 or PAFUSE_SPLIT_X");
+    if (heads <= 0 || C <= 0 || C % heads || C % 32) return fail(PAFUSE_E_SHAPE, "qkv_attention_image: C=%d, heads=%d", C, heads);
+    const int mode = scheme == PAFUSE_SPLIT_X ? 4 : 3, d = C / heads;
+    if (L <= 0 || !(mode == 4 ? xfqa_has(L, d, heads) : fqa_has(L, d, 3)))
+        return fail(PAFUSE_E_SHAPE, "qkv_attention_image: no fused form for sequences of %d tokens at head dim %d", L, d);
+    if (nseq == 0) return PAFUSE_OK;
+    const int lp = fqa_lp(L, mode), dp = fqa_dp(d);
+    FqaParams f{};
+    f.g.Ah = (const uint8_t*)x_img, f.g.Wh = (const uint8_t*)qkv_hs, f.g.bias = qkv_hb, f.g.ln_in = stats;
+    f.g.M = M, f.g.N = heads * 3 * dp, f.g.K = C, f.g.bf16 = mode;
+    f.o = (float*)o_img, f.nseq = nseq, f.L = L, f.C = C, f.heads = heads, f.d = d;
+    f.nseq_tile = fqa_nseq_tile(L, lp);
+    if (f.nseq_tile * L > fqa_tile_rows(lp)) return fail(PAFUSE_E_SHAPE, "qkv_attention_image: %d sequences of %d tokens do not fit a tile", f.nseq_tile, L);
+    f.group = group, f.group_stride = group_stride, f.seq_stride = seq_stride, f.tok_stride = tok_stride;
+    f.scale = qk_scale != 0.f ? qk_scale : 1.0f / sqrtf((float)d);
+    return fused_qkv_attention(f, (hipStream_t)stream);
 }
 
 int pafuse_mlp_h(const void* xh, const float* stats_in, const void* W1h, const float* bias1, const void* W2hp, const float* bias2,

@@ -320,7 +320,11 @@ class D3DP(nn.Module):
                 cap = torch.cuda.Stream(device=dev)
                 cap.wait_stream(stream)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=cap):
+                # the side streams are shared by every D3DP instance of the process (_SHARED_AUX): the fork events of the capture pull
+                # them into it, so no other instance may enqueue on them meanwhile - captures are serialised behind the lock that
+                # guards the stream set, and use_graph must not be combined with instances that run CONCURRENTLY (other threads)
+                # on the same device while a capture is being made (their eager launches would be recorded into this graph)
+                with _SHARED_AUX_LOCK, torch.cuda.graph(graph, stream=cap):
                     launch(st["x2d"], st["x2f"], st["noise"], st["out"], st["ws"], torch.cuda.current_stream(dev))
                 stream.wait_stream(cap)
                 g = self._graphs[key] = (graph, st)
@@ -362,21 +366,33 @@ class D3DP(nn.Module):
         return self.pred_parts(input_2d, x_poses, t.squeeze(-1))
 
     # ------------------------------------------------------------------------------------------------ training
+    def prepare_for_ddp(self):
+        """Call ONCE, on every rank, before wrapping a training model in DistributedDataParallel (or stepping it beside any other
+        collective): a step in 'bf16x3' issues v_mfma_f32_32x32x16_bf16 (whole-row forward tiles, dX, dW), the instruction beside
+        which a packed-fp32 VALU instruction of ANOTHER queue's kernel returns wrong lanes on MI355X
+        (profiles/r03_bf16_mfma_concurrency.md).  This library is compiled without such instructions; RCCL's reduction kernels,
+        which DDP overlaps with the backward on its own stream, are not ours.  Until a multi-GPU soak shows bit-equal gradients a
+        process group of more than one rank trains on the fp32 matrix cores: this method switches the model to 'f32' (unless
+        allow_split_products_under_ddp is set) and returns the precision in effect.  The decision is made here, explicitly and
+        once - forward() never changes the configuration; it refuses to run a split-precision step under a multi-rank process
+        group that was not prepared."""
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi and self.is_train and not self.allow_split_products_under_ddp and self.precision in ("bf16x3_images", "bf16x3"):
+            self.precision = "f32"
+        self._ddp_prepared = True
+        return self.precision
+
     def _training_precision(self):
-        """Training beside a collective: a step in 'bf16x3' issues v_mfma_f32_32x32x16_bf16 (whole-row forward tiles, dX, dW),
-        the instruction beside which a packed-fp32 VALU instruction of ANOTHER queue's kernel returns wrong lanes on MI355X
-        (profiles/r03_bf16_mfma_concurrency.md).  This library is compiled without such instructions; RCCL's reduction
-        kernels, which DistributedDataParallel overlaps with the backward on its own stream, are not ours.  Until a
-        multi-GPU soak shows bit-equal gradients, a process group of more than one rank trains on the fp32 matrix cores
-        ('f32'; set allow_split_products_under_ddp to keep 'bf16x3' at your own risk)."""
-        if self.allow_split_products_under_ddp or self.precision not in ("bf16x3_images", "bf16x3"):
+        """forward()'s guard (it changes nothing): see prepare_for_ddp."""
+        if self.allow_split_products_under_ddp or getattr(self, "_ddp_prepared", False) or self.precision not in ("bf16x3_images", "bf16x3"):
             return
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            import warnings
-            warnings.warn("pafuse_amd.D3DP: training under torch.distributed with world size > 1 runs 'f32' products (the "
-                          "bf16 matrix instruction of 'bf16x3' is not proven safe beside RCCL's kernels on MI355X)")
-            self.precision = "f32"
+            raise _lib.PafuseError("pafuse_amd.D3DP: training under torch.distributed with world size > 1: call model.prepare_for_ddp() on "
+                                   "every rank before the first step (it moves the model to 'f32' products: the bf16 matrix instruction "
+                                   "of 'bf16x3' is not proven safe beside RCCL's kernels on MI355X), or set "
+                                   "allow_split_products_under_ddp = True to keep 'bf16x3' at your own risk")
 
     def prepare_targets(self, targets):
         """common/diffusionpose.py:358-388: per sample one timestep and one noise draw (in that order, on the

@@ -429,10 +429,10 @@ def split_image(weight, layout, f16=False, x=False):
     weight, 4 bytes per element + a 256-byte tail); `x`: the X image of mode 4 (three bf16 slices, [N][K/32][3][32])."""
     lib = _lib.load()
     N, K = weight.shape
-    img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    flags = int(layout) | (SPLIT_F16X2 if f16 else 0) | (SPLIT_X if x else 0)
+    img = torch.empty(lib.pafuse_split_image_bytes(N, K, flags), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
-        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K,
-                                            int(layout) | (SPLIT_F16X2 if f16 else 0) | (SPLIT_X if x else 0), img.data_ptr(),
+        _lib.check(lib.pafuse_split_weights(_ptr(weight.detach(), "weight"), N, K, flags, img.data_ptr(),
                                             torch.cuda.current_stream(weight.device).cuda_stream))
     return img
 

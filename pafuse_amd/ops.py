@@ -230,6 +230,37 @@ def hjoin_rows(image, R, K):
     return (v[:, :, 0] + v[:, :, 1] * 2.0 ** -11).reshape(R, K)
 
 
+def qkv_attention_fused(x, qkv_weight, qkv_bias, heads, nseq, L, scheme="bf16x3_images", rstd=None, group=1, group_stride=None,
+                        seq_stride=0, tok_stride=1):
+    """The fused qkv + attention kernel on its own (pafuse_qkv_attention_image): x [M,C] fp32 (with `rstd` [M]: the centred rows of
+    a folded LayerNorm) -> o [M,C] fp32 decoded from the image the kernel writes; q | k | v = rstd (x W^T) + b per head, then
+    softmax(q k^T d^-1/2) v per (sequence, head).  scheme 'f16x2' (hfqa_kernel, H images) or 'bf16x3_images' (xfqa_kernel, X
+    images).  Sequence map as `attention`."""
+    from .mixste2 import head_major_qkv
+    lib = _lib.load()
+    M, Cw = x.shape
+    _need(scheme in ("f16x2", "bf16x3_images"), "qkv_attention_fused: scheme 'f16x2' or 'bf16x3_images'")
+    _need(tuple(qkv_weight.shape) == (3 * Cw, Cw) and qkv_bias.numel() == 3 * Cw and Cw % heads == 0, "qkv_attention_fused: qkv must be [3C, C] + [3C]")
+    gs = L if group_stride is None else group_stride
+    if nseq:   # the last row any sequence touches must exist
+        last = ((nseq - 1) // group) * gs + ((nseq - 1) % group) * seq_stride + (L - 1) * tok_stride
+        _need(0 <= last < M and min(gs, seq_stride, tok_stride) >= 0, f"qkv_attention_fused: sequences reach row {last} of {M}")
+    f16 = scheme == "f16x2"
+    table = {"b.0.attn.qkv.weight": qkv_weight.contiguous(), "b.0.attn.qkv.bias": qkv_bias.contiguous()}
+    hs, hb, _ = head_major_qkv(table.__getitem__, "b.0.attn.qkv.weight", heads, False, f16, not f16)
+    xi = hsplit_rows(x.contiguous()) if f16 else xsplit_rows(x.contiguous())
+    stats = None
+    if rstd is not None:
+        stats = torch.stack([torch.zeros_like(rstd), rstd], dim=1).contiguous()
+    eb = 4 if f16 else 6
+    oi = torch.zeros(M * Cw * eb, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_qkv_attention_image(4 if f16 else 8, xi.data_ptr(), stats.data_ptr() if stats is not None else None,
+                                                  hs.data_ptr(), _ptr(hb, "qkv_hb"), oi.data_ptr(), M, nseq, L, Cw, heads, group, gs,
+                                                  seq_stride, tok_stride, 0.0, _stream(x)))
+    return hjoin_rows(oi, M, Cw) if f16 else xjoin_rows(oi, M, Cw)
+
+
 def mlp_fused(xc, rstd, fc1_weight, fc1_bias, fc2_weight, fc2_bias, eps=1e-6, in_place=False):
     """The fused MLP kernel on its own (pafuse_mlp_h): xc [M,C] = rows of the residual stream centred on their means, rstd [M] or
     None -> (y - mean(y) as fp32 [M,C] decoded from the H image the kernel writes, stats [M,2] = (mean(y), rstd(y))) with
@@ -266,7 +297,7 @@ def split_weights(weight, layout=0, scheme="bf16x3"):
     _need(layout in (0, 2), "split_weights: layout 0 (fc1 kernel) or 2 (qkv kernel)")
     _need(scheme in SCHEME_FLAG, f"split_weights: scheme must be one of {sorted(SCHEME_FLAG)}")
     N, K = weight.shape
-    img = torch.empty(lib.pafuse_split_weights_bytes(N, K), dtype=torch.uint8, device=weight.device)
+    img = torch.empty(lib.pafuse_split_image_bytes(N, K, layout | SCHEME_FLAG[scheme]), dtype=torch.uint8, device=weight.device)
     with torch.cuda.device(weight.device):
         _lib.check(lib.pafuse_split_weights(_ptr(weight, "weight"), N, K, layout | SCHEME_FLAG[scheme], img.data_ptr(),
                                             _stream(weight)))
@@ -285,7 +316,7 @@ def linear_split(x, weight, bias, act=None, image=None, layout=0, scheme="bf16x3
     N = weight.shape[0]
     _need(tuple(weight.shape) == (N, K) and bias.numel() == N, f"linear: x [..,{K}] needs weight [N,{K}] and bias [N]")
     img = split_weights(weight, layout, scheme) if image is None else image
-    _need(img.numel() == lib.pafuse_split_weights_bytes(N, K), "linear_split: image size does not match the weight")
+    _need(img.numel() == lib.pafuse_split_image_bytes(N, K, layout | SCHEME_FLAG[scheme]), "linear_split: image size does not match the weight")
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
     if scheme == "f16x2":      # both operands as H images (pafuse_linear_h)

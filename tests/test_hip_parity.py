@@ -467,6 +467,68 @@ def test_fused_qkv_attention_kernel_is_the_same_function(fold, precision):
     assert float((fused - ref).abs().mean()) <= 1.25 * float((two - ref).abs().mean()) + 1e-8
 
 
+def _qkv_attention_fp64(x, w, b, heads, seqs, rstd=None):
+    """fp64 evaluation of what the fused kernel computes: seqs [nseq, L] = row indices of every sequence"""
+    C_ = x.shape[1]
+    d = C_ // heads
+    y = x.double() @ w.double().t()
+    if rstd is not None:
+        y = y * rstd.double()[:, None]
+    qkv = y + b.double()
+    o = torch.zeros(x.shape[0], C_, dtype=torch.float64)
+    q, k, v = (qkv[seqs][..., i * C_:(i + 1) * C_].reshape(seqs.shape[0], seqs.shape[1], heads, d).transpose(1, 2) for i in range(3))
+    att = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1) @ v                   # [nseq, heads, L, d]
+    o[seqs.reshape(-1)] = att.transpose(1, 2).reshape(-1, C_)
+    return o
+
+
+FQA_FORMS = [   # (name, L, C, temporal joints J or 0): every instantiation of hfqa_kernel / xfqa_kernel the loop launches
+    ("body spatial <32,48>", 24, 384, 0), ("body temporal <32,48>", 27, 384, 24), ("face spatial <80,32>", 68, 224, 0),
+    ("face temporal <32,32>", 27, 224, 68), ("hands spatial <48,32>", 42, 256, 0), ("hands temporal <32,32>", 27, 256, 42)]
+
+
+@pytest.mark.parametrize("scheme", ["f16x2", "bf16x3_images"])
+@pytest.mark.parametrize("form", FQA_FORMS, ids=[f[0] for f in FQA_FORMS])
+def test_fused_qkv_attention_kernel_against_fp64(form, scheme):
+    """hfqa_kernel ('f16x2') and xfqa_kernel ('bf16x3_images') on their own (pafuse_qkv_attention_image)
+    against an fp64 evaluation - every form the loop launches (32-token tiles at head dim 48 and 32, the 48-token form, the
+    80-token five-wave form; spatial and temporal addressing), sequence counts that end in ragged tiles, with and without the
+    folded LayerNorm's row factor.  And exact data: q = k = 0 (uniform attention) with a selector v - the output is the
+    sequence mean of one input channel per output channel, so a slip in the token gather, the head-major row order, the q | k | v
+    tile layout or the image store shows as an O(1) error."""
+    from pafuse_amd import ops
+    name, L, C_, J = form
+    heads, g = 8, torch.Generator().manual_seed(17 + L + C_)
+    R = 3                                              # hypotheses-like outer rows: 3 x 27 frames x J (temporal) / 7 sequences + 2 (spatial)
+    if J:
+        M, nseq = R * 27 * J, R * J
+        seqs = (torch.arange(R)[:, None, None] * 27 * J + torch.arange(J)[None, :, None] + torch.arange(27)[None, None, :] * J).reshape(nseq, 27)
+        kw = dict(group=J, group_stride=27 * J, seq_stride=1, tok_stride=J)
+    else:
+        nseq = 23                                      # never a multiple of the sequences per tile (5, 1 or 2, 3)
+        M = nseq * L
+        seqs = torch.arange(M).reshape(nseq, L)
+        kw = {}
+    x = torch.randn(M, C_, generator=g)
+    w = torch.randn(3 * C_, C_, generator=g) * C_ ** -0.5
+    b = torch.randn(3 * C_, generator=g) * 0.1
+    for rstd in (None, 0.5 + torch.rand(M, generator=g)):
+        truth = _qkv_attention_fp64(x, w, b, heads, seqs, rstd)
+        out = ops.qkv_attention_fused(x.to(DEV), w.to(DEV), b.to(DEV), heads, nseq, L, scheme,
+                                      rstd=None if rstd is None else rstd.to(DEV), **kw).cpu().double()
+        err = (out - truth).abs()
+        # (logits reach |s| ~ 10 with the row factor: the largest errors are single sharp softmax rows; the mean is the yardstick)
+        assert float(err.max()) <= 1.5e-5 and float(err.mean()) <= 4e-7, (name, scheme, rstd is not None, float(err.max()), float(err.mean()))
+    xi = torch.randint(-8, 9, (M, C_), generator=g).float()
+    sel = torch.randint(0, C_, (C_,), generator=g)
+    wi = torch.zeros(3 * C_, C_)
+    wi[2 * C_ + torch.arange(C_), sel] = 1.0           # v[:, c] = x[:, sel[c]]; q = k = 0: softmax = 1 / L everywhere
+    out = ops.qkv_attention_fused(xi.to(DEV), wi.to(DEV), torch.zeros(3 * C_, device=DEV), heads, nseq, L, scheme, **kw).cpu().double()
+    want = torch.zeros(M, C_, dtype=torch.float64)
+    want[seqs.reshape(-1)] = xi.double()[seqs][:, :, sel].mean(1, keepdim=True).expand(-1, L, -1).reshape(-1, C_)
+    assert float((out - want).abs().max()) <= 4e-6, (name, scheme, float((out - want).abs().max()))
+
+
 @pytest.mark.parametrize("C_", [224, 256, 384])
 def test_fused_mlp_kernel_against_fp64(C_):
     """hmlp_kernel on its own (pafuse_mlp_h): y = xc + GELU(rstd (xc W1^T) + b1) W2^T + b2 with the hidden activations in
@@ -532,6 +594,28 @@ def test_fused_mlp_kernel_is_the_same_function():
     for m in parts.values():      # with the fp32 residual rows kept, or without the fold, the block runs the two launches
         m.fuse_mlp, m.keep_f32_residual = True, True
     assert not any(bool(m.weights_struct().ste[0].fc2_hp) for m in parts.values())
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3_images"])
+def test_f32_residual_rows_option_is_the_same_function(precision):
+    """MixSTE2.keep_f32_residual (a public attribute, a C-ABI field, bench.py --f32-residual) - the image pipelines
+    with the fp32 rows of the residual stream kept beside its image (the whole-row kernels then read fp32 residuals and write
+    both forms; the fused MLP is off) against their default, the image-only stream: the same function, rounding-level
+    differences, both within 1e-5 of the oracle."""
+    from __graft_entry__ import make_model
+    model, sd = make_model(3, 2, seed=57)
+    model.precision = precision
+    x2d, x2f = gu.synthetic_inputs_2d(B=2)
+    noises = gu.synthetic_noises(B=2, P=3, n=2, seed=6)
+    model.noise_fn = lambda k, shape, device: noises[k]
+    default = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    for m in model.denoisers().values():
+        m.keep_f32_residual = True
+    kept = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
+    ref = orc.ddim_sample(sd, x2d, noises, 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    assert not torch.equal(kept, default)
+    assert float((kept - default).abs().max()) <= 4e-6, float((kept - default).abs().max())
+    assert float((kept - ref).abs().max()) <= 1e-5 and float((default - ref).abs().max()) <= 1e-5
 
 
 def test_g5_p1t1_both_samplers_golden(g5):
