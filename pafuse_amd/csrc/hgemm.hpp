@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) hsplit_weights_kernel(const float* W, uin
 // the slab a wave instruction moves 1 KiB in 8 lines (4 rows x 256 B).
 // LDS (the dead ring): [7 BM WN floats: cross-wave partial sums][5 BN floats: per-column vectors][NW slabs of 32 x (32 NTH + 4)].
 // NSLICE = 3: the X pipeline (xgemm.hpp) - images are X images (three bf16 slices, 6 bytes per element, exact), ws = 1
-template <int WN, int NT, int BM, int NW, int NTH, bool HRES, int NSLICE = 2>   // HRES: the residual is the centred image of x (p.resid_h)
+template <int WN, int NT, int BM, int NW, int NTH, bool HRES, int NSLICE>   // HRES: the residual is the centred image of x (p.resid_h); NSLICE defaults to 2 (kernels.hpp)
 __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0, const int wm,
                                                 const int wn, const int r, const int h, const int wave, const int lane, float* smem,
                                                 const float ws) {
@@ -239,17 +239,17 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                     const f32x4 lo4 = *reinterpret_cast<const f32x4*>(slab + row * ST + 8 * sb);
                     const f32x4 hi4 = *reinterpret_cast<const f32x4*>(slab + row * ST + 8 * sb + 4);
                     const size_t at = (size_t)(mw + row) * p.N + ncol0 + 8 * sb;
+                    f32x4 c0 = lo4, c1 = hi4;
+                    if (centred) {   // the stream is stored centred on the row mean, in whichever form it is kept (fp32 rows, image, both)
+                        const float mu = rowmean[row];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) c0[e] -= mu, c1[e] -= mu;
+                    }
                     if (dst32) {
-                        *reinterpret_cast<f32x4*>(dst32 + at) = lo4;
-                        *reinterpret_cast<f32x4*>(dst32 + at + 4) = hi4;
+                        *reinterpret_cast<f32x4*>(dst32 + at) = c0;
+                        *reinterpret_cast<f32x4*>(dst32 + at + 4) = c1;
                     }
                     if (dsth) {
-                        f32x4 c0 = lo4, c1 = hi4;
-                        if (centred) {
-                            const float mu = rowmean[row];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) c0[e] -= mu, c1[e] -= mu;
-                        }
                         if constexpr (NSLICE == 3) {
                             xsplit_store8(dsth + (size_t)(mw + row) * p.N * 6, ncol0 + 8 * sb, c0, c1);
                         } else {

@@ -1131,13 +1131,23 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// the whole-row epilogue through per-wave LDS slabs (defined in hgemm.hpp, round 4: every global access of a tensor row covers
+// whole row segments; a direct access of row-per-lane accumulators touches 32 rows per instruction) - since round 5 also the
+// inference epilogue of the LDS-DMA whole-row tiles below (same arithmetic in the same order as epilogue_row_per_lane)
+template <int WN, int NT, int BM, int NW, int NTH, bool HRES, int NSLICE = 2>
+__device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmParams& p, const int64_t m0, const int n0, const int wm,
+                                                const int wn, const int r, const int h, const int wave, const int lane, float* smem,
+                                                const float ws);
+
 // ABL (diagnostic builds of tools/gemm_bench.hip only; results wrong by design): 1 = no fragment reads / split / MFMAs
 // (the operand stream alone), 2 = no DMA (the compute side alone, on whatever the LDS holds), 3 = 2 without the split
 // arithmetic (raw fragment bits as slices: LDS reads + MFMAs only), 4 = 3 without the epilogue.
 // One tile of the kernel as a device function: `b` of `nb` is the workgroup's index in its launch (or in its slot of a
 // grouped launch, see grouped_rowln_kernel); nb may exceed the tile count (slots are padded to multiples of 8 so that
 // b & 7 stays the XCD of the workgroup): surplus workgroups return at once.
-template <int WM, int WN, int NT, int EPI, int NSTAGE, int ABL = 0, int BKC = 32>
+// SLAB: the inference whole-row epilogue through per-wave LDS slabs (the per-part launches); false = the direct row-per-lane form (the
+// grouped grids, whose one kernel holds three tile shapes: with the slab form in all three it spilled 1 320 bytes per lane) - same bits
+template <int WM, int WN, int NT, int EPI, int NSTAGE, int ABL = 0, int BKC = 32, bool SLAB = true>
 __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, const int nb, float* smem) {
     using T = DmaTile<WM, WN, NT, BKC>;
     constexpr int NW = T::NW, BM = T::BM, BN = T::BN, CNT = T::CNT, IA = T::IA, IW = T::IW;
@@ -1515,7 +1525,15 @@ __device__ __forceinline__ void gemm_dma_tile(const GemmParams& p, const int b, 
         if (sacc == 123.456f) p.out[0] = sacc;  // keeps the accumulators alive, stores nothing
         return;
     }
-    epilogue_row_per_lane<WN, NT, BM, EPI, VEC>(acc, p, m0, n0, wm, wn, r, h, smem);
+    if constexpr (EPI == EPI_ROWLN && SLAB) {   // inference: rows in and out through per-wave slabs (fp32 residual, fp32 x, (mean, rstd))
+        constexpr size_t RINGF = (size_t)NSTAGE * T::STAGE_BYTES / sizeof(float);
+        constexpr auto need = [](int nth) { return (size_t)VEC + 5 * BN + (size_t)NW * 32 * (32 * nth + 4); };
+        constexpr int NTH = (NT % 2 == 0 && need(2) <= RINGF) ? 2 : 1;
+        static_assert(need(NTH) <= RINGF, "epilogue scratch must fit the ring");
+        epilogue_rows_h<WN, NT, BM, NW, NTH, false, 2>(acc, p, m0, n0, wm, wn, r, h, wave, lane, smem, 1.0f);
+    } else {
+        epilogue_row_per_lane<WN, NT, BM, EPI, VEC>(acc, p, m0, n0, wm, wn, r, h, smem);
+    }
 }
 
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int MINW, int ABL = 0, int BKC = 32>
@@ -1555,9 +1573,9 @@ __global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemm
     const GemmParams& p = g.p[s];
     const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
     switch (p.N) {  // workgroup-uniform
-        case 384: gemm_dma_tile<2, 2, 6, EPI, 2, 0, 16>(p, lb, nb, smem); break;
-        case 256: gemm_dma_tile<2, 2, 4, EPI, 2, 0, 16>(p, lb, nb, smem); break;
-        case 224: gemm_dma_tile<4, 1, 7, EPI, 2, 0, 16>(p, lb, nb, smem); break;
+        case 384: gemm_dma_tile<2, 2, 6, EPI, 2, 0, 16, false>(p, lb, nb, smem); break;
+        case 256: gemm_dma_tile<2, 2, 4, EPI, 2, 0, 16, false>(p, lb, nb, smem); break;
+        case 224: gemm_dma_tile<4, 1, 7, EPI, 2, 0, 16, false>(p, lb, nb, smem); break;
         default: break;
     }
 }
