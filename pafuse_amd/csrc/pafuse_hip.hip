@@ -452,9 +452,11 @@ int gemm_rowln_as(const GemmParams& p0, hipStream_t s) {
                 // chunks, four waves, a two-stage ring and TWO workgroups per CU - the LayerNorm epilogue of one tile
                 // (a third of a tile's time when nothing overlaps it) runs under the K loop of the other.  The same
                 // variants serve the grouped launches below, so both routes give bit-identical rows.
+                // (round 5, with the slab epilogue: 128-row eight-wave tiles - half the weight re-reads - measured again: proj 62 vs 58 us,
+                // fc2 104 vs 98: the two-workgroup tiles stay)
                 case 384: return launch_gemm_dma<2, 2, 6, EPI, 2, 2, 16>(p, s);
-                case 288: return launch_gemm_dma<2, 3, 3, EPI, 2, 2, 16>(p, s);  // the single-model variant (cs = 288)
                 case 256: return launch_gemm_dma<2, 2, 4, EPI, 2, 2, 16>(p, s);
+                case 288: return launch_gemm_dma<2, 3, 3, EPI, 2, 2, 16>(p, s);  // the single-model variant (cs = 288)
                 case 224:
                     return p.M >= 4096 ? launch_gemm_dma<4, 1, 7, EPI, 2, 2, 16>(p, s) : launch_gemm_dma<2, 1, 7, EPI, 2, 2, 16>(p, s);
                 case 128: return launch_gemm<1, 4, 1, EPI, 1, 1, 1, 2>(p, s);

@@ -339,6 +339,9 @@ def ddim_loop(x2d: torch.Tensor, x2d_flip: torch.Tensor, noise: torch.Tensor, we
     joint_part, joint_local = joint_part.to(dev), joint_local.to(dev)
     perm = flip_perm.to(device=dev, dtype=torch.int32).contiguous()
     cfg.joint_part, cfg.joint_local, cfg.flip_perm = joint_part.data_ptr(), joint_local.data_ptr(), perm.data_ptr()
+    # one stream, every layer part by part: the launches (and so the bits) of the modules' three-stream schedule - the shared grids
+    # of the library's own single-stream schedule keep another whole-row epilogue (same function, rounding-level differences)
+    cfg.part_by_part_launches = 1
     steps = (_lib.DDIMStep * T)()
     for k in range(T):
         st = steps[k]

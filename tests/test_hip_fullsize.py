@@ -387,11 +387,14 @@ def test_single_model_variant_training_is_refused_loudly():
 
 def test_grouped_launches_equal_part_by_part_launches():
     """The single-stream schedule (no aux streams) puts the same layer of the three parts into shared grids
-    (grouped_*_kernel).  A tile's arithmetic must not depend on the grid it runs in: the same loop with every layer
+    (grouped_*_kernel).  A tile's products and sums do not depend on the grid it runs in: the same loop with every layer
     launched part by part (pafuse_d3dp_config.part_by_part_launches, a per-call option: the library keeps no process-wide
-    schedule state) gives the same bits."""
+    schedule state) is the same function.  Since round 5 the per-part whole-row launches write their rows through per-wave LDS
+    slabs (epilogue_rows_h) while the shared grid keeps the direct epilogue (three tile shapes in one kernel: the slab form
+    spilled there) - the same arithmetic, contracted differently by the compiler in the two code shapes, so the outputs agree
+    to rounding, not bit for bit: both within 1e-5 of the oracle, within 4e-6 of each other."""
     from __graft_entry__ import make_model
-    model, _ = make_model(20, 2, seed=52)
+    model, sd = make_model(20, 2, seed=52)
     model.precision = "bf16x3"       # (the shared grids are the single-stream schedule of the round-3 kernels)
     model.n_aux_streams = 0
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
@@ -400,7 +403,10 @@ def test_grouped_launches_equal_part_by_part_launches():
     grouped = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     model.part_by_part_launches = True
     part_by_part = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
-    assert torch.equal(grouped, part_by_part)
+    assert float((grouped - part_by_part).abs().max()) <= 4e-6, float((grouped - part_by_part).abs().max())
+    sub = [0, 7, 19]
+    ref = orc.ddim_sample(sd, x2d, [n[:, sub] for n in noises], 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
+    assert float((grouped[:, :, sub] - ref).abs().max()) <= 1e-5 and float((part_by_part[:, :, sub] - ref).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize("precision", ["bf16x3_images", "bf16x3", "f32", "f16x2"])
@@ -419,6 +425,8 @@ def test_side_streams_return_the_single_stream_bits(precision):
     for aux in (0, 2, 5):
         model, _ = make_model(20, T_FULL, seed=52)
         model.precision, model.n_aux_streams = precision, aux
+        model.part_by_part_launches = True      # the single-stream reference launches what the streams launch (no shared grids: their
+        #                                         whole-row epilogue is another code shape, equal to rounding only - round 5)
         model.noise_fn = lambda k, shape, device: noises[k]
         lanes = _lib.check(_lib.load().pafuse_d3dp_lanes(ctypes.byref(model.config_struct(True)), 1, 20, aux))
         assert lanes == aux + 1, (aux, lanes)
