@@ -17,19 +17,23 @@ run() { echo "== $*" >&2; "$@"; }
 # build BEFORE anything runs under the profiler: a stale or missing library would otherwise be compiled (hipcc and its
 # children exec'd) inside a profiled, GPU-initialised process, and pollute the first pass
 run python3 -c "import sys; sys.path.insert(0, '$R'); import __graft_entry__ as ge; ge.build()" || exit 1
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg > "$O/stats_bench_line.json" 2> "$O/stats.err" || exit 1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-secondary > "$O/stats_bench_line.json" 2> "$O/stats.err" || exit 1
 # the single-stream schedule (grouped grids): every launch alone on the chip, so the --stats averages are the kernels' own
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats1 -- python3 "$R/bench.py" --streams 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg > "$O/stats1_bench_line.json" 2> "$O/stats1.err" || exit 1
-run rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > "$O/fetch_bench_line.json" 2> "$O/fetch.err" || exit 1
-run rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O" -o write -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > "$O/write_bench_line.json" 2> "$O/write.err" || exit 1
-run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O" -o mfma -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > "$O/mfma_bench_line.json" 2> "$O/mfma.err" || exit 1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats1 -- python3 "$R/bench.py" --streams 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-secondary > "$O/stats1_bench_line.json" 2> "$O/stats1.err" || exit 1
+run rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O" -o fetch -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-secondary > "$O/fetch_bench_line.json" 2> "$O/fetch.err" || exit 1
+run rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O" -o write -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-secondary > "$O/write_bench_line.json" 2> "$O/write.err" || exit 1
+run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$O" -o mfma -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-secondary > "$O/mfma_bench_line.json" 2> "$O/mfma.err" || exit 1
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o train -- python3 "$R/bench.py" --train --steps 3 --warmup 1 --no-cpu-baseline > "$O/train_bench_line.json" 2> "$O/train.err" || exit 1
 run python3 "$R/bench.py" > "$O/bench_line.json" 2> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --dtype f32 --no-cpu-baseline --no-train-leg > "$O/bench_line_f32.json" 2>> "$O/bench.err" || exit 1
-run python3 "$R/bench.py" --dtype bf16x3 --no-cpu-baseline --no-train-leg > "$O/bench_line_bf16x3.json" 2>> "$O/bench.err" || exit 1
+run python3 "$R/bench.py" --dtype bf16x3_images --no-cpu-baseline --no-train-leg > "$O/bench_line_bf16x3_images.json" 2>> "$O/bench.err" || exit 1
+run python3 "$R/bench.py" --dtype f16x2 --no-cpu-baseline --no-train-leg > "$O/bench_line_f16x2.json" 2>> "$O/bench.err" || exit 1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats1x -- python3 "$R/bench.py" --dtype bf16x3_images --streams 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-roofline > "$O/stats1x_bench_line.json" 2> "$O/stats1x.err" || exit 1
+run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats1h -- python3 "$R/bench.py" --dtype f16x2 --streams 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-roofline > "$O/stats1h_bench_line.json" 2> "$O/stats1h.err" || exit 1
+run python3 "$R/tests/reports/error_growth.py" --out "$O/error_growth.json" > "$O/error_growth.log" 2>&1 || exit 1
 run python3 "$R/bench.py" --train --no-cpu-baseline > "$O/train_bench_line_unprofiled.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --train --train-dtype f32 --no-cpu-baseline > "$O/train_bench_line_f32_unprofiled.json" 2>> "$O/bench.err" || exit 1
-run python3 "$R/tools/soak_determinism.py" 200 > "$O/soak_determinism.json" 2>> "$O/bench.err" || exit 1
+run python3 "$R/tools/soak_determinism.py" 200 bf16x3 > "$O/soak_determinism.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/tests/reports/error_budget.py" --out "$O/error_budget.json" > "$O/error_budget.log" 2>&1 || exit 1
 run python3 "$R/tests/reports/parity_report.py" --out "$O/parity_report.json" > "$O/parity_report.log" 2>&1 || exit 1
 ls -la "$O" | head -40

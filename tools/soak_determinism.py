@@ -29,7 +29,7 @@ from pafuse_amd._lib import kernel_source_digest  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    precision = sys.argv[2] if len(sys.argv) > 2 else "f16x2"
+    precision = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
     aux = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     model, _ = make_model(20, 10, seed=77)
     model.precision = precision
@@ -37,6 +37,7 @@ def main():
     single, _ = make_model(20, 10, seed=77)
     single.precision = precision
     single.n_aux_streams = 0
+    single.part_by_part_launches = True      # the launches of the streamed run (the shared grids keep another whole-row epilogue)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=20, n=10, seed=3)
     model.noise_fn = single.noise_fn = lambda k, shape, device: noises[k]
