@@ -259,6 +259,28 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint
     *reinterpret_cast<bf16x8*>(dst + 32) = s.s2;
 }
 
+// The same image of the TRANSPOSE of a [R,Nrows] fp32 matrix (training: dX = dY W runs the plain GEMM on W^T; the image is
+// made from W as it lies, no transposed copy in between): image row n = column n of `W`, contraction index k = row k of `W`.
+// One (group of 8 k, n) per thread, n fastest: the eight loads of a wave are coalesced along n.
+template <int BKC>
+__global__ void __launch_bounds__(256) split_weights_transposed_kernel(const float* W, uint8_t* out, int Nrows, int R) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int groups = R / 8;
+    if (idx >= (int64_t)Nrows * groups) return;
+    constexpr int SUBS = BKC / 8, ROW = 6 * BKC;
+    const int n = (int)(idx % Nrows), g8 = (int)(idx / Nrows);
+    const int chunk = g8 / SUBS, sb = g8 % SUBS;
+    const float* src = W + (int64_t)g8 * 8 * Nrows + n;
+    f32x4 lo, hi;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = src[(int64_t)i * Nrows], hi[i] = src[(int64_t)(4 + i) * Nrows];
+    const bf16x8x3 sp = split3(lo, hi);
+    uint8_t* dst = out + ((int64_t)chunk * Nrows + n) * ROW + wsplit_sub_offset<BKC, 0>(n, sb);
+    *reinterpret_cast<bf16x8*>(dst) = sp.s0;
+    *reinterpret_cast<bf16x8*>(dst + 16) = sp.s1;
+    *reinterpret_cast<bf16x8*>(dst + 32) = sp.s2;
+}
+
 // torch.clamp(x, -lim, lim): a NaN stays a NaN (common/diffusionpose.py:193,216-217) - fminf(fmaxf(x, -lim), lim) would turn it into
 // -lim, a finite wrong pose.  Both comparisons are false for a NaN.
 __device__ __forceinline__ float clamp_keep_nan(float x, float lim) { return x < -lim ? -lim : (x > lim ? lim : x); }
@@ -285,6 +307,24 @@ __device__ __forceinline__ float gelu_erf(float x) {
     q = q * a + -1.6279072761535645f;
     const float e = 1.0f - __builtin_amdgcn_exp2f(q * a);
     return x * 0.5f * (1.0f + copysignf(e, z));
+}
+// d/dx [x Phi(x)] = Phi(x) + x phi(x), Phi from the same erf form (absolute error 4.5e-7), phi = exp(-x^2/2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float z = x * 0.70710678118654752440f;
+    const float a = fminf(fabsf(z), 4.0f);
+    float q = 1.1622890269791242e-05f;
+    q = q * a + -0.00015313830226659775f;
+    q = q * a + 0.000848921830765903f;
+    q = q * a + -0.0022762208245694637f;
+    q = q * a + 8.650000381749123e-05f;
+    q = q * a + 0.02772335335612297f;
+    q = q * a + -0.14830751717090607f;
+    q = q * a + -0.918442964553833f;
+    q = q * a + -1.6279072761535645f;
+    const float e = 1.0f - __builtin_amdgcn_exp2f(q * a);
+    const float cdf = 0.5f * (1.0f + copysignf(e, z));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2) = 2^(-x^2 / (2 ln 2))
+    return cdf + x * pdf;
 }
 
 // sum over the 32 lanes that share (lane >> 5); every lane of the half ends with the total
@@ -317,6 +357,11 @@ struct GemmParams {
     const uint8_t* Wsplit;  // mode 2: the pre-split image of W (split_weights_kernel), wsplit_bytes(N, K) bytes
     int wlayout;            // host-side only: 0 = the 32x32x16 kernels' image, 2 = the gemm16_tile (qkv) image
     int act;   // EPI_BIAS: 0 none, 1 GELU
+    // training, EPI_BIAS through the coalesced (slab) epilogue only (gemm_bias checks): with out_act, `out` receives the
+    // pre-activation u and out_act gelu(u) (fc1 forward: the backward needs both); with dact_u, out = (acc + bias) * gelu'(dact_u)
+    // (the dX GEMM of fc2: the gradient reaches the pre-activation in the same pass)
+    float* out_act;
+    const float* dact_u;
     // EPI_ROWLN (the workgroup owns whole rows, N == BN; row-per-lane form only):  y = A W^T + bias + resid
     //   z  = post_w ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;  out_x = z
     //   n  = next_w ? LN(z; next) : -  ;  out_n = n   |  out_head = n @ head_w^T + head_b
@@ -901,7 +946,17 @@ __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, cons
                             if (p.act) v[e] = gelu_erf(v[e]);
                         }
                     }
+                    if (p.dact_u) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(p.dact_u + (mw + row) * p.N + ncol);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(u[e]);
+                    }
                     *reinterpret_cast<f32x4*>(p.out + (mw + row) * p.N + ncol) = v;
+                    if (p.out_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        *reinterpret_cast<f32x4*>(p.out_act + (mw + row) * p.N + ncol) = v;
+                    }
                 }
             }
             if (nt0 + NTH < NT) __syncthreads();

@@ -392,6 +392,9 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
+    // the training epilogue options live in the slab epilogue of gemm_tile only: every N % 64 == 0 route below ends there
+    if ((p.out_act || p.dact_u) && (p.N % 64 || p.bf16 > 2 || (p.bf16 == 2 && p.wlayout == 2) || p.ln_in || p.act))
+        return fail(PAFUSE_E_ARG, "linear: out_act / dact_u need N %% 64 == 0 and a plain fp32 or bf16x3 product");
     if (p.bf16 == 3) return hgemm_bias(p, s);   // f16x2: the H pipeline
     if (p.bf16 == 4) return xgemm_bias(p, s);   // bf16x3 on images: the X pipeline
     // small accumulators + single LDS stage = 4-5 independent workgroups per CU, which hides the per-tile

@@ -231,8 +231,21 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
     const int col = threadIdx.x % COLS, g = threadIdx.x / COLS;
     const int i = blockIdx.x * COLS + col;
     float s = 0.f;
-    if (i < n)
-        for (int k = g; k < nparts; k += G) s += partial[(int64_t)k * stride + i];
+    if (i < n) {  // four independent chains (parts k = g + G (4 q + c), c = 0..3), joined in a fixed order: the loads of a
+                  // chain of ~60 parts were a serial latency chain, 14 us for 3 MB
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        const float* src = partial + i;
+        int k = g;
+        for (; k + 3 * G < nparts; k += 4 * G) {
+            const float v0 = src[(int64_t)k * stride], v1 = src[(int64_t)(k + G) * stride];
+            const float v2 = src[(int64_t)(k + 2 * G) * stride], v3 = src[(int64_t)(k + 3 * G) * stride];
+            c0 += v0, c1 += v1, c2 += v2, c3 += v3;
+        }
+        if (k < nparts) c0 += src[(int64_t)k * stride];
+        if (k + G < nparts) c1 += src[(int64_t)(k + G) * stride];
+        if (k + 2 * G < nparts) c2 += src[(int64_t)(k + 2 * G) * stride];
+        s = (c0 + c1) + (c2 + c3);
+    }
     float* dst = i < split ? out + i : out2 + (i - split);
     if (G == 1) {
         if (i < n) *dst = accumulate ? *dst + s : s;
@@ -402,6 +415,134 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
             const int n = n0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
             if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[b][reg];
         }
+    }
+}
+
+// The split-precision weight gradient, round 5: both operands are split ONCE per workgroup, where they are staged.
+// tn_gemm_kernel<1> splits every fragment in registers right before its MFMAs: the X fragments are the same for the four
+// waves, so 5 splits of 8 values (~ 280 VALU instructions of 4 cycles) sit beside 24 MFMAs (768 cycles) - the kernel is
+// VALU-bound near 0.3 of the scheme's ceiling.  Here the thread that stages 8 consecutive m of a column pair splits them
+// (xsplit_pair, 5.5 instructions per value, once) and writes the three bf16 slices TRANSPOSED: LDS holds per operand
+// [slice][m group of 8][column][8 x bf16], so a fragment (8 consecutive m of one column) is one ds_read_b128 per slice -
+// 30 b128 reads per wave and chunk instead of 80 scalar ones, and 2.5x fewer VALU instructions.
+//   column position inside its block of 16: (col & 15) ^ ((col >> 4) & 1) - a staging wave writes columns 2 lane + j, i.e.
+//   every other 16-byte slot; the flip of odd blocks puts the 16 lanes of a write group on 16 different bank quads, and
+//   the fragment reads (32 consecutive columns) stay a permutation inside each block.
+// colsum (may be null): the column sums of Y over the split's rows, partial[split][n] - the bias gradient of the same
+// Linear, taken from the values the staging threads hold anyway (written by the workgroups of the first k tile).
+constexpr int TNS_PLANE = 4 * 128 * 16;  // bytes of one slice plane of one operand: 4 m groups x 128 columns x 16 B
+__device__ __forceinline__ int tns_slot(int mg, int col) {
+    return (mg * 128 + (col & ~15) + ((col & 15) ^ ((col >> 4) & 1))) * 16;
+}
+
+struct TnSplitParams {
+    const float *Y, *X;  // [M,N], [M,K]
+    float* partial;      // [splits][N][K]
+    float* colsum;       // [splits][N] or null
+    int64_t M, rows_per_split;
+    int N, K;
+};
+
+#ifndef PAFUSE_TNS_MINW
+#define PAFUSE_TNS_MINW 2
+#endif
+__global__ void __launch_bounds__(256, PAFUSE_TNS_MINW) tn_split_gemm_kernel(const TnSplitParams p) {
+    __shared__ __attribute__((aligned(16))) uint8_t Ys[3 * TNS_PLANE];
+    __shared__ __attribute__((aligned(16))) uint8_t Xs[3 * TNS_PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tiles_k = (p.K + TN_BK - 1) / TN_BK;
+    const int n0 = (blockIdx.x / tiles_k) * TN_BN, k0 = (blockIdx.x % tiles_k) * TN_BK;
+    const int64_t m_lo = (int64_t)blockIdx.y * p.rows_per_split;
+    const int64_t m_hi = m_lo + p.rows_per_split < p.M ? m_lo + p.rows_per_split : p.M;
+    // staging: wave w holds the m group w (8 rows) of the 32-row chunk, lane c the column pair 2c, 2c + 1
+    const int mg = wave, c2 = 2 * lane;
+    const bool y_in = n0 + c2 < p.N, x_in = k0 + c2 < p.K;  // N, K are even
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t yreg[8], xreg[8];
+    const f32x2_t zero2 = {0.f, 0.f};
+    auto load = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t m = m0 + 8 * mg + i;
+            yreg[i] = (y_in && m < m_hi) ? *reinterpret_cast<const f32x2_t*>(p.Y + m * p.N + n0 + c2) : zero2;
+            xreg[i] = (x_in && m < m_hi) ? *reinterpret_cast<const f32x2_t*>(p.X + m * p.K + k0 + c2) : zero2;
+        }
+    };
+    float csum[2] = {0.f, 0.f};
+    auto store_operand = [&](const f32x2_t* v, uint8_t* base) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t s0[4], s1[4], s2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xsplit_pair(v[2 * q][j], v[2 * q + 1][j], s0[q], s1[q], s2[q]);
+            uint8_t* dst = base + tns_slot(mg, c2 + j);
+            *reinterpret_cast<u32x4*>(dst) = u32x4{s0[0], s0[1], s0[2], s0[3]};
+            *reinterpret_cast<u32x4*>(dst + TNS_PLANE) = u32x4{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<u32x4*>(dst + 2 * TNS_PLANE) = u32x4{s2[0], s2[1], s2[2], s2[3]};
+        }
+    };
+    auto store = [&]() {
+        if (p.colsum) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) csum[0] += yreg[i][0], csum[1] += yreg[i][1];  // ascending m
+        }
+        store_operand(yreg, Ys);
+        store_operand(xreg, Xs);
+    };
+    f32x16 acc[TN_KB];
+#pragma unroll
+    for (int b = 0; b < TN_KB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+    if (m_lo < m_hi) {
+        load(m_lo);
+        store();
+        __syncthreads();
+        for (int64_t m0 = m_lo; m0 < m_hi; m0 += 32) {
+            const bool more = m0 + 32 < m_hi;
+            if (more) load(m0 + 32);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // lane (r, h) of a 16-deep step feeds m = 16 s2 + 8 h + 0..7 of its column = m group 2 s2 + h
+                const uint8_t* ya = Ys + tns_slot(2 * s2 + h, wave * 32 + r);
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ya);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ya + TNS_PLANE);
+                const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(ya + 2 * TNS_PLANE);
+#pragma unroll
+                for (int b = 0; b < TN_KB; ++b) {
+                    const uint8_t* xb = Xs + tns_slot(2 * s2 + h, 32 * b + r);
+                    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(xb);
+                    const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(xb + TNS_PLANE);
+                    const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(xb + 2 * TNS_PLANE);
+                    acc[b] = mfma_bf16_k16(a0, x2, acc[b]);   // small terms first, the leading product last
+                    acc[b] = mfma_bf16_k16(a2, x0, acc[b]);
+                    acc[b] = mfma_bf16_k16(a1, x1, acc[b]);
+                    acc[b] = mfma_bf16_k16(a0, x1, acc[b]);
+                    acc[b] = mfma_bf16_k16(a1, x0, acc[b]);
+                    acc[b] = mfma_bf16_k16(a0, x0, acc[b]);
+                }
+            }
+            __syncthreads();
+            if (more) store();
+            __syncthreads();
+        }
+    }
+    float* out = p.partial + (int64_t)blockIdx.y * p.N * p.K;
+#pragma unroll
+    for (int b = 0; b < TN_KB; ++b) {
+        const int k = k0 + 32 * b + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int n = n0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[b][reg];
+        }
+    }
+    if (p.colsum && k0 == 0) {  // the four m groups of every column, added in ascending group order
+        float* red = reinterpret_cast<float*>(Ys);  // the K loop is over: every wave passed its last barrier
+        red[wave * 128 + c2] = csum[0], red[wave * 128 + c2 + 1] = csum[1];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < p.N)
+            p.colsum[(int64_t)blockIdx.y * p.N + n0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
     }
 }
 
