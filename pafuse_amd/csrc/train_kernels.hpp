@@ -463,9 +463,11 @@ __global__ void __launch_bounds__(256, PAFUSE_TNS_MINW) tn_split_gemm_kernel(con
     auto load = [&](int64_t m0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int64_t m = m0 + 8 * mg + i;
-            yreg[i] = (y_in && m < m_hi) ? *reinterpret_cast<const f32x2_t*>(p.Y + m * p.N + n0 + c2) : zero2;
-            xreg[i] = (x_in && m < m_hi) ? *reinterpret_cast<const f32x2_t*>(p.X + m * p.K + k0 + c2) : zero2;
+            const int64_t m = m0 + 8 * mg + i, mc = m < m_hi ? m : m_hi - 1;   // clamped, unconditional loads: no branch per row
+            const f32x2_t yv = *reinterpret_cast<const f32x2_t*>(p.Y + mc * p.N + (y_in ? n0 + c2 : 0));
+            const f32x2_t xv = *reinterpret_cast<const f32x2_t*>(p.X + mc * p.K + (x_in ? k0 + c2 : 0));
+            yreg[i] = (y_in && m < m_hi) ? yv : zero2;
+            xreg[i] = (x_in && m < m_hi) ? xv : zero2;
         }
     };
     float csum[2] = {0.f, 0.f};
@@ -543,6 +545,184 @@ __global__ void __launch_bounds__(256, PAFUSE_TNS_MINW) tn_split_gemm_kernel(con
         __syncthreads();
         if (tid < 128 && n0 + tid < p.N)
             p.colsum[(int64_t)blockIdx.y * p.N + n0 + tid] = ((red[tid] + red[128 + tid]) + red[256 + tid]) + red[384 + tid];
+    }
+}
+
+// The same product on LARGE tiles.  The 128 x 128 tile above streams 32 KB per 32 rows of the contraction for 1 MFLOP: two
+// workgroups per CU ask the CU's memory pipe for 42 B per clock - the kernel is bound there (it measured 112 us per launch
+// with the staging split against 118 without: the VALU work was not the limit).  The output of a weight gradient is small and
+// the contraction (M = 24 - 68 k rows) is cut into splits anyway, so the tile can be as large as the accumulators allow:
+// (32 NB) x (32 KB) outputs on WN x WK waves, every wave NB/WN x KB/WK blocks of 32 x 32 (96 - 128 accumulator registers),
+// picked so that the three PAFUSE widths divide without padding - 256 x 256 on eight waves (hands: 256, 512, 768),
+// 192 x 192 on six (body: 384, 768, 1152), 224 x 224 on seven (face: 224, 448, 672).  Bytes per FLOP halve, one workgroup
+// per CU, 11 B per clock.
+// Chunks of 16 rows of the contraction, two LDS stages ([stage][operand][slice][m group of 8][column][8 x bf16], the layout
+// and column flip of tn_split_gemm_kernel): iteration i splits and stores the registers of chunk i + 1 into the other stage,
+// loads chunk i + 2 into registers and multiplies chunk i - one barrier per chunk, the split instructions sit in the
+// shadow of the MFMAs.  Thread t stages 8 rows x 2 columns: the first 32 NB threads Y (16 NB column pairs x 2 m groups),
+// the rest X - 32 (NB + KB) = the workgroup's thread count for all three shapes.
+template <int NB, int KB, int WN, int WK>
+__global__ void __launch_bounds__(64 * WN * WK, 2) tn_split_big_kernel(const TnSplitParams p) {
+    constexpr int NTHR = 64 * WN * WK, BNW = NB / WN, BKW = KB / WK, YC = 32 * NB, XC = 32 * KB;
+    static_assert(NB % WN == 0 && KB % WK == 0 && 32 * (NB + KB) == NTHR, "tile / wave grid");
+    constexpr int Y_PLANE = 2 * YC * 16, X_PLANE = 2 * XC * 16;       // bytes of one slice plane (two m groups)
+    constexpr int X_BASE = 3 * Y_PLANE, STAGE = 3 * (Y_PLANE + X_PLANE);
+    extern __shared__ __attribute__((aligned(16))) uint8_t tn_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int wn = wave / WK, wk = wave % WK;
+    const int tiles_k = p.K / XC;
+    const int n0 = (blockIdx.x / tiles_k) * YC, k0 = (blockIdx.x % tiles_k) * XC;
+    const int64_t m_lo = (int64_t)blockIdx.y * p.rows_per_split;
+    const int64_t m_hi = m_lo + p.rows_per_split < p.M ? m_lo + p.rows_per_split : p.M;
+    auto slot = [](int pitch, int mg, int col) { return (mg * pitch + (col & ~15) + ((col & 15) ^ ((col >> 4) & 1))) * 16; };
+    // staging role of this thread
+    const bool is_y = tid < 32 * NB;
+    const int st = is_y ? tid : tid - 32 * NB;
+    const int pairs = is_y ? 16 * NB : 16 * KB;
+    const int smg = st / pairs, sc2 = 2 * (st % pairs);
+    const float* sbase = is_y ? p.Y + n0 + sc2 : p.X + k0 + sc2;
+    const int sld = is_y ? p.N : p.K;
+    const int s_lds = is_y ? slot(YC, smg, sc2) : X_BASE + slot(XC, smg, sc2);
+    const int s_lds1 = is_y ? slot(YC, smg, sc2 + 1) : X_BASE + slot(XC, smg, sc2 + 1);
+    const int s_plane = is_y ? Y_PLANE : X_PLANE;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t sreg[8];
+    const f32x2_t zero2 = {0.f, 0.f};
+    auto load = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // unconditional load from a clamped row, zeroed afterwards: a guarded load compiles to a branch per row, and the
+            // eight branches cut the loop body into blocks the scheduler cannot overlap
+            const int64_t m = m0 + 8 * smg + i;
+            const f32x2_t v = *reinterpret_cast<const f32x2_t*>(sbase + (m < m_hi ? m : m_hi - 1) * sld);
+            sreg[i] = m < m_hi ? v : zero2;
+        }
+    };
+    float csum[2] = {0.f, 0.f};
+    auto store = [&](int stage) {
+        if (p.colsum && is_y) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) csum[0] += sreg[i][0], csum[1] += sreg[i][1];  // ascending m
+        }
+        uint8_t* base = tn_lds + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint32_t s0[4], s1[4], s2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xsplit_pair(sreg[2 * q][j], sreg[2 * q + 1][j], s0[q], s1[q], s2[q]);
+            uint8_t* dst = base + (j ? s_lds1 : s_lds);
+            *reinterpret_cast<u32x4*>(dst) = u32x4{s0[0], s0[1], s0[2], s0[3]};
+            *reinterpret_cast<u32x4*>(dst + s_plane) = u32x4{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<u32x4*>(dst + 2 * s_plane) = u32x4{s2[0], s2[1], s2[2], s2[3]};
+        }
+    };
+    f32x16 acc[BNW][BKW];
+#pragma unroll
+    for (int a = 0; a < BNW; ++a)
+#pragma unroll
+        for (int b = 0; b < BKW; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // fragment addresses of this lane inside a stage: m group h, column (block) * 32 + r
+    int ya[BNW], xa[BKW];
+#pragma unroll
+    for (int a = 0; a < BNW; ++a) ya[a] = slot(YC, h, (wn * BNW + a) * 32 + r);
+#pragma unroll
+    for (int b = 0; b < BKW; ++b) xa[b] = X_BASE + slot(XC, h, (wk * BKW + b) * 32 + r);
+    const int64_t nchunks = m_lo < m_hi ? (m_hi - m_lo + 15) / 16 : 0;
+    if (nchunks > 0) {
+        load(m_lo);
+        store(0);
+        if (nchunks > 1) load(m_lo + 16);
+        __syncthreads();
+        // One iteration = the 6 BNW BKW MFMAs of chunk i, and BETWEEN them, one small piece per MFMA in program order (a
+        // scheduling fence after every slot): the split of the registers of chunk i + 1 (16 half splits of a value pair, 5 - 6
+        // VALU instructions each), their six stage writes, then the eight row loads of chunk i + 2.  A wave issues in order: an
+        // MFMA holds the matrix pipe for 32 cycles, the 5 - 6 instructions behind it issue in its shadow.  (The compiler's own
+        // order put all ~115 split instructions in front of the first MFMA.)  Past the last chunk the loads return zeros
+        // (rows >= m_hi) and the writes fill a stage nobody reads: the body has no branch.
+        constexpr int NSLOT = 6 * BNW * BKW;
+        const float* sbase_lo = sbase + m_lo * sld;
+        const int nrows = (int)(m_hi - m_lo);
+        static_assert(NSLOT >= 30, "not enough MFMA slots for the staging pieces");
+        for (int64_t i = 0; i < nchunks; ++i) {
+            const uint8_t* st_base = tn_lds + (int)(i & 1) * STAGE;
+            uint8_t* wr_base = tn_lds + (int)((i + 1) & 1) * STAGE;
+            const int r_next = 16 * ((int)i + 2) + 8 * smg;
+            const int r_cur = 16 * ((int)i + 1) + 8 * smg;   // first of this thread's rows of the chunk being split, from m_lo
+            const bool want_csum = p.colsum && is_y;
+            bf16x8 a0[BNW], a1[BNW], a2[BNW], x0[2], x1[2], x2[2];
+#pragma unroll
+            for (int a = 0; a < BNW; ++a) {
+                a0[a] = *reinterpret_cast<const bf16x8*>(st_base + ya[a]);
+                a1[a] = *reinterpret_cast<const bf16x8*>(st_base + ya[a] + Y_PLANE);
+                a2[a] = *reinterpret_cast<const bf16x8*>(st_base + ya[a] + 2 * Y_PLANE);
+            }
+            x0[0] = *reinterpret_cast<const bf16x8*>(st_base + xa[0]);
+            x1[0] = *reinterpret_cast<const bf16x8*>(st_base + xa[0] + X_PLANE);
+            x2[0] = *reinterpret_cast<const bf16x8*>(st_base + xa[0] + 2 * X_PLANE);
+            SplitPair sp[8];   // pair 4 j + q: rows 2 q, 2 q + 1 of column j
+            static_for<NSLOT>([&](auto S) {
+                constexpr int sl = decltype(S)::value;
+                constexpr int b = sl / (6 * BNW), term = (sl / BNW) % 6, a = sl % BNW, cur = b & 1;
+                if constexpr (term == 0 && a == 0 && b + 1 < BKW) {   // the next block column's fragments, one column ahead
+                    x0[cur ^ 1] = *reinterpret_cast<const bf16x8*>(st_base + xa[b + 1]);
+                    x1[cur ^ 1] = *reinterpret_cast<const bf16x8*>(st_base + xa[b + 1] + X_PLANE);
+                    x2[cur ^ 1] = *reinterpret_cast<const bf16x8*>(st_base + xa[b + 1] + 2 * X_PLANE);
+                }
+                // the six products of a block small terms first, the leading one last; term-major over the wave's row blocks
+                if constexpr (term == 0) acc[a][b] = mfma_bf16_k16(a0[a], x2[cur], acc[a][b]);
+                if constexpr (term == 1) acc[a][b] = mfma_bf16_k16(a2[a], x0[cur], acc[a][b]);
+                if constexpr (term == 2) acc[a][b] = mfma_bf16_k16(a1[a], x1[cur], acc[a][b]);
+                if constexpr (term == 3) acc[a][b] = mfma_bf16_k16(a0[a], x1[cur], acc[a][b]);
+                if constexpr (term == 4) acc[a][b] = mfma_bf16_k16(a1[a], x0[cur], acc[a][b]);
+                if constexpr (term == 5) acc[a][b] = mfma_bf16_k16(a0[a], x0[cur], acc[a][b]);
+                if constexpr (sl < 16) {
+                    constexpr int pi = sl / 2, jj = pi / 4, q = pi % 4;
+                    if constexpr (sl % 2 == 0) {
+                        // rows past the split's end are zeroed HERE, an iteration after their load was issued: a select right
+                        // behind the load makes the wave wait for it on the spot
+                        float v0 = r_cur + 2 * q < nrows ? sreg[2 * q][jj] : 0.f, v1 = r_cur + 2 * q + 1 < nrows ? sreg[2 * q + 1][jj] : 0.f;
+                        if (want_csum) csum[jj] += v0, csum[jj] += v1;   // ascending m
+                        asm volatile("" : "+v"(v0), "+v"(v1));   // ONE value for all slices (see split2h)
+                        sp[pi].x0 = v0, sp[pi].x1 = v1;
+                        sp[pi].template stage<0>(), sp[pi].template stage<1>(), sp[pi].template stage<2>();
+                    } else {
+                        sp[pi].template stage<3>(), sp[pi].template stage<4>();
+                    }
+                } else if constexpr (sl < 22) {
+                    constexpr int w = sl - 16, jj = w / 3, slice = w % 3;
+                    uint8_t* dst = wr_base + (jj ? s_lds1 : s_lds) + slice * s_plane;
+                    if constexpr (slice == 0) *reinterpret_cast<u32x4*>(dst) = u32x4{sp[4 * jj].s0, sp[4 * jj + 1].s0, sp[4 * jj + 2].s0, sp[4 * jj + 3].s0};
+                    if constexpr (slice == 1) *reinterpret_cast<u32x4*>(dst) = u32x4{sp[4 * jj].s1, sp[4 * jj + 1].s1, sp[4 * jj + 2].s1, sp[4 * jj + 3].s1};
+                    if constexpr (slice == 2) *reinterpret_cast<u32x4*>(dst) = u32x4{sp[4 * jj].s2, sp[4 * jj + 1].s2, sp[4 * jj + 2].s2, sp[4 * jj + 3].s2};
+                } else if constexpr (sl < 30) {
+                    constexpr int q = sl - 22;
+                    const int rel = r_next + q;   // row from m_lo, clamped into the split (32-bit: a split spans a few MB)
+                    sreg[q] = *reinterpret_cast<const f32x2_t*>(sbase_lo + (uint32_t)((rel < nrows ? rel : nrows - 1) * sld));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();
+        }
+    }
+    float* out = p.partial + (int64_t)blockIdx.y * p.N * p.K;
+#pragma unroll
+    for (int a = 0; a < BNW; ++a)
+#pragma unroll
+        for (int b = 0; b < BKW; ++b) {
+            const int k = k0 + (wk * BKW + b) * 32 + r;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int n = n0 + (wn * BNW + a) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                out[(int64_t)n * p.K + k] = acc[a][b][reg];
+            }
+        }
+    if (p.colsum && k0 == 0) {  // the two m groups of every column (the last barrier of the loop is behind every wave)
+        float* red = reinterpret_cast<float*>(tn_lds);
+        if (is_y) red[smg * YC + sc2] = csum[0], red[smg * YC + sc2 + 1] = csum[1];
+        __syncthreads();
+        if (tid < YC) p.colsum[(int64_t)blockIdx.y * p.N + n0 + tid] = red[tid] + red[YC + tid];
     }
 }
 
