@@ -865,6 +865,200 @@ __global__ void __launch_bounds__(256) attn_backward_kernel(const AttnBackwardPa
     }
 }
 
+// The same on the matrix cores (v_mfma_f32_16x16x4_f32, fp32 products), nothing but Q, K, V, dO and three row vectors in LDS.
+// One (sequence, head) per workgroup of T = LP/16 waves; wave w owns QUERY tile w in pass 1 and KEY tile w in pass 2:
+//   pass 1  S^T = K Q^T and dP^T = V dO^T (the forward kernel's form: the query on the lane, the keys in the accumulator
+//           registers): softmax statistics of the wave's 16 queries in registers + two xor-shuffles, dS in registers, and
+//           dQ^T = K^T dS^T takes dS straight from the accumulators as its B operand.  max, 1/sum and rowsum(P dP) of
+//           every query go to LDS.
+//   pass 2  S = Q K^T and dP = dO V^T for the wave's 16 KEYS against all query tiles (the key on the lane, the queries in
+//           the accumulator registers); P and dS are rebuilt from the statistics of pass 1 and feed dK^T = Q^T dS and
+//           dV^T = dO^T P as B operands.
+// S is computed twice (the products are 20 - 35 % of the MFMAs of an item) so that neither P nor dS ever has to be
+// transposed through LDS.  Contraction indices are permuted the same way for both operands of every product (lane group g
+// holds k = 16 s + 4 g + j, or the key / query 16 t + 4 g + reg), which is all an inner product needs.
+template <int LP, int DP>
+__global__ void __launch_bounds__((LP / 16) * 64) attn_backward_mfma_kernel(const AttnBackwardParams p) {
+    constexpr int T = LP / 16, CT = DP / 16, SD = DP / 16, LDV = DP + 4, NTHR = T * 64, C4 = DP / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;               // [LP][LDV] each, zero-padded
+    float* Ks = Qs + LP * LDV;
+    float* Vs = Ks + LP * LDV;
+    float* Gs = Vs + LP * LDV;      // dO
+    float* St = Gs + LP * LDV;      // [3][LP]: row max, 1 / row sum, rowsum(P dP)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, g = lane >> 4;
+    int64_t seq;
+    int head;
+    attn_item<1>((int64_t)blockIdx.x, p.nseq, p.heads, seq, head);
+    const int64_t base = (seq / p.group) * p.group_stride + (seq % p.group) * p.seq_stride;
+    const int C3 = 3 * p.C;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < LP * C4; idx += NTHR) {
+        const int t = idx / C4, c4 = idx % C4;
+        f32x4 q = zero, k = zero, v = zero, gg = zero;
+        if (t < p.L && 4 * c4 < p.d) {
+            const int64_t row = base + (int64_t)t * p.tok_stride;
+            const float* src = p.qkv + row * C3 + head * p.d + 4 * c4;
+            q = *reinterpret_cast<const f32x4*>(src);
+            k = *reinterpret_cast<const f32x4*>(src + p.C);
+            v = *reinterpret_cast<const f32x4*>(src + 2 * p.C);
+            gg = *reinterpret_cast<const f32x4*>(p.d_o + row * p.C + head * p.d + 4 * c4);
+        }
+        *reinterpret_cast<f32x4*>(Qs + t * LDV + 4 * c4) = q;
+        *reinterpret_cast<f32x4*>(Ks + t * LDV + 4 * c4) = k;
+        *reinterpret_cast<f32x4*>(Vs + t * LDV + 4 * c4) = v;
+        *reinterpret_cast<f32x4*>(Gs + t * LDV + 4 * c4) = gg;
+    }
+    __syncthreads();
+    constexpr float LOG2E = 1.44269504088896340736f;
+    // ------------------------------------------------------------------ pass 1: query 16 w + l15 on the lane
+    {
+        f32x4 sc[T], dc[T];
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt) sc[kt] = zero, dc[kt] = zero;
+#pragma unroll
+        for (int s = 0; s < SD; ++s) {
+            const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + (16 * w + l15) * LDV + 16 * s + 4 * g);
+            const f32x4 gf = *reinterpret_cast<const f32x4*>(Gs + (16 * w + l15) * LDV + 16 * s + 4 * g);
+            f32x4 kf[T], vf[T];
+#pragma unroll
+            for (int kt = 0; kt < T; ++kt) {
+                kf[kt] = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + l15) * LDV + 16 * s + 4 * g);
+                vf[kt] = *reinterpret_cast<const f32x4*>(Vs + (16 * kt + l15) * LDV + 16 * s + 4 * g);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kt = 0; kt < T; ++kt) {
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kt][j], qf[j], sc[kt], 0, 0, 0);
+                    dc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[kt][j], gf[j], dc[kt], 0, 0, 0);
+                }
+        }
+        // sc[kt][reg] = <q, k>, dc[kt][reg] = <dO, v> for query 16 w + l15 and key 16 kt + 4 g + reg
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float v = 16 * kt + 4 * g + reg < p.L ? sc[kt][reg] * p.scale : -INFINITY;
+                sc[kt][reg] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float e = __builtin_amdgcn_exp2f((sc[kt][reg] - mx) * LOG2E);   // 0 for the masked keys
+                sc[kt][reg] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                sc[kt][reg] *= inv;                       // P
+                dot += sc[kt][reg] * dc[kt][reg];
+            }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        if (g == 0) St[16 * w + l15] = mx, St[LP + 16 * w + l15] = inv, St[2 * LP + 16 * w + l15] = dot;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) sc[kt][reg] = sc[kt][reg] * (dc[kt][reg] - dot) * p.scale;   // dS (0 where P is 0)
+        // dQ^T = K^T dS^T: the K element is the A operand (row = channel), dS the B operand (column = query)
+        f32x4 dq[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dq[ct] = zero;
+#pragma unroll
+        for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float* krow = Ks + (16 * kt + 4 * g + reg) * LDV + l15;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    dq[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(krow[16 * ct], sc[kt][reg], dq[ct], 0, 0, 0);
+            }
+        // dq[ct][r] = dQ[query 16 w + l15][channel 16 ct + 4 g + r]
+        const int q1 = 16 * w + l15;
+        if (q1 < p.L) {
+            float* dst = p.dqkv + (base + (int64_t)q1 * p.tok_stride) * C3 + head * p.d + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (16 * ct + 4 * g < p.d) *reinterpret_cast<f32x4*>(dst + 16 * ct) = dq[ct];
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ pass 2: key 16 w + l15 on the lane
+    {
+        f32x4 s2[T], d2[T];
+#pragma unroll
+        for (int qt = 0; qt < T; ++qt) s2[qt] = zero, d2[qt] = zero;
+#pragma unroll
+        for (int s = 0; s < SD; ++s) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * w + l15) * LDV + 16 * s + 4 * g);
+            const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (16 * w + l15) * LDV + 16 * s + 4 * g);
+            f32x4 qf[T], gf[T];
+#pragma unroll
+            for (int qt = 0; qt < T; ++qt) {
+                qf[qt] = *reinterpret_cast<const f32x4*>(Qs + (16 * qt + l15) * LDV + 16 * s + 4 * g);
+                gf[qt] = *reinterpret_cast<const f32x4*>(Gs + (16 * qt + l15) * LDV + 16 * s + 4 * g);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int qt = 0; qt < T; ++qt) {
+                    s2[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[qt][j], kf[j], s2[qt], 0, 0, 0);
+                    d2[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[qt][j], vf[j], d2[qt], 0, 0, 0);
+                }
+        }
+        // s2[qt][reg] = <q, k>, d2[qt][reg] = <dO, v> for query 16 qt + 4 g + reg and key 16 w + l15
+        const int k1 = 16 * w + l15;
+#pragma unroll
+        for (int qt = 0; qt < T; ++qt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int q = 16 * qt + 4 * g + reg;
+                const float pr = (q < p.L && k1 < p.L)
+                                     ? __builtin_amdgcn_exp2f((s2[qt][reg] * p.scale - St[q]) * LOG2E) * St[LP + q] : 0.f;
+                s2[qt][reg] = pr;                                           // P
+                d2[qt][reg] = pr * (d2[qt][reg] - St[2 * LP + q]) * p.scale;   // dS
+            }
+        // dK^T = Q^T dS, dV^T = dO^T P: the Q / dO element is the A operand (row = channel), dS / P the B operand (column = key)
+        f32x4 dk[CT], dv[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dk[ct] = zero, dv[ct] = zero;
+#pragma unroll
+        for (int qt = 0; qt < T; ++qt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float* qrow = Qs + (16 * qt + 4 * g + reg) * LDV + l15;
+                const float* grow = Gs + (16 * qt + 4 * g + reg) * LDV + l15;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    dk[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(qrow[16 * ct], d2[qt][reg], dk[ct], 0, 0, 0);
+                    dv[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(grow[16 * ct], s2[qt][reg], dv[ct], 0, 0, 0);
+                }
+            }
+        if (k1 < p.L) {
+            float* dst = p.dqkv + (base + (int64_t)k1 * p.tok_stride) * C3 + head * p.d + 4 * g;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                if (16 * ct + 4 * g < p.d) {
+                    *reinterpret_cast<f32x4*>(dst + p.C + 16 * ct) = dk[ct];
+                    *reinterpret_cast<f32x4*>(dst + 2 * p.C + 16 * ct) = dv[ct];
+                }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // Small reductions of the first / last layers
 // ----------------------------------------------------------------------------------------------------------------
