@@ -318,11 +318,7 @@ struct TnParams {
 constexpr int TN_BN = 128, TN_BK = 128, TN_LDY = TN_BN + 32, TN_LDX = TN_BK + 32;
 constexpr int TN_KB = TN_BK / 32;  // 32-column blocks per wave strip
 
-// SPLIT = 1 (training with split-precision products, precision 'bf16x3'): the same tiles and the same staging, the products
-// as six v_mfma_f32_32x32x16_bf16 per 16 rows of the contraction - both operands are activations, so both fragments are split
-// into their three bf16 slices in registers right after their LDS reads (8 scalar reads per fragment: 8 consecutive m of
-// one column); fp32-equivalent, one rounding per 16 rows instead of per 2.
-template <int SPLIT>
+// (fp32 products; the split-precision weight gradients are tn_split_gemm_kernel / tn_split_big_kernel below)
 __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
     __shared__ __attribute__((aligned(16))) float Ys[32 * TN_LDY];
     __shared__ __attribute__((aligned(16))) float Xs[32 * TN_LDX];
@@ -367,39 +363,14 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
         for (int64_t m0 = m_lo; m0 < m_hi; m0 += 32) {
             const bool more = m0 + 32 < m_hi;
             if (more) load(m0 + 32);
-            if constexpr (SPLIT) {
-                // lane (r, h) of a 16-deep step feeds m = 16 s2 + 8 h + 0..7 of its column: the same m set for both operands
+            const float* ya = Ys + h * TN_LDY + wave * 32 + r;
+            const float* xb = Xs + h * TN_LDX + r;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const float* ya = Ys + (16 * s2 + 8 * h) * TN_LDY + wave * 32 + r;
-                    const float* xb = Xs + (16 * s2 + 8 * h) * TN_LDX + r;
-                    f32x4 lo, hi;
+            for (int s = 0; s < 16; ++s) {
+                const float a = ya[2 * s * TN_LDY];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) lo[j] = ya[j * TN_LDY], hi[j] = ya[(4 + j) * TN_LDY];
-                    const bf16x8x3 a = split3(lo, hi);
-#pragma unroll
-                    for (int b = 0; b < TN_KB; ++b) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) lo[j] = xb[j * TN_LDX + 32 * b], hi[j] = xb[(4 + j) * TN_LDX + 32 * b];
-                        const bf16x8x3 x = split3(lo, hi);
-                        acc[b] = mfma_bf16_k16(a.s0, x.s2, acc[b]);   // small terms first, the leading product last
-                        acc[b] = mfma_bf16_k16(a.s2, x.s0, acc[b]);
-                        acc[b] = mfma_bf16_k16(a.s1, x.s1, acc[b]);
-                        acc[b] = mfma_bf16_k16(a.s0, x.s1, acc[b]);
-                        acc[b] = mfma_bf16_k16(a.s1, x.s0, acc[b]);
-                        acc[b] = mfma_bf16_k16(a.s0, x.s0, acc[b]);
-                    }
-                }
-            } else {
-                const float* ya = Ys + h * TN_LDY + wave * 32 + r;
-                const float* xb = Xs + h * TN_LDX + r;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float a = ya[2 * s * TN_LDY];
-#pragma unroll
-                    for (int b = 0; b < TN_KB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[2 * s * TN_LDX + 32 * b], acc[b], 0, 0, 0);
-                }
+                for (int b = 0; b < TN_KB; ++b)
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[2 * s * TN_LDX + 32 * b], acc[b], 0, 0, 0);
             }
             __syncthreads();
             if (more) store();
@@ -419,7 +390,7 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
 }
 
 // The split-precision weight gradient, round 5: both operands are split ONCE per workgroup, where they are staged.
-// tn_gemm_kernel<1> splits every fragment in registers right before its MFMAs: the X fragments are the same for the four
+// Round 4's kernel split every fragment in registers right before its MFMAs: the X fragments are the same for the four
 // waves, so 5 splits of 8 values (~ 280 VALU instructions of 4 cycles) sit beside 24 MFMAs (768 cycles) - the kernel is
 // VALU-bound near 0.3 of the scheme's ceiling.  Here the thread that stages 8 consecutive m of a column pair splits them
 // (xsplit_pair, 5.5 instructions per value, once) and writes the three bf16 slices TRANSPOSED: LDS holds per operand
