@@ -391,8 +391,8 @@ __global__ void __launch_bounds__(256) tn_gemm_kernel(const TnParams p) {
 
 // The split-precision weight gradient, round 5: both operands are split ONCE per workgroup, where they are staged.
 // Round 4's kernel split every fragment in registers right before its MFMAs: the X fragments are the same for the four
-// waves, so 5 splits of 8 values (~ 280 VALU instructions of 4 cycles) sit beside 24 MFMAs (768 cycles) - the kernel is
-// VALU-bound near 0.3 of the scheme's ceiling.  Here the thread that stages 8 consecutive m of a column pair splits them
+// waves, so 5 splits of 8 values (~ 280 VALU instructions of 4 cycles) sat beside 24 MFMAs (768 cycles), at 0.3 of the
+// scheme's ceiling.  Here the thread that stages 8 consecutive m of a column pair splits them
 // (xsplit_pair, 5.5 instructions per value, once) and writes the three bf16 slices TRANSPOSED: LDS holds per operand
 // [slice][m group of 8][column][8 x bf16], so a fragment (8 consecutive m of one column) is one ds_read_b128 per slice -
 // 30 b128 reads per wave and chunk instead of 80 scalar ones, and 2.5x fewer VALU instructions.
