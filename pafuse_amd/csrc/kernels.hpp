@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) split_weights_kernel(const float* W, uint
 // The same image of the TRANSPOSE of a [R,Nrows] fp32 matrix (training: dX = dY W runs the plain GEMM on W^T; the image is
 // made from W as it lies, no transposed copy in between): image row n = column n of `W`, contraction index k = row k of `W`.
 // One (group of 8 k, n) per thread, n fastest: the eight loads of a wave are coalesced along n.
-template <int BKC>
+template <int BKC, int M16 = 0>
 __global__ void __launch_bounds__(256) split_weights_transposed_kernel(const float* W, uint8_t* out, int Nrows, int R) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int groups = R / 8;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) split_weights_transposed_kernel(const flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) lo[i] = src[(int64_t)i * Nrows], hi[i] = src[(int64_t)(4 + i) * Nrows];
     const bf16x8x3 sp = split3(lo, hi);
-    uint8_t* dst = out + ((int64_t)chunk * Nrows + n) * ROW + wsplit_sub_offset<BKC, 0>(n, sb);
+    uint8_t* dst = out + ((int64_t)chunk * Nrows + n) * ROW + wsplit_sub_offset<BKC, M16>(n, sb);
     *reinterpret_cast<bf16x8*>(dst) = sp.s0;
     *reinterpret_cast<bf16x8*>(dst + 16) = sp.s1;
     *reinterpret_cast<bf16x8*>(dst + 32) = sp.s2;
@@ -357,7 +357,7 @@ struct GemmParams {
     const uint8_t* Wsplit;  // mode 2: the pre-split image of W (split_weights_kernel), wsplit_bytes(N, K) bytes
     int wlayout;            // host-side only: 0 = the 32x32x16 kernels' image, 2 = the gemm16_tile (qkv) image
     int act;   // EPI_BIAS: 0 none, 1 GELU
-    // training, EPI_BIAS through the coalesced (slab) epilogue only (gemm_bias checks): with out_act, `out` receives the
+    // training, EPI_BIAS through the coalesced (slab) epilogue of gemm_tile or gemm16_tile's (gemm_bias checks): with out_act, `out` receives the
     // pre-activation u and out_act gelu(u) (fc1 forward: the backward needs both); with dact_u, out = (acc + bias) * gelu'(dact_u)
     // (the dX GEMM of fc2: the gradient reaches the pre-activation in the same pass)
     float* out_act;
@@ -1121,7 +1121,17 @@ __device__ __forceinline__ void gemm16_tile(const GemmParams& p, const int b, co
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (p.act) v[e] = gelu_erf(v[e]);
+            if (p.dact_u) {   // training: the gradient reaches the pre-activation in the same pass (GemmParams.dact_u)
+                const f32x4 u = *reinterpret_cast<const f32x4*>(p.dact_u + m * p.N + n0 + 4 * qd + 16 * n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(u[e]);
+            }
             *reinterpret_cast<f32x4*>(orow + 16 * n) = v;
+            if (p.out_act) {  // training: `out` keeps the pre-activation, out_act its GELU
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                *reinterpret_cast<f32x4*>(p.out_act + m * p.N + n0 + 4 * qd + 16 * n) = v;
+            }
         }
     }
 }

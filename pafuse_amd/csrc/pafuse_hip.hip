@@ -392,8 +392,8 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     if (p.M <= 0) return PAFUSE_OK;
     if (p.K % BK || p.N % 32 || p.K <= 0 || p.N <= 0)
         return fail(PAFUSE_E_SHAPE, "linear: N=%d K=%d must be positive multiples of 32", p.N, p.K);
-    // the training epilogue options live in the slab epilogue of gemm_tile only: every N % 64 == 0 route below ends there
-    if ((p.out_act || p.dact_u) && (p.N % 64 || p.bf16 > 2 || (p.bf16 == 2 && p.wlayout == 2) || p.ln_in || p.act))
+    // the training epilogue options live in the slab epilogue of gemm_tile (every N % 64 == 0 route below ends there) and in gemm16_tile's
+    if ((p.out_act || p.dact_u) && ((p.N % 64 && !(p.bf16 == 2 && p.wlayout == 2)) || p.bf16 > 2 || p.ln_in || p.act))
         return fail(PAFUSE_E_ARG, "linear: out_act / dact_u need N %% 64 == 0 and a plain fp32 or bf16x3 product");
     if (p.bf16 == 3) return hgemm_bias(p, s);   // f16x2: the H pipeline
     if (p.bf16 == 4) return xgemm_bias(p, s);   // bf16x3 on images: the X pipeline
@@ -406,6 +406,7 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     if (p.bf16 == 2 && p.wlayout == 2) {  // the qkv layers: 16x16x32 MFMAs on the M16 image (3 - 10 % per launch, kernels.hpp)
         if (p.N % 128 == 0) return launch_gemm16<8, 3>(p, s);    // body 1152, hands 768: 128 x 128 tiles, 3 workgroups per CU
         if (p.N % 96 == 0) return launch_gemm16<6, 3>(p, s);     // face 672, single-model 864: 128 x 96
+        if (p.N % 112 == 0) return launch_gemm16<7, 3>(p, s);    // face 224, 448 (training: every plain GEMM of the face): 128 x 112
         if (p.N % 64 == 0) return launch_gemm16<4, 4>(p, s);
         return launch_gemm16<2, 4>(p, s);
     }

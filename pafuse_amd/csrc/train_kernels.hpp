@@ -222,10 +222,12 @@ __global__ void __launch_bounds__(256) ln_backward_quad_kernel(const LnBackwardP
 // columns; its G lane groups each sum the parts s = g, g + G, ... in ascending order, then the G group sums are added
 // in ascending g.  G = 1 for wide outputs (plenty of columns to fill the chip), 16 for narrow ones with many parts
 // (LayerNorm / bias gradients: a few hundred columns, up to ~1000 parts).  Columns >= split go to out2[i - split]
-// (LayerNorm: dw and db partials lie side by side but their gradients are separate tensors).
+// (LayerNorm: dw and db partials lie side by side but their gradients are separate tensors), columns >= split2 to out3 when
+// it is given (the third vector of a LayerNorm backward: the bias gradient of the branch below).
 template <int G>
 __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* partial, float* out, float* out2, int split,
-                                                              int n, int nparts, int64_t stride, int accumulate) {
+                                                              int n, int nparts, int64_t stride, int accumulate,
+                                                              float* out3 = nullptr, int split2 = 0) {
     constexpr int COLS = 256 / G;
     __shared__ float red[G][COLS];
     const int col = threadIdx.x % COLS, g = threadIdx.x / COLS;
@@ -246,7 +248,8 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
         if (k + 2 * G < nparts) c2 += src[(int64_t)(k + 2 * G) * stride];
         s = (c0 + c1) + (c2 + c3);
     }
-    float* dst = i < split ? out + i : out2 + (i - split);
+    // columns [0, split) -> out, [split, split2) -> out2, [split2, n) -> out3 (out3 null: everything from split on -> out2)
+    float* dst = i < split ? out + i : ((out3 && i >= split2) ? out3 + (i - split2) : out2 + (i - split));
     if (G == 1) {
         if (i < n) *dst = accumulate ? *dst + s : s;
         return;
@@ -258,6 +261,72 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const float* parti
 #pragma unroll
         for (int k = 1; k < G; ++k) t += red[k][col];
         *dst = accumulate ? *dst + t : t;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// Every weight image of a pass in ONE launch.  The weights change once per step, their images are needed once in the forward
+// (W: layout of the plain / the whole-row kernels) and once in the backward (W^T for the dX GEMMs): made one by one in front
+// of their GEMMs they were 96 five-microsecond launches per part and pass in the middle of the dependent chain.
+// kind 0: split_weights_kernel<32> (plain GEMMs)   1: <16> (whole-row GEMMs)   2: split_weights_transposed_kernel<32>
+//      3, 4: as 0, 2 in the layout of the 16x16x32 kernel (gemm16_tile)
+// ----------------------------------------------------------------------------------------------------------------
+constexpr int SPLIT_BATCH_MAX = 4 * 2 * PAFUSE_MAX_DEPTH;
+struct SplitBatchItem {
+    const float* W;
+    uint8_t* out;
+    int N, K;          // the weight as it lies: [N, K]
+    int kind;
+    int first_block;   // index of this item's first workgroup in the launch
+};
+struct SplitBatchParams {
+    SplitBatchItem item[SPLIT_BATCH_MAX];
+    int count;
+};
+
+template <int BKC, int M16>
+__device__ __forceinline__ void split_group_of_8(const float* W, uint8_t* out, int N, int K, int64_t idx) {
+    const int groups = K / 8;
+    if (idx >= (int64_t)N * groups) return;
+    constexpr int SUBS = BKC / 8, ROW = 6 * BKC;
+    const int n = (int)(idx / groups), g8 = (int)(idx % groups);
+    const int chunk = g8 / SUBS, sb = g8 % SUBS;
+    const float* src = W + (int64_t)n * K + g8 * 8;
+    const bf16x8x3 sp = split3(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4));
+    uint8_t* dst = out + ((int64_t)chunk * N + n) * ROW + wsplit_sub_offset<BKC, M16>(n, sb);
+    *reinterpret_cast<bf16x8*>(dst) = sp.s0;
+    *reinterpret_cast<bf16x8*>(dst + 16) = sp.s1;
+    *reinterpret_cast<bf16x8*>(dst + 32) = sp.s2;
+}
+
+__global__ void __launch_bounds__(256) split_weights_batch_kernel(const SplitBatchParams p) {
+    int lo = 0, hi = p.count - 1;   // the last item whose first workgroup is <= blockIdx.x (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (p.item[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const SplitBatchItem it = p.item[lo];
+    const int64_t idx = (int64_t)((int)blockIdx.x - it.first_block) * 256 + threadIdx.x;
+    if (it.kind == 0) {
+        split_group_of_8<32, 0>(it.W, it.out, it.N, it.K, idx);
+    } else if (it.kind == 1) {
+        split_group_of_8<16, 0>(it.W, it.out, it.N, it.K, idx);
+    } else if (it.kind == 3) {
+        split_group_of_8<32, 1>(it.W, it.out, it.N, it.K, idx);
+    } else {   // image rows = the K columns of W, contraction = its N rows (split_weights_transposed_kernel<32>)
+        const int Nrows = it.K, R = it.N, groups = R / 8;
+        if (idx >= (int64_t)Nrows * groups) return;
+        const int n = (int)(idx % Nrows), g8 = (int)(idx / Nrows);
+        const int chunk = g8 / 4, sb = g8 % 4;
+        const float* src = it.W + (int64_t)g8 * 8 * Nrows + n;
+        f32x4 l4, h4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l4[i] = src[(int64_t)i * Nrows], h4[i] = src[(int64_t)(4 + i) * Nrows];
+        const bf16x8x3 sp = split3(l4, h4);
+        uint8_t* dst = it.out + ((int64_t)chunk * Nrows + n) * 192 + (it.kind == 4 ? wsplit_sub_offset<32, 1>(n, sb) : wsplit_sub_offset<32, 0>(n, sb));
+        *reinterpret_cast<bf16x8*>(dst) = sp.s0;
+        *reinterpret_cast<bf16x8*>(dst + 16) = sp.s1;
+        *reinterpret_cast<bf16x8*>(dst + 32) = sp.s2;
     }
 }
 

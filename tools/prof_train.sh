@@ -26,6 +26,14 @@ for r in csv.DictReader(open(t)):
     n = r["Kernel_Name"]
     if any(k in n for k in ("tn_", "gemm_kernel", "gemm_dma", "attn_backward", "ln_backward")):
         agg[(n[:70], r["Grid_Size_X"], r["Grid_Size_Y"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+q = collections.defaultdict(float); span = {}
+for r in csv.DictReader(open(t)):
+    k = (r["Queue_Id"], r["Stream_Id"]); b, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    q[k] += (e - b) / 1e6
+    lo, hi = span.get(k, (b, e)); span[k] = (min(lo, b), max(hi, e))
+print("per (queue, stream): kernel ms, first-to-last span ms")
+for k, v in sorted(q.items(), key=lambda kv: -kv[1])[:8]:
+    print(f"  queue {k[0]} stream {k[1]}: {v:8.1f} {(span[k][1] - span[k][0]) / 1e6:8.1f}")
 print("per (kernel, grid x, grid y): calls, mean us, min us")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"  {len(v):5d} {sum(v)/len(v):8.1f} {min(v):8.1f}  {k[0]}  grid {k[1]} x {k[2]}")
