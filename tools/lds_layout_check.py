@@ -1,4 +1,5 @@
-"""CPU check of the X pipeline's LDS stage (pafuse_amd/csrc/xgemm.hpp): no GPU needed.
+"""CPU check of the LDS stages of the X pipeline (pafuse_amd/csrc/xgemm.hpp) and of the large-tile weight-gradient kernel
+(train_kernels.hpp, check_tn_tile): no GPU needed.
 
 For every tile shape the library launches it replays, in integers, (a) the LDS-DMA fill of one stage - which source bytes
 (row, slice, sub-block of 8 k) each lane of each 1 KiB wave instruction deposits where - and (b) the fragment reads of the K
@@ -74,9 +75,73 @@ def check_tile(wm_, wn_, nt_, bkc):
     return (ia + iw), a_bytes + 3 * w_plane
 
 
+def check_tn_tile(nb_, kb_, wn_, wk_):
+    """tn_split_big_kernel<NB, KB, WN, WK> (pafuse_amd/csrc/train_kernels.hpp): one LDS stage of the weight-gradient kernel.
+    Fill: thread t stages 8 rows of the contraction x 2 columns of Y (t < 32 NB) or X and writes, per column and slice, one
+    16-byte slot at slot(pitch, m group, column).  Reads: lane (r, h) of wave (wn, wk) takes m group h of column 32 block + r.
+    Asserts that every read finds (operand, slice, m group, column) it expects and that reads and writes are conflict-free
+    under the b128 group rule."""
+    nthr = 64 * wn_ * wk_
+    assert 32 * (nb_ + kb_) == nthr
+    yc, xc = 32 * nb_, 32 * kb_
+    y_plane, x_plane = 2 * yc * 16, 2 * xc * 16
+    x_base = 3 * y_plane
+
+    def slot(pitch, mg, col):
+        return (mg * pitch + (col & ~15) + ((col & 15) ^ ((col >> 4) & 1))) * 16
+
+    lds = {}
+    writes = []   # per (j, slice): address of every thread
+    for j in range(2):
+        for sl in range(3):
+            addrs = []
+            for t in range(nthr):
+                is_y = t < 32 * nb_
+                st = t if is_y else t - 32 * nb_
+                pairs = 16 * nb_ if is_y else 16 * kb_
+                smg, sc2 = st // pairs, 2 * (st % pairs)
+                a = (slot(yc, smg, sc2 + j) if is_y else x_base + slot(xc, smg, sc2 + j)) + sl * (y_plane if is_y else x_plane)
+                assert a not in lds
+                lds[a] = ("Y" if is_y else "X", sl, smg, sc2 + j)
+                addrs.append(a)
+            writes.append(addrs)
+    assert len(lds) == 3 * 2 * (yc + xc)
+    bnw, bkw = nb_ // wn_, kb_ // wk_
+    for wave in range(wn_ * wk_):
+        wn, wk = wave // wk_, wave % wk_
+        for sl in range(3):
+            for which, blocks in (("Y", [wn * bnw + a for a in range(bnw)]), ("X", [wk * bkw + b for b in range(bkw)])):
+                for blk in blocks:
+                    addrs = []
+                    for lane in range(64):
+                        r, h = lane & 31, lane >> 5
+                        col = blk * 32 + r
+                        a = (slot(yc, h, col) + sl * y_plane) if which == "Y" else (x_base + slot(xc, h, col) + sl * x_plane)
+                        assert lds[a] == (which, sl, h, col), (which, lane, lds[a], (sl, h, col))
+                        addrs.append(a)
+                    _assert_b128_conflict_free(addrs, ("read", which, wave, sl, blk))
+    for w, addrs in enumerate(writes):     # the stage writes, wave by wave
+        for wave in range(nthr // 64):
+            _assert_b128_conflict_free(addrs[64 * wave:64 * wave + 64], ("write", w, wave))
+    return 3 * 2 * (yc + xc) * 16
+
+
+def _assert_b128_conflict_free(addrs, what):
+    for grp in B128_GROUPS:
+        seen = {}
+        for lane in grp:
+            for d in range(4):
+                bank = (addrs[lane] // 4 + d) % 64
+                assert seen.setdefault(bank, addrs[lane]) == addrs[lane], ("bank conflict",) + tuple(what)
+
+
+X_SHAPES = [(4, 2, 2, 16), (4, 1, 7, 16), (4, 1, 3, 16), (4, 2, 6, 16), (2, 2, 4, 16), (4, 1, 9, 16), (4, 1, 6, 16), (5, 1, 3, 16),
+            (4, 2, 2, 32), (2, 2, 4, 32), (4, 1, 7, 32)]
+TN_SHAPES = [(8, 8, 4, 2), (12, 4, 4, 2), (6, 6, 3, 2), (7, 7, 7, 1)]
+
 if __name__ == "__main__":
-    shapes = [(4, 2, 2, 16), (4, 1, 7, 16), (4, 1, 3, 16), (4, 2, 6, 16), (2, 2, 4, 16), (4, 1, 9, 16), (4, 1, 6, 16), (5, 1, 3, 16),
-              (4, 2, 2, 32), (2, 2, 4, 32), (4, 1, 7, 32)]
-    for s in shapes:
+    for s in TN_SHAPES:
+        print(f"tn_split_big_kernel<NB={s[0]}, KB={s[1]}, WN={s[2]}, WK={s[3]}>: stage {check_tn_tile(*s)} bytes: fill = reads, no bank conflicts")
+    for s in X_SHAPES:
         pieces, stage = check_tile(*s)
         print(f"XTile<WM={s[0]}, WN={s[1]}, NT={s[2]}, BKC={s[3]}>: {pieces} DMA pieces, stage {stage} bytes: fill = reads, no bank conflicts")
