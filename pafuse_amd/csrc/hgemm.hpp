@@ -153,7 +153,9 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
     // and no number of the stream is ever rounded at the magnitude of an outlier mean (the fp32 reference rounds there).
     auto load_resid = [&](int ps, f32x4 (&dst)[LD]) {
         const int nth = pass_cols(ps), qpr = Q4 * nth;
-        const int ncol0 = n0 + (wn * NT + ps * NTH) * 32;
+        int psv = ps;
+        asm volatile("" : "+s"(psv));   // (addresses formed in program order, as in store_rows below)
+        const int ncol0 = n0 + (wn * NT + psv * NTH) * 32;
 #pragma unroll
         for (int it = 0; it < LD; ++it) {
             const int idx = it * 64 + lane, row = idx / qpr, c4 = idx % qpr;
@@ -219,7 +221,10 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int nth = pass_cols(ps), spr = 4 * nth;
-            const int ncol0 = n0 + (wn * NT + ps * NTH) * 32;
+            int psv = ps;
+            asm volatile("" : "+s"(psv));   // the pass' addresses are formed HERE, in program order: hoisted out of the unrolled loop
+                                            // (seven passes at NT = 7) they cost 116 bytes of scratch per lane
+            const int ncol0 = n0 + (wn * NT + psv * NTH) * 32;
 #pragma unroll
             for (int j = 0; j < NTH; ++j)
                 if (j < nth) {
