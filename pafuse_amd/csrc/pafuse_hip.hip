@@ -381,6 +381,9 @@ int debug_f32_mask() {
 constexpr int debug_f32_mask() { return 0; }
 #endif
 
+#ifndef PAFUSE_FC1_MINW
+#define PAFUSE_FC1_MINW 2
+#endif
 int gemm_bias(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     if (p.bf16 == 2 && (debug_f32_mask() & 1)) p.bf16 = 0;
@@ -413,7 +416,7 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
     if (p.bf16 == 2) {  // split precision (bf16x3): fp32-equivalent products on the bf16 matrix cores
         // measured per shape with tools/gemm_bench.hip (profiles/r02_gemm_bench_split_v1.log): 128x128 tiles at two
         // workgroups per CU where N allows (159 TFLOP/s at the body qkv shape), 128x64 at four otherwise (148)
-        if (p.N % 128 == 0 && p.M >= 4096) return launch_gemm<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>(p, s);
+        if (p.N % 128 == 0 && p.M >= 4096) return launch_gemm<4, 1, 4, EPI_BIAS, 1, PAFUSE_FC1_MINW, 0, 2>(p, s);
         if (p.N % 64 == 0) return launch_gemm<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>(p, s);
         if (p.N % 96 == 0) return launch_gemm<4, 1, 3, EPI_BIAS, 1, 1, 1, 2>(p, s);
         return launch_gemm<4, 1, 1, EPI_BIAS, 1, 1, 0, 2>(p, s);
