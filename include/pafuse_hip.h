@@ -13,6 +13,8 @@
  *   pafuse_layernorm         torch.nn.LayerNorm as used in common/mixste.py:96,101,203-204,208
  *   pafuse_attention         Attention.forward between qkv and proj, common/mixste.py:65-79
  *   pafuse_block_forward     Block.forward, common/mixste.py:113-116
+ *   pafuse_attention_backward, pafuse_linear_weight_grad   the backward of the two above as torch autograd derives it
+ *                            (unit entries of the training step's kernels)
  *   pafuse_time_embed        MixSTE2.time_mlp, common/mixste.py:127-139,179-184
  *   pafuse_mixste2_forward   MixSTE2.forward (is_train=False), common/mixste.py:278-298
  *   pafuse_d3dp_sample       D3DP.ddim_sample_flip / ddim_sample, common/diffusionpose.py:227-316
@@ -268,6 +270,20 @@ int pafuse_layernorm(const float *x, const float *w, const float *b, float *out,
  * seq_stride=1, tok_stride=J. */
 int pafuse_attention(const float *qkv, float *o, int64_t nseq, int32_t L, int32_t C, int32_t heads, int64_t group,
                      int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void *stream);
+
+/* Unit entry points of the training step's backward kernels (round 5; the step itself is pafuse_mixste2_train_backward).
+ * pafuse_attention_backward: dqkv[M,3C] from qkv[M,3C] and dO[M,C] - what autograd derives from common/mixste.py:66-79
+ * (S = q k^T d^-1/2, P = softmax(S), O = P v:  dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(P dP)), dQ = dS K d^-1/2,
+ * dK = dS^T Q d^-1/2), sequence map as pafuse_attention.  Rows no sequence touches are left alone.
+ * pafuse_linear_weight_grad: dW[N,K] += dY[M,N]^T X[M,K] and, with db, db[N] += column sums of dY - the weight and bias
+ * gradient of nn.Linear (common/mixste.py:30-43,54,57) as the training step forms them: operand_bf16 0 = fp32 matrix cores,
+ * 2 = split (bf16x3) products on the large tiles where a PAFUSE width divides; partial sums in a fixed order (bit-reproducible).
+ * workspace: pafuse_linear_weight_grad_bytes() bytes. */
+int pafuse_attention_backward(const float *qkv, const float *d_o, float *dqkv, int64_t nseq, int32_t L, int32_t C, int32_t heads,
+                              int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void *stream);
+size_t pafuse_linear_weight_grad_bytes(void);
+int pafuse_linear_weight_grad(const float *dY, const float *X, float *dW, float *db, int64_t M, int32_t N, int32_t K,
+                              int32_t operand_bf16, void *workspace, size_t workspace_bytes, void *stream);
 
 /* x[S*L,C] <- Block(x) in place for S contiguous sequences of L tokens (Block.forward, eps 1e-6).  operand_bf16: the
  * matrix-product mode of the four linear layers (as pafuse_mixste2_weights.operand_bf16; 2, 3 and 4 need the *_ws images of

@@ -79,6 +79,11 @@ SIGNATURES = {
                                    C.c_void_p]),
     "pafuse_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                    C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "pafuse_attention_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    "pafuse_linear_weight_grad_bytes": (C.c_size_t, []),
+    "pafuse_linear_weight_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pafuse_block_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "pafuse_block_forward": (C.c_int, [C.POINTER(BlockWeights), C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),

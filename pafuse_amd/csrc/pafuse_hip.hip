@@ -1635,6 +1635,36 @@ int pafuse_d3dp_replay_layers(const pafuse_d3dp_config* cfg, int32_t B, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------------- training
+int pafuse_attention_backward(const float* qkv, const float* d_o, float* dqkv, int64_t nseq, int32_t L, int32_t C, int32_t heads,
+                              int64_t group, int64_t group_stride, int64_t seq_stride, int64_t tok_stride, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!qkv || !d_o || !dqkv || nseq < 0 || heads <= 0 || C % heads || group <= 0 || L <= 0)
+        return fail(PAFUSE_E_ARG, "attention_backward: bad argument");
+    if (nseq == 0) return PAFUSE_OK;
+    AttnBackwardParams ab{};
+    ab.qkv = qkv, ab.d_o = d_o, ab.dqkv = dqkv, ab.nseq = nseq, ab.group = group, ab.group_stride = group_stride;
+    ab.seq_stride = seq_stride, ab.tok_stride = tok_stride, ab.L = L, ab.C = C, ab.heads = heads, ab.d = C / heads;
+    ab.scale = 1.0f / sqrtf((float)(C / heads));
+    return attention_backward(ab, (hipStream_t)stream);
+}
+
+size_t pafuse_linear_weight_grad_bytes(void) { return TRAIN_PARTIAL_FLOATS * sizeof(float); }
+
+int pafuse_linear_weight_grad(const float* dY, const float* X, float* dW, float* db, int64_t M, int32_t N, int32_t K,
+                              int32_t operand_bf16, void* workspace, size_t workspace_bytes, void* stream) {
+    StreamDevice on_stream_device(stream);
+    if (!dY || !X || !dW || !workspace || M < 0 || N <= 0 || K <= 0) return fail(PAFUSE_E_ARG, "linear_weight_grad: bad argument");
+    if (operand_bf16 != 0 && operand_bf16 != 2) return fail(PAFUSE_E_ARG, "linear_weight_grad: matrix-product mode %d (0 or 2)", operand_bf16);
+    if (N % 4 || K % 4) return fail(PAFUSE_E_SHAPE, "linear_weight_grad: N=%d K=%d must be multiples of 4", N, K);
+    if (workspace_bytes < pafuse_linear_weight_grad_bytes()) return fail(PAFUSE_E_WORKSPACE, "workspace too small");
+    if (M == 0) return PAFUSE_OK;
+    TrainBuffers tb{};
+    tb.split = operand_bf16 == 2;
+    tb.partial = tb.partial_side = (float*)workspace;
+    tb.partial_floats = TRAIN_PARTIAL_FLOATS;
+    return weight_grad(dY, X, dW, M, N, K, tb, (hipStream_t)stream, false, db);
+}
+
 size_t pafuse_mixste2_train_bytes(const pafuse_mixste2_weights* w, int32_t B) {
     if (!w || B <= 0 || check_weights(w, true)) return 0;
     return train_bytes(w, B);

@@ -64,6 +64,42 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
     return o
 
 
+def attention_backward(qkv, d_o, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok_stride=1):
+    """dqkv [M,3C] of attention(): the training step's attention backward kernel on its own (rows no sequence touches: 0)."""
+    lib = _lib.load()
+    M, C3 = qkv.shape
+    Cc = C3 // 3
+    gs = L if group_stride is None else group_stride
+    _need(C3 % 3 == 0 and Cc % heads == 0 and nseq >= 0 and group >= 1 and tuple(d_o.shape) == (M, Cc),
+          "attention_backward: qkv must be [M, 3*heads*d] and d_o [M, heads*d]")
+    if nseq:
+        last = ((nseq - 1) // group) * gs + ((nseq - 1) % group) * seq_stride + (L - 1) * tok_stride
+        _need(0 <= last < M and min(gs, seq_stride, tok_stride) >= 0, f"attention_backward: sequences reach row {last} of {M}")
+    dqkv = torch.zeros(M, C3, device=qkv.device, dtype=torch.float32)
+    with torch.cuda.device(qkv.device):
+        _lib.check(lib.pafuse_attention_backward(_ptr(qkv, "qkv"), _ptr(d_o, "d_o"), dqkv.data_ptr(), nseq, L, Cc, heads, group,
+                                                 gs, seq_stride, tok_stride, _stream(qkv)))
+    return dqkv
+
+
+def linear_weight_grad(d_y, x, precision="bf16x3", bias=True):
+    """(dW [N,K], db [N] or None) = (d_y^T x, column sums of d_y) for d_y [M,N], x [M,K]: the weight / bias gradient kernels of
+    the training step on their own; precision 'bf16x3' (split products) or 'f32'."""
+    lib = _lib.load()
+    _need(precision in ("bf16x3", "f32"), "linear_weight_grad: precision 'bf16x3' or 'f32'")
+    M, N = d_y.shape
+    K = x.shape[1]
+    _need(x.shape[0] == M, "linear_weight_grad: d_y [M,N] and x [M,K]")
+    dw = torch.zeros(N, K, device=x.device, dtype=torch.float32)
+    db = torch.zeros(N, device=x.device, dtype=torch.float32) if bias else None
+    nbytes = lib.pafuse_linear_weight_grad_bytes()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pafuse_linear_weight_grad(_ptr(d_y, "d_y"), _ptr(x, "x"), dw.data_ptr(), db.data_ptr() if bias else None, M, N, K,
+                                                 PRECISIONS[precision], ws.data_ptr(), nbytes, _stream(x)))
+    return dw, db
+
+
 PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 2, "f16x2": 3, "bf16x3_images": 4}       # as pafuse_amd.D3DP.PRECISIONS
 
 

@@ -328,3 +328,82 @@ def test_train_gradients_vs_oracle_odd_shapes(F, J, C, depth, B):
     ref.backward(dout)
     for n, p in m.named_parameters():
         _close(p.grad, leaves[n].grad, n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The backward kernels on their own (unit entries pafuse_attention_backward / pafuse_linear_weight_grad): against fp64
+# ---------------------------------------------------------------------------------------------------------------------------
+def _attention_fp64(qkv, heads, rows_of):
+    """softmax(q k^T d^-1/2) v in fp64 with torch autograd; rows_of: list of index tensors, the rows of each sequence."""
+    M, C3 = qkv.shape
+    C = C3 // 3
+    d = C // heads
+    o = torch.zeros(M, C, dtype=torch.float64)
+    for rows in rows_of:
+        x = qkv[rows].reshape(len(rows), 3, heads, d)
+        q, k, v = x[:, 0].transpose(0, 1), x[:, 1].transpose(0, 1), x[:, 2].transpose(0, 1)      # [heads, L, d]
+        p = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, dim=-1)
+        o = o.index_put((rows,), (p @ v).transpose(0, 1).reshape(len(rows), C))
+    return o
+
+
+# (L, d): the four instantiations the step launches (spatial 24 / 68 / 42 joints, temporal 27 frames at d = 48 / 28 / 32), the
+# padded corners (L = 80 = a full tile, 17, 5; d = 8, 16) and one shape of the FMA fallback (d = 12 is not a multiple of 16... it
+# is a multiple of 4: the matrix kernel; L = 81 exceeds its tiles)
+@pytest.mark.parametrize("L,d,temporal", [(24, 48, False), (27, 48, True), (68, 28, False), (27, 28, True), (42, 32, False),
+                                          (27, 32, True), (80, 8, False), (17, 16, True), (5, 4, False), (33, 12, False),
+                                          (81, 8, False)])
+def test_attention_backward_kernel_against_fp64(L, d, temporal):
+    from pafuse_amd import ops
+    heads, other = 8, 3                     # `other` = the axis the sequences do not run over (frames or joints), 2 clips
+    C = heads * d
+    g = torch.Generator().manual_seed(1000 * L + d)
+    nseq, M = 2 * other, 2 * other * L
+    qkv = torch.randn(M, 3 * C, generator=g) * 1.5
+    d_o = torch.randn(M, C, generator=g)
+    if temporal:     # rows (b, f, j) with f the sequence axis: sequence s = (b, j) holds rows b L other + t other + j
+        rows_of = [torch.arange(L) * other + (s // other) * L * other + s % other for s in range(nseq)]
+        kw = dict(group=other, group_stride=L * other, seq_stride=1, tok_stride=other)
+    else:
+        rows_of = [torch.arange(L) + s * L for s in range(nseq)]
+        kw = {}
+    q64 = qkv.double().requires_grad_(True)
+    _attention_fp64(q64, heads, rows_of).backward(d_o.double())
+    got = ops.attention_backward(qkv.to(DEV), d_o.to(DEV), heads, nseq, L, **kw).cpu().double()
+    err = (got - q64.grad).abs()
+    scale = float(q64.grad.abs().max())
+    print(f"attention backward L={L} d={d}: max {float(err.max()):.2e} mean {float(err.mean()):.2e} of scale {scale:.2e}")
+    assert float(err.max()) <= 4e-6 * scale + 1e-7 and float(err.mean()) <= 3e-7 * scale, (float(err.max()), float(err.mean()), scale)
+
+
+# (N, K): one shape per tile form of the split kernel - 256 x 256 (hands), 384 x 128 (body), 224 x 224 (face), 192 x 192 (a width
+# that only that tile divides), the 128 x 128 fallback with ragged edges - at a contraction that is not a multiple of anything
+@pytest.mark.parametrize("N,K,M", [(768, 256, 4696), (1152, 384, 4696), (672, 224, 4696), (192, 576, 4696), (200, 72, 4696),
+                                   (768, 256, 389)])          # (below 4096 rows: the 128 x 128 kernel whatever the width)
+@pytest.mark.parametrize("precision", ["bf16x3", "f32"])
+def test_weight_gradient_kernels_exact_on_integers_and_against_fp64(N, K, M, precision):
+    from pafuse_amd import ops
+    g = torch.Generator().manual_seed(N + K + M)
+    # small integers: every product and every partial sum is exact in fp32, whatever the order - any slip of a fragment
+    # layout, a tile edge or a split boundary shows as a wrong integer
+    dy = torch.randint(-3, 4, (M, N), generator=g).float()
+    x = torch.randint(-3, 4, (M, K), generator=g).float()
+    dw, db = ops.linear_weight_grad(dy.to(DEV), x.to(DEV), precision)
+    assert torch.equal(dw.cpu().double(), dy.double().t() @ x.double())
+    assert torch.equal(db.cpu().double(), dy.double().sum(0))
+    # 24-bit integers against powers of two: all three slices of an operand are needed
+    xi = torch.randint(-2 ** 23, 2 ** 23, (M, K), generator=g).float()
+    dp = torch.zeros(M, N)
+    dp[torch.arange(M), torch.randint(0, N, (M,), generator=g)] = 1.0      # one 1 per row: every sum has few terms... of one column
+    dp = dp * (2.0 ** torch.randint(-3, 4, (M, 1), generator=g).float())
+    if precision == "bf16x3":
+        dw2, _ = ops.linear_weight_grad(dp.to(DEV), xi.to(DEV), precision, bias=False)
+        want = dp.double().t() @ xi.double()
+        assert float((dw2.cpu().double() - want).abs().max()) <= 2.0 ** -20 * float(want.abs().max())
+    # random data against fp64
+    dy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g) * 2 + 0.5
+    dw, db = ops.linear_weight_grad(dy.to(DEV), x.to(DEV), precision)
+    want = dy.double().t() @ x.double()
+    err = (dw.cpu().double() - want).abs()
+    assert float(err.max()) <= 3e-6 * float(want.abs().max()) and float(err.mean()) <= 3e-7 * float(want.abs().max())
+    _close(db, dy.double().sum(0).float(), "db", rel=3e-6)
