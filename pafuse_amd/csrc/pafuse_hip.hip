@@ -381,6 +381,8 @@ int debug_f32_mask() {
 constexpr int debug_f32_mask() { return 0; }
 #endif
 
+// A/B build switch (tools/build_variant.py): workgroups per CU the 128 x 128 plain split tile is compiled for.  3 fits (152
+// registers, 43 KB of LDS) and measured slower: 98.5 - 100.2 us per fc1 launch against 95.7 - 97.3 at 2 (round 5, same GPU call).
 #ifndef PAFUSE_FC1_MINW
 #define PAFUSE_FC1_MINW 2
 #endif
@@ -1640,6 +1642,7 @@ int pafuse_attention_backward(const float* qkv, const float* d_o, float* dqkv, i
     StreamDevice on_stream_device(stream);
     if (!qkv || !d_o || !dqkv || nseq < 0 || heads <= 0 || C % heads || group <= 0 || L <= 0)
         return fail(PAFUSE_E_ARG, "attention_backward: bad argument");
+    if ((C / heads) % 4) return fail(PAFUSE_E_SHAPE, "attention_backward: head width %d must be a multiple of 4", C / heads);
     if (nseq == 0) return PAFUSE_OK;
     AttnBackwardParams ab{};
     ab.qkv = qkv, ab.d_o = d_o, ab.dqkv = dqkv, ab.nseq = nseq, ab.group = group, ab.group_stride = group_stride;
