@@ -248,6 +248,9 @@ class D3DP(nn.Module):
         P = noise.shape[2]
         if tuple(noise.shape) != (n_draws, B, P, self.frames, self.num_kps, 3):
             raise ValueError(f"noise draws have shape {tuple(noise.shape)}")
+        if B == 0:       # an empty batch: torch runs the reference on it and stacks T empty predictions (the draws above keep the
+            #              generator where the reference's torch.randn calls of zero elements leave it)
+            return torch.zeros((0, len(steps), P, self.frames, self.num_kps, 3), device=dev, dtype=torch.float32)
         per_clip = (2 if flip else 1) * P
         bc = max(1, self.max_rows_per_launch // per_clip)
         if B > bc:                                      # cut along the (independent) clip axis

@@ -28,6 +28,8 @@ def linear(x, weight, bias, act=None, bf16=False):
     _need(tuple(weight.shape) == (N, K) and bias.numel() == N, f"linear: x [..,{K}] needs weight [N,{K}] and bias [N]")
     x2 = x.contiguous().view(-1, K)
     out = torch.empty(x2.shape[0], N, device=x.device, dtype=torch.float32)
+    if x2.shape[0] == 0:      # no rows: nothing to launch (an empty tensor has no storage to point the library at)
+        return out.view(*x.shape[:-1], N)
     with torch.cuda.device(x.device):
         _lib.check(lib.pafuse_linear(_ptr(x2, "x"), _ptr(weight, "weight"), _ptr(bias, "bias"), out.data_ptr(),
                                      x2.shape[0], N, K, (1 if act == "gelu" else 0) | (2 if bf16 else 0), _stream(x)))
@@ -40,6 +42,8 @@ def layer_norm(x, weight, bias, eps):
     _need(weight.numel() == Cc and bias.numel() == Cc, f"layer_norm: weight and bias must have {Cc} elements")
     x2 = x.contiguous().view(-1, Cc)
     out = torch.empty_like(x2)
+    if x2.shape[0] == 0:
+        return out.view_as(x)
     with torch.cuda.device(x.device):
         _lib.check(lib.pafuse_layernorm(_ptr(x2, "x"), _ptr(weight, "w"), _ptr(bias, "b"), out.data_ptr(), x2.shape[0],
                                         Cc, eps, _stream(x)))
@@ -57,6 +61,8 @@ def attention(qkv, heads, nseq, L, group=1, group_stride=None, seq_stride=0, tok
         last = ((nseq - 1) // group) * gs + ((nseq - 1) % group) * seq_stride + (L - 1) * tok_stride
         _need(0 <= last < M and min(gs, seq_stride, tok_stride) >= 0, f"attention: sequences reach row {last} of {M}")
     o = torch.zeros(M, Cc, device=qkv.device, dtype=torch.float32)
+    if M == 0 or nseq == 0:
+        return o
     with torch.cuda.device(qkv.device):
         _lib.check(lib.pafuse_attention(_ptr(qkv, "qkv"), o.data_ptr(), nseq, L, Cc, heads, group,
                                         L if group_stride is None else group_stride, seq_stride, tok_stride,

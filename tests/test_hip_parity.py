@@ -1368,3 +1368,20 @@ def test_g18_mixste2_constructor_options_golden(mode):
     m.is_train, m.operand_bf16 = True, 0
     with pytest.raises(NotImplementedError, match="PAFUSE configuration"):
         m(z["x2d"].to(DEV), z["x3d"][:, 0].to(DEV), z["t"].to(DEV))
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "bf16x3_images", "f16x2"])
+def test_empty_inputs_give_empty_outputs(precision):
+    """torch runs the reference on an empty batch and returns an empty tensor (every reshape of diffusionpose.py / mixste.py keeps
+    a zero-sized batch axis); so do the modules and the unit entry points - no launch, no error."""
+    import __graft_entry__ as ge
+    from pafuse_amd import ops
+    model, _ = ge.make_model(3, 2, seed=51)
+    model.precision = precision
+    x2d = torch.zeros(0, 27, 134, 2, device=DEV)
+    out = model(x2d, None, input_2d_flip=x2d.clone())
+    assert tuple(out.shape) == (0, 2, 3, 27, 134, 3) and out.dtype == torch.float32
+    if precision == "f32":
+        assert tuple(ops.linear(torch.zeros(0, 64, device=DEV), torch.zeros(96, 64, device=DEV), torch.zeros(96, device=DEV)).shape) == (0, 96)
+        assert tuple(ops.layer_norm(torch.zeros(0, 64, device=DEV), torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 1e-6).shape) == (0, 64)
+        assert tuple(ops.attention(torch.zeros(0, 3 * 64, device=DEV), 8, 0, 5).shape) == (0, 64)
