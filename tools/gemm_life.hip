@@ -7,6 +7,7 @@
 #include <cstring>
 #include <vector>
 #include "../pafuse_amd/csrc/kernels.hpp"
+#include "../pafuse_amd/csrc/hgemm.hpp"   // the slab whole-row epilogue (epilogue_rows_h) the default path uses since round 5
 using namespace pafuse;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -95,31 +96,30 @@ int main() {
     CK(hipMemcpy(bias, h.data(), 1152 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(vec, h.data() + 5000, 1152 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(x, h.data(), Mmax * 384 * 4, hipMemcpyHostToDevice));
-    GemmParams p{};
-    p.A = A, p.W = W, p.bias = bias, p.out = out;
-    p.M = 25920, p.N = 1152, p.K = 384;
-    life<4, 1, 2, EPI_BIAS, 1>("body qkv <4,1,2> s1", p);
-    life<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body qkv SPLIT <4,1,4> s1", p);
-    life<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>("body qkv SPLIT <4,1,2> s1", p);
-    life<4, 1, 3, EPI_BIAS, 1, 1, 1>("body qkv <4,1,3> s1 TR", p);
-    p.N = 768, p.act = 1;
-    life<4, 1, 2, EPI_BIAS, 1>("body fc1+gelu <4,1,2> s1", p);
-    life<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>("body fc1+gelu SPLIT <4,1,4> s1", p);
-    GemmParams q{};
-    q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.out_n = xn;
-    q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f, q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
-    q.M = 25920, q.N = 384, q.K = 768;
-    life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body fc2 rowln SPLIT dma16 <2,2,6> st2", q);
-    life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body fc2 rowln <1,4,3> s1 TR", q);
-    q.K = 384;
-    life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2", q);
-    { GemmParams a = q; a.out_x = nullptr; a.out_n = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL no stores", a); }
-    { GemmParams a = q; a.post_w = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL no post LN", a); }
-    { GemmParams a = q; a.post_w = nullptr; a.next_w = nullptr; a.out_n = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL no LN at all", a); }
-    { GemmParams a = q; a.post_w = nullptr; a.next_w = nullptr; a.out_n = nullptr; a.out_x = nullptr; life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>("body proj rowln SPLIT dma16 <2,2,6> st2 ABL resid only", a); }
-    life<1, 4, 3, EPI_ROWLN, 1, 1, 1>("body proj rowln <1,4,3> s1 TR", q);
-    q.M = 73440, q.N = 224, q.K = 448;
-    life_dma<4, 1, 7, EPI_ROWLN, 2, 2, 16>("face fc2 rowln SPLIT dma16 <4,1,7> st2", q);
-    life<1, 7, 1, EPI_ROWLN, 1, 1, 1>("face fc2 rowln <1,7,1> s1 TR", q);
+    float* stats; CK(hipMalloc(&stats, Mmax * 2 * 4));
+    { std::vector<float> st(Mmax * 2); for (int64_t i = 0; i < Mmax; ++i) st[2 * i] = 0.f, st[2 * i + 1] = 1.f; CK(hipMemcpy(stats, st.data(), Mmax * 2 * 4, hipMemcpyHostToDevice)); }
+    // ---- round 5: the default path as it runs (LayerNorm folded: the plain GEMMs read (mean, rstd), the whole-row GEMMs write them and
+    // store the centred row through the slab epilogue), the three parts at P = 20 flip-TTA
+    struct Part { const char* name; int64_t M; int C; } parts[3] = {{"body", 25920, 384}, {"face", 73440, 224}, {"hands", 45360, 256}};
+    for (const Part& pt : parts) {
+        char tag[160];
+        GemmParams p{};
+        p.A = A, p.W = W, p.bias = bias, p.out = out, p.ln_in = stats, p.act = 1;
+        p.M = pt.M, p.N = 2 * pt.C, p.K = pt.C;
+        snprintf(tag, sizeof tag, "%s fc1 + GELU, folded LN, 128 x 128 SPLIT <4,1,4> (face: 128 x 64 <4,1,2>)", pt.name);
+        if (p.N % 128 == 0) life<4, 1, 4, EPI_BIAS, 1, 2, 0, 2>(tag, p);
+        else life<4, 1, 2, EPI_BIAS, 1, 4, 0, 2>(tag, p);
+        for (int which = 0; which < 2; ++which) {   // proj (K = C, next LayerNorm folded), fc2 (K = 2 C, post norm + next folded)
+            GemmParams q{};
+            q.A = A, q.W = W, q.bias = bias, q.resid = x, q.out_x = x, q.ln_stats = stats;
+            q.next_w = vec, q.next_b = vec, q.next_eps = 1e-6f;
+            if (which) q.post_w = vec, q.post_b = vec, q.post_eps = 1e-6f;
+            q.M = pt.M, q.N = pt.C, q.K = which ? 2 * pt.C : pt.C;
+            snprintf(tag, sizeof tag, "%s %s whole-row, slab epilogue, centred store", pt.name, which ? "fc2" : "proj");
+            if (pt.C == 384) life_dma<2, 2, 6, EPI_ROWLN, 2, 2, 16>(tag, q);
+            else if (pt.C == 256) life_dma<2, 2, 4, EPI_ROWLN, 2, 2, 16>(tag, q);
+            else life_dma<4, 1, 7, EPI_ROWLN, 2, 2, 16>(tag, q);
+        }
+    }
     return 0;
 }
