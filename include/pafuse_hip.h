@@ -61,14 +61,17 @@ typedef struct pafuse_block_weights {
      * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv), 1 (proj, fc2), 0 (fc1) -
      * mode 3: with PAFUSE_SPLIT_F16X2 - (a cache - remake after a weight changes); NULL otherwise */
     const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
-    /* split-precision mode, optional: LayerNorm folded into the GEMM that consumes it (all four set, in every block of a
-     * denoiser, or none).  With them set, qkv_ws / fc1_ws must be the images of W (.) g - the weight scaled along its
+    /* split-precision modes, optional: LayerNorm folded into the GEMM that consumes it (qkv_lt and fc1_lt set, in every block
+     * of a denoiser, or neither).  With them set, qkv_ws / fc1_ws must be the images of W (.) g - the weight scaled along its
      * input axis by norm1 / norm2's weight g - and
-     *   qkv_ls[n] = sum_k g_k W_nk,   qkv_lt[n] = sum_k beta_k W_nk + b_n     (norm1 -> qkv; fc1_* likewise with norm2)
-     * formed in fp64 and rounded once.  The whole-row kernels then emit a row's (mean, rstd) instead of the normalised
-     * row, and qkv / fc1 read the un-normalised row and apply rstd (acc - mean ls) + lt in their epilogue: the same
-     * function as LN(x) W^T + b (common/mixste.py:113-116) with one [M,C] store and one normalise pass less per
-     * whole-row launch.  pafuse_block_forward ignores them (it is handed a normalised-input-free block). */
+     *   qkv_lt[n] = sum_k beta_k W_nk + b_n     (norm1 -> qkv; fc1_lt likewise with norm2)
+     * formed in fp64 and rounded once.  The whole-row kernels then store the residual stream CENTRED on its row mean
+     * (x - mean(x): every reader of the stream is a LayerNorm or the residual add that feeds one, and LayerNorm does not see
+     * a row's mean) and emit the row's (mean, rstd) instead of the normalised row; qkv / fc1 read the centred row and apply
+     * rstd acc + lt in their epilogue: the same function as LN(x) W^T + b (common/mixste.py:113-116) with one [M,C] store
+     * and one normalise pass less per whole-row launch, and nothing that cancels on rows whose mean is large against their
+     * spread.  qkv_ls / fc1_ls (sum_k g_k W_nk: round 3's uncentred form) are not read any more; leave them NULL.
+     * pafuse_block_forward ignores the fold (it is handed a normalised-input-free block). */
     const float *qkv_ls, *qkv_lt, *fc1_ls, *fc1_lt;
     /* split-precision mode, optional: the qkv projection and the attention of a block in ONE kernel (fqa_kernel: one
      * workgroup = whole sequences x one head; q, k, v never reach memory).  qkv_hs is the layout-2 image of the HEAD-MAJOR
@@ -95,20 +98,21 @@ typedef struct pafuse_block_weights {
  * `depth` temporal blocks, `heads` heads (C % heads == 0), mlp hidden = 2C unless mlp_hidden says otherwise. */
 typedef struct pafuse_mixste2_weights {
     int32_t frames, joints, channels, depth, heads, in_chans; /* in_chans must be 5 (2-D + 3-D) */
-    int32_t operand_bf16; /* matrix-product mode of the linear layers (activations, LayerNorm, softmax, attention and
-                             everything in memory are fp32 in every mode):
+    int32_t operand_bf16; /* matrix-product mode of the linear layers (LayerNorm, softmax and the attention arithmetic are fp32 in
+                             every mode, and so is everything in memory except the operand images of modes 3 and 4;
+                             pafuse_amd.D3DP's default is 2):
                              0: fp32-input matrix cores (v_mfma_f32_32x32x2_f32): a k-ordered fp32 FMA chain.
                              2: split precision "bf16x3": every fp32 operand is the exact sum of three bf16 slices,
                                 products keep the six terms above 2^-24 relative on the bf16 matrix cores with fp32
                                 accumulation - fp32-equivalent results (closer to exact arithmetic than the FMA
                                 chain) at 2.7x the matrix rate.  Inference entry points need the *_ws weight images;
-                                the training entry points do not (they split the weight a GEMM is about to read
-                                themselves - weights change every step) and run every GEMM of the step this way.
+                                the training entry points do not (weights change every step: each pass makes the images
+                                of its weights itself, in one launch) and run every GEMM of the step this way.
                              3: split precision "f16x2" (inference only): activations as two fp16 slices, weights as two
                                 stored + one derived (PAFUSE_SPLIT_F16X2 images in *_ws), three products per k on the fp16
                                 matrix cores - fp32-equivalent results at 5.3x the fp32 matrix rate.
-                             4: split precision "bf16x3" on the image pipeline (round 5, inference only; the default of the
-                                part-based model): the arithmetic of mode 2 - every operand the exact sum of three bf16 slices,
+                             4: split precision "bf16x3" on the image pipeline (round 5, inference only, opt-in: it measures
+                                85 hypotheses/s against mode 2's 100): the arithmetic of mode 2 - every operand the exact sum of three bf16 slices,
                                 the six products above 2^-24 relative, fp32 accumulation - with both GEMM operands as pre-split
                                 "X images" (PAFUSE_SPLIT_X images in *_ws / qkv_hs; activations split once by their producer),
                                 qkv + attention fused in every block (qkv_hs, qkv_hb required), and - with the LayerNorm

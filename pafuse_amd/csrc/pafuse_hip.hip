@@ -651,7 +651,7 @@ PartBuffers offset_rows(const PartBuffers& pb, int64_t row0, int C) {
     return o;
 }
 
-static bool ln_folded(const pafuse_mixste2_weights* w) { return w->ste[0].qkv_ls != nullptr; }
+static bool ln_folded(const pafuse_mixste2_weights* w) { return w->ste[0].qkv_lt != nullptr; }   // (qkv_ls / fc1_ls: round 3's uncentred form, not read)
 // f16x2 with the LayerNorm folded: the residual stream between the blocks lives in memory as its H image only
 static bool h_residual_only(const pafuse_mixste2_weights* w) { return w->operand_bf16 >= 3 && ln_folded(w) && !w->keep_f32_residual; }
 
@@ -693,13 +693,13 @@ int check_weights(const pafuse_mixste2_weights* w, bool training = false) {
                 if ((!b->qkv_ws && w->operand_bf16 != 4) || !b->proj_ws || !b->fc1_ws || !b->fc2_ws)   // (mode 4 multiplies qkv_hs only)
                     return fail(PAFUSE_E_ARG, "split-precision mode needs the pre-split image of every linear weight "
                                               "(pafuse_split_weights)");
-    // a folded LayerNorm (pafuse_block_weights.qkv_ls ...) is a property of the whole denoiser: the producer of a block's
+    // a folded LayerNorm (pafuse_block_weights.qkv_lt, fc1_lt) is a property of the whole denoiser: the producer of a block's
     // statistics is the block before it
     const bool fold = ln_folded(w);
     for (int i = 0; i < w->depth; ++i)
         for (const pafuse_block_weights* b : {&w->ste[i], &w->tte[i]}) {
-            const int set = (b->qkv_ls != nullptr) + (b->qkv_lt != nullptr) + (b->fc1_ls != nullptr) + (b->fc1_lt != nullptr);
-            if (set != (fold ? 4 : 0)) return fail(PAFUSE_E_ARG, "folded-LayerNorm vectors must be set in every block or in none");
+            const int set = (b->qkv_lt != nullptr) + (b->fc1_lt != nullptr);
+            if (set != (fold ? 2 : 0)) return fail(PAFUSE_E_ARG, "folded-LayerNorm vectors (qkv_lt, fc1_lt) must be set in every block or in none");
         }
     if (fold && w->operand_bf16 < 2) return fail(PAFUSE_E_ARG, "the folded LayerNorm exists in the split-precision modes only");
     return PAFUSE_OK;
