@@ -58,7 +58,7 @@ typedef struct pafuse_block_weights {
     const float *fc1_w, *fc1_b;     /* [H,C], [H]   (H = mlp hidden width, 2C by default) */
     const float *fc2_w, *fc2_b;     /* [C,H], [C] */
     /* split-precision modes only (pafuse_mixste2_weights.operand_bf16 == 2 or 3): the pre-split images of the four linear
-     * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv), 1 (proj, fc2), 0 (fc1) -
+     * weights, made by pafuse_split_weights from the fp32 tensors above with layout 2 (qkv, fc1), 1 (proj, fc2) -
      * mode 3: with PAFUSE_SPLIT_F16X2 - (a cache - remake after a weight changes); NULL otherwise */
     const void *qkv_ws, *proj_ws, *fc1_ws, *fc2_ws;
     /* split-precision modes, optional: LayerNorm folded into the GEMM that consumes it (qkv_lt and fc1_lt set, in every block
@@ -177,7 +177,7 @@ const char *pafuse_last_error(void);
 /* Layout version of the structs above (bumped whenever a field is added, moved or removed: this header has no size fields).
  * A caller built against another header gets shifted pointers, not an error - compare with PAFUSE_ABI_VERSION at load time
  * (pafuse_amd/_lib.py does; tests/cabi/linear_smoke.c shows the C side). */
-#define PAFUSE_ABI_VERSION 5
+#define PAFUSE_ABI_VERSION 6
 int pafuse_abi_version(void);
 
 /* out[M,N] = act(A[M,K] @ W[N,K]^T + bias), act: 0 none, 1 exact-erf GELU; +2: bf16 operands (see operand_bf16).
@@ -188,9 +188,9 @@ int pafuse_linear(const float *A, const float *W, const float *bias, float *out,
 /* Split-precision weight image: W [N,K] fp32 (K % 32 == 0) -> `out`, pafuse_split_weights_bytes(N, K) = 6*N*K bytes
  * ([K/c][N][6c B] with c = 32 or 16: per row and K chunk, sub-blocks of 8 k x 3 bf16 slices, laid out as the kernels'
  * LDS image).  `layout` names the layer the image is for - it decides c and the rotation of the sub-blocks inside a row:
- *   0  mlp.fc1 (and pafuse_linear_split without PAFUSE_LINEAR_QKV_IMAGE): the 32x32x16-MFMA plain kernel
+ *   0  pafuse_linear_split without PAFUSE_LINEAR_QKV_IMAGE: the 32x32x16-MFMA plain kernel (mlp.fc1 until ABI 5)
  *   1  attn.proj, mlp.fc2: the whole-row kernels (c = 16 at the widths that have an LDS-DMA tile)
- *   2  attn.qkv: the 16x16x32-MFMA kernel (pafuse_block_weights.qkv_ws must be made with layout 2)
+ *   2  attn.qkv, mlp.fc1: the 16x16x32-MFMA kernels (pafuse_block_weights.qkv_ws and - since ABI 6 - fc1_ws must be made with layout 2)
  * pafuse_linear_split is pafuse_linear on such an image (act: 0 none, 1 GELU, + PAFUSE_LINEAR_QKV_IMAGE when the image
  * has layout 2): the unit entry of the split-precision products, which replace the same nn.Linear call sites
  * (common/mixste.py:38-42,65,80). */

@@ -122,9 +122,9 @@ SIGNATURES = {
 
 _lib = None
 
-ABI_VERSION = 5      # include/pafuse_hip.h PAFUSE_ABI_VERSION: the struct layouts mirrored above
+ABI_VERSION = 6      # include/pafuse_hip.h PAFUSE_ABI_VERSION: the struct layouts mirrored above
 
-KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/hgemm.hpp", "pafuse_amd/csrc/xgemm.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
+KERNEL_SOURCES = ("pafuse_amd/csrc/kernels.hpp", "pafuse_amd/csrc/hgemm.hpp", "pafuse_amd/csrc/xgemm.hpp", "pafuse_amd/csrc/sgemm.hpp", "pafuse_amd/csrc/train_kernels.hpp", "pafuse_amd/csrc/pafuse_hip.hip",
                   "pafuse_amd/csrc/train_host.inc", "include/pafuse_hip.h")
 
 

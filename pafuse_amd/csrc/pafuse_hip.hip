@@ -14,6 +14,7 @@
 #include "kernels.hpp"
 #include "hgemm.hpp"
 #include "xgemm.hpp"
+#include "sgemm.hpp"
 #include "train_kernels.hpp"
 
 using namespace pafuse;
@@ -237,6 +238,62 @@ int launch_gemm16(const GemmParams& p, hipStream_t s) {
     return check_launch("gemm16_kernel");
 }
 
+// ---- the strip GEMM (sgemm.hpp, round 6): the plain split-precision layers (qkv, fc1) on the software-pipelined persistent kernel.
+// A launch is STRIP_WGS_PER_CU workgroups per CU (two fit: 68 - 80 KB of LDS each) walking the tile stream; fewer tiles than slots
+// = one workgroup per tile.  The CU count is the current device's (cached per device).
+#ifndef PAFUSE_STRIP_WGS_PER_CU
+#define PAFUSE_STRIP_WGS_PER_CU 2
+#endif
+int device_cus() {
+    static int cus[DeviceOnce::MAX_DEV] = {};
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= DeviceOnce::MAX_DEV) return 256;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        cus[d] = n;
+    }
+    return cus[d];
+}
+
+template <int NB, int FLAGS>
+int launch_strip2(const GemmParams& p, hipStream_t s) {
+    constexpr int RG = 2, NW = 4;
+    using T = StripTile<NB, RG, NW, 2>;
+    static_assert(T::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    if (!p.Wsplit) return fail(PAFUSE_E_ARG, "split-precision GEMM without a pre-split weight image");
+    auto k = sgemm2_kernel<NB, RG, NW, SEPI_BIAS, 2, FLAGS>;
+    static DeviceOnce once;
+    if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)T::LDS_BYTES);
+    const int64_t tiles = ((p.M + T::BM - 1) / T::BM) * (p.N / T::BN);
+    if (tiles <= 0 || tiles > 0x7fffffff) return fail(PAFUSE_E_ARG, "gemm grid out of range");
+    int64_t grid = (int64_t)device_cus() * PAFUSE_STRIP_WGS_PER_CU / 8 * 8;   // a multiple of 8: virtual workgroup v = b + j grid keeps b's XCD
+    if (grid >= tiles || grid <= 0) grid = tiles;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(T::NTHR), T::LDS_BYTES, s, p);
+    return check_launch("sgemm2_kernel");
+}
+// which plain layers the strip kernel takes: an M16 image, no training epilogue options, at least four 32-deep chunks (the deferred
+// stores of a tile go out inside the first four chunks of the next one), a column count one of its tiles divides
+bool strip2_ok(const GemmParams& p) {
+    return p.bf16 == 2 && p.wlayout == 2 && !p.out_act && !p.dact_u && p.K % 32 == 0 && p.K >= 128 && p.M > 0 &&
+           (p.N % 128 == 0 || p.N % 112 == 0 || p.N % 96 == 0);
+}
+template <int NB>
+int launch_strip2_flags(const GemmParams& p, hipStream_t s) {
+    const int flags = (p.ln_in ? 1 : 0) | (p.act ? 2 : 0);
+    switch (flags) {
+        case 0: return launch_strip2<NB, 0>(p, s);
+        case 1: return launch_strip2<NB, 1>(p, s);
+        case 2: return launch_strip2<NB, 2>(p, s);
+        default: return launch_strip2<NB, 3>(p, s);
+    }
+}
+int strip2_bias(const GemmParams& p, hipStream_t s) {
+    if (p.N % 128 == 0) return launch_strip2_flags<8>(p, s);    // body 1152 / 768, hands 768 / 512: 128 x 128
+    if (p.N % 112 == 0) return launch_strip2_flags<7>(p, s);    // face 672 / 448: 128 x 112
+    return launch_strip2_flags<6>(p, s);                         // 128 x 96 (the single-model variant: 864 = 9 x 96)
+}
+
 // split-precision GEMM, LDS-DMA pipelined form (one workgroup per CU, NSTAGE ring of 32-deep chunks)
 // K-chunk depth of the pre-split image of a weight (the image format is a property of the weight, fixed when it is
 // split, so every launch on it - any M - must use a kernel of that depth): the whole-row layers of widths 384, 288, 256
@@ -408,7 +465,10 @@ int gemm_bias(const GemmParams& p0, hipStream_t s) {
 #ifdef PAFUSE_QKV_32X32   // A/B build (tools/): the qkv layers on the 32x32x16 tiles, their images in layout 0
     p.wlayout = 0;
 #endif
-    if (p.bf16 == 2 && p.wlayout == 2) {  // the qkv layers: 16x16x32 MFMAs on the M16 image (3 - 10 % per launch, kernels.hpp)
+#ifndef PAFUSE_NO_STRIP
+    if (strip2_ok(p)) return strip2_bias(p, s);   // qkv, fc1 (+ GELU): the pipelined persistent strip kernel (sgemm.hpp; same bits as gemm16_tile)
+#endif
+    if (p.bf16 == 2 && p.wlayout == 2) {  // 16x16x32 MFMAs on the M16 image (kernels.hpp gemm16_tile): training's epilogue options, short K
         if (p.N % 128 == 0) return launch_gemm16<8, 3>(p, s);    // body 1152, hands 768: 128 x 128 tiles, 3 workgroups per CU
         if (p.N % 96 == 0) return launch_gemm16<6, 3>(p, s);     // face 672, single-model 864: 128 x 96
         if (p.N % 112 == 0) return launch_gemm16<7, 3>(p, s);    // face 224, 448 (training: every plain GEMM of the face): 128 x 112
@@ -785,7 +845,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     // h = GELU(xn W1^T + b1)                                                            mixste.py:38-39
     GemmParams& f1 = b.fc1;
     f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = hidden, f1.K = C, f1.act = 1;
-    f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws;
+    f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws, f1.wlayout = 2;   // (round 6: fc1 images are in the M16 layout too)
     if (fold) f1.A = pb.x, f1.ln_in = stats, f1.ln_s = bw.fc1_ls, f1.bias = bw.fc1_lt;
     if (hp) f1.Ah = xn_h, f1.Wh = (const uint8_t*)bw.fc1_ws, f1.out_h = reinterpret_cast<uint8_t*>(pb.wide);
     if (fold) f1.ln_s = nullptr;

@@ -410,7 +410,7 @@ def fill_weights_struct(w, get, freqs, frames, joints, channels, depth, heads, i
                 setattr(dst[i], field, vec.data_ptr() if vec is not None else None)
 
 
-LAYOUT_OF = {"attn.qkv.weight": 2, "attn.proj.weight": 1, "mlp.fc2.weight": 1, "mlp.fc1.weight": 0}
+LAYOUT_OF = {"attn.qkv.weight": 2, "attn.proj.weight": 1, "mlp.fc2.weight": 1, "mlp.fc1.weight": 2}     # (round 6: fc1 runs the 16x16x32 kernels, its image is the M16 one like qkv's)
 
 
 def image_layout(name):

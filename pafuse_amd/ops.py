@@ -126,7 +126,7 @@ def block_forward(block_params, x, heads=8, precision="f32"):
         mode = 2
     if mode >= 2:
         for field, lin, layout in (("qkv_ws", block_params.attn.qkv, 2), ("proj_ws", block_params.attn.proj, 1),
-                                   ("fc1_ws", block_params.mlp.fc1, 0), ("fc2_ws", block_params.mlp.fc2, 1)):
+                                   ("fc1_ws", block_params.mlp.fc1, 2), ("fc2_ws", block_params.mlp.fc2, 1)):
             if mode == 4 and field == "qkv_ws":
                 continue
             images.append(split_image(lin.weight, layout, mode == 3, mode == 4))

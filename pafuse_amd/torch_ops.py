@@ -253,7 +253,7 @@ def block(x: torch.Tensor, weights: List[torch.Tensor], heads: int, precision: s
     if mode == 4 and not lib.pafuse_mode_supported(4, Cc, 0, heads, L, L):
         mode = 2
     if mode in (2, 3, 4):
-        for field, idx, layout in (("qkv_ws", 2, 2), ("proj_ws", 4, 1), ("fc1_ws", 8, 0), ("fc2_ws", 10, 1)):
+        for field, idx, layout in (("qkv_ws", 2, 2), ("proj_ws", 4, 1), ("fc1_ws", 8, 2), ("fc2_ws", 10, 1)):
             if mode == 4 and field == "qkv_ws":
                 continue
             images.append(cached_split_image(weights[idx], layout, mode == 3, mode == 4))
