@@ -77,7 +77,7 @@ typedef struct pafuse_block_weights {
      * workgroup = whole sequences x one head; q, k, v never reach memory).  qkv_hs is the layout-2 image of the HEAD-MAJOR
      * qkv weight: for head h = 0 .. heads-1 the d rows of q_h, then zero rows up to DP, then k_h and v_h likewise
      * (DP = 32 for head dim d <= 32, else 48; [heads * 3 * DP, C] in all) - of W (.) g when the LayerNorm is folded;
-     * qkv_hb [heads * 3 * DP] is the bias (folded: qkv_lt) and qkv_hl the folded qkv_ls in that row order, zeros in the
+     * qkv_hb [heads * 3 * DP] is the bias (folded: qkv_lt) in that row order (qkv_hl: round 3's uncentred term, not read - leave it NULL), zeros in the
      * padding.  Used when set and the sequence length has a fused form (L <= 48; in f16x2 mode L <= 80 at head dim <= 32:
      * the 68 joints of the face); otherwise, and for
      * pafuse_block_forward, the block runs qkv GEMM + attention from qkv_ws.  Same arithmetic per product and the same

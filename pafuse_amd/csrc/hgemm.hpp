@@ -116,16 +116,17 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) s += acc[nt][i];
-        const float mean = row_total(s, slot) * invC;
+        float mean = row_total(s, slot) * invC;
+                asm volatile("" : "+v"(mean));   // ONE rounded value: `x - mean` below must not contract into an fma on the unrounded product (HIP's __fmul_rn is a plain multiply)
         float qv = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float d = acc[nt][i] - mean;
-                qv += d * d;
+                qv = fmaf(d, d, qv);   // (explicit fma: both whole-row epilogues contract alike - the same bits on every launch route)
             }
-        const float rstd = 1.0f / sqrtf(row_total(qv, slot + 1) * invC + eps);
+        const float rstd = 1.0f / sqrtf(fmaf(row_total(qv, slot + 1), invC, eps));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -133,7 +134,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                 const int n = nb + 32 * nt + 8 * q;
                 const f32x4 g4 = vec4(vslot, n), b4 = vec4(vslot + 1, n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
+                for (int e = 0; e < 4; ++e) acc[nt][4 * q + e] = fmaf((acc[nt][4 * q + e] - mean) * rstd, g4[e], b4[e]);
             }
     };
 
@@ -284,16 +285,17 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) s += acc[nt][i];
-                const float mean = row_total(s, 2) * invC;
+                float mean = row_total(s, 2) * invC;
+                asm volatile("" : "+v"(mean));   // ONE rounded value: `x - mean` below must not contract into an fma on the unrounded product (HIP's __fmul_rn is a plain multiply)
                 float qv = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const float d = acc[nt][i] - mean;
-                        qv += d * d;
+                        qv = fmaf(d, d, qv);   // (explicit fma: both whole-row epilogues contract alike - the same bits on every launch route)
                     }
-                const float rstd = 1.0f / sqrtf(row_total(qv, 3) * invC + p.next_eps);
+                const float rstd = 1.0f / sqrtf(fmaf(row_total(qv, 3), invC, p.next_eps));
                 if (live && h == 0 && wn == 0) {
                     p.ln_stats[2 * m] = mean;
                     p.ln_stats[2 * m + 1] = rstd;
@@ -321,7 +323,7 @@ __device__ __forceinline__ void epilogue_rows_h(f32x16 (&acc)[NT], const GemmPar
                     for (int q = 0; q < 4; ++q) {
                         const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + nb + 32 * nt + 8 * q);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s += acc[nt][4 * q + e] * hw[e];
+                        for (int e = 0; e < 4; ++e) s = fmaf(acc[nt][4 * q + e], hw[e], s);
                     }
                 s = row_total(s, 4 + k);
                 if (live && h == 0 && wn == 0) p.out_head[m * 3 + k] = s + p.head_b[k];

@@ -383,9 +383,9 @@ struct GemmParams {
     // LayerNorm folded into the consumer GEMM (split-precision inference only; run_blocks sets these up):
     //   producer (EPI_ROWLN with ln_stats): the NEXT LayerNorm of the chain is not applied; the row's (mean, rstd) go to
     //     ln_stats[m][2] and out_n is not written - one [M,C] store and one normalise pass less per whole-row launch;
-    //   consumer (EPI_BIAS with ln_in): A is the un-normalised row x, Wsplit the image of W (.) g (g = the LayerNorm's
-    //     weight, scaled along k), ln_s[n] = sum_k g_k W_nk, bias[n] = sum_k beta_k W_nk + b_n (both formed in fp64), and
-    //     out = act(rstd_m * (acc - mean_m * ln_s[n]) + bias[n])  ==  act(LN(x) W^T + b) up to rounding.
+    //   consumer (EPI_BIAS with ln_in): A is the row CENTRED on its mean, x - mean(x) (what the producer stores since round 5), Wsplit the
+    //     image of W (.) g (g = the LayerNorm's weight, scaled along k), bias[n] = sum_k beta_k W_nk + b_n (formed in fp64), and
+    //     out = act(rstd_m * acc + bias[n])  ==  act(LN(x) W^T + b) up to rounding.  (ln_s: round 3's uncentred term, never read.)
     float* ln_stats;
     const float* ln_in;
     const float* ln_s;
@@ -533,16 +533,17 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s += acc[nt][i];
-            const float mean = row_total(s, slot) * invC;
+            float mean = row_total(s, slot) * invC;
+                asm volatile("" : "+v"(mean));   // ONE rounded value: `x - mean` below must not contract into an fma on the unrounded product (HIP's __fmul_rn is a plain multiply)
             float qv = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float d = acc[nt][i] - mean;
-                    qv += d * d;
+                    qv = fmaf(d, d, qv);   // (explicit fma: both whole-row epilogues contract alike - the same bits on every launch route)
                 }
-            const float rstd = 1.0f / sqrtf(row_total(qv, slot + 1) * invC + eps);
+            const float rstd = 1.0f / sqrtf(fmaf(row_total(qv, slot + 1), invC, eps));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -552,7 +553,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                     const f32x4 b4 = vec4(gb, vslot + 1, n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc[nt][4 * q + e] = (acc[nt][4 * q + e] - mean) * rstd * g4[e] + b4[e];
+                        acc[nt][4 * q + e] = fmaf((acc[nt][4 * q + e] - mean) * rstd, g4[e], b4[e]);
                 }
         };
         float rs = 1.0f;
@@ -623,16 +624,17 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s += acc[nt][i];
-            const float mean = row_total(s, 2) * invC;
+            float mean = row_total(s, 2) * invC;
+                asm volatile("" : "+v"(mean));   // ONE rounded value: `x - mean` below must not contract into an fma on the unrounded product (HIP's __fmul_rn is a plain multiply)
             float qv = 0.f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float d = acc[nt][i] - mean;
-                    qv += d * d;
+                    qv = fmaf(d, d, qv);   // (explicit fma: both whole-row epilogues contract alike - the same bits on every launch route)
                 }
-            const float rstd = 1.0f / sqrtf(row_total(qv, 3) * invC + p.next_eps);
+            const float rstd = 1.0f / sqrtf(fmaf(row_total(qv, 3), invC, p.next_eps));
             if (live && h == 0 && wn == 0) {
                 p.ln_stats[2 * m] = mean;
                 p.ln_stats[2 * m + 1] = rstd;
@@ -676,7 +678,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + nb + 32 * nt + 8 * q);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) s += acc[nt][4 * q + e] * hw[e];
+                            for (int e = 0; e < 4; ++e) s = fmaf(acc[nt][4 * q + e], hw[e], s);
                         }
                     s = row_total(s, 4 + k);
                     if (live && h == 0 && wn == 0) p.out_head[m * 3 + k] = s + p.head_b[k];

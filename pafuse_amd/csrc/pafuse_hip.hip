@@ -568,8 +568,10 @@ bool group_ok_rowln(const GemmParams& p) {
     return p.bf16 == 2 && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 && p.K > 0 &&
            !(debug_f32_mask() & 2);
 }
-bool group_ok_bias(const GemmParams& p) {
-    return p.bf16 == 2 && p.Wsplit && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 && !(debug_f32_mask() & 29);
+bool group_ok_bias(const GemmParams& p) {   // (layout-0 images only: the shared plain grid is the 32x32x16 tile; since round 6 qkv AND fc1 carry M16
+    //                                             images and go part by part through the persistent strip kernel, which fills the chip alone)
+    return p.bf16 == 2 && p.Wsplit && p.wlayout == 0 && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 &&
+           !(debug_f32_mask() & 29);
 }
 // (whether the parts of a configuration share grids is the caller's choice per call: pafuse_d3dp_config.part_by_part_launches -
 // same tiles, same arithmetic, same bits either way; there is no process-wide schedule state)
@@ -804,7 +806,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     GemmParams& g = b.qkv;
     g.A = pb.xn, g.W = bw.qkv_w, g.bias = bw.qkv_b, g.out = pb.wide, g.M = M, g.N = 3 * C, g.K = C, g.act = 0;
     g.bf16 = bf16, g.Wsplit = (const uint8_t*)bw.qkv_ws, g.wlayout = 2;   // qkv images are in the M16 layout (include/pafuse_hip.h)
-    if (fold) g.A = pb.x, g.ln_in = stats, g.ln_s = bw.qkv_ls, g.bias = bw.qkv_lt;
+    if (fold) g.A = pb.x, g.ln_in = stats, g.bias = bw.qkv_lt;
     if (hp) g.Ah = xn_h, g.Wh = (const uint8_t*)bw.qkv_ws;
     if (fold) g.ln_s = nullptr;   // x (its image; mode 2: its fp32 rows) is stored centred on the row mean: rstd acc + lt, no mean term
     AttnParams& a = b.attn;
@@ -814,7 +816,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     if (hp) a.o_h = reinterpret_cast<uint8_t*>(pb.o);
     // the two in one kernel where a head-major image was supplied and the shape has a fused form
     b.fused = false;
-    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && (bf16 == 4 ? xfqa_has(L, C / heads, heads) : fqa_has(L, C / heads, bf16)) && (!fold || bw.qkv_hl || bf16 == 4)) {
+    if (bf16 >= 2 && bw.qkv_hs && bw.qkv_hb && (bf16 == 4 ? xfqa_has(L, C / heads, heads) : fqa_has(L, C / heads, bf16))) {   // (qkv_hl, round 3's uncentred term, is not read: not required)
         const int lp = fqa_lp(L, bf16), dp = fqa_dp(C / heads);
         FqaParams& f = b.fqa;
         f.g = g;
@@ -846,7 +848,7 @@ BlockLaunch make_block(const pafuse_block_weights& bw, const PartBuffers& pb, in
     GemmParams& f1 = b.fc1;
     f1.A = pb.xn, f1.W = bw.fc1_w, f1.bias = bw.fc1_b, f1.out = pb.wide, f1.M = M, f1.N = hidden, f1.K = C, f1.act = 1;
     f1.bf16 = bf16, f1.Wsplit = (const uint8_t*)bw.fc1_ws, f1.wlayout = 2;   // (round 6: fc1 images are in the M16 layout too)
-    if (fold) f1.A = pb.x, f1.ln_in = stats, f1.ln_s = bw.fc1_ls, f1.bias = bw.fc1_lt;
+    if (fold) f1.A = pb.x, f1.ln_in = stats, f1.bias = bw.fc1_lt;
     if (hp) f1.Ah = xn_h, f1.Wh = (const uint8_t*)bw.fc1_ws, f1.out_h = reinterpret_cast<uint8_t*>(pb.wide);
     if (fold) f1.ln_s = nullptr;
     // x = post(x + h W2^T + b2) [+ pos] ; xn = next(x) | head                           mixste.py:41,115,243,250,257
@@ -1124,7 +1126,7 @@ int pafuse_mixste2_fused_blocks(const pafuse_mixste2_weights* w) {
         for (int k = 0; k < 2; ++k)   // the condition of make_block, plus the tile-capacity check it makes
             if (w->operand_bf16 >= 2 && pair[k]->qkv_hs && pair[k]->qkv_hb &&
                 (w->operand_bf16 == 4 ? xfqa_has(len[k], d, w->heads) : fqa_has(len[k], d, w->operand_bf16)) &&
-                (!fold || pair[k]->qkv_hl || w->operand_bf16 == 4)) {
+                true) {   // (no qkv_hl requirement: nothing reads it since the centred fold of round 5)
                 const int lp = fqa_lp(len[k], w->operand_bf16);
                 n += (fqa_nseq_tile(len[k], lp) * len[k] <= fqa_tile_rows(lp)) ? 1 : 0;
             }

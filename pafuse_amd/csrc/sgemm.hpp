@@ -335,19 +335,31 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm_kernel(const GemmParams p
 #define SGEMM_PIN_ACC(A) asm volatile("" : "+v"(A))
 #define SGEMM_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
 
-// FLAGS (compile-time, so that the epilogue is straight-line code with every load issued up front): bit 0 = folded LayerNorm
-// (p.ln_in), bit 1 = GELU (p.act)
-template <int NB, int RG, int NW, int EPI, int MINW, int FLAGS>
+// FLAGS (compile-time, so that the epilogue is straight-line code with every load issued up front):
+//   EPI = SEPI_BIAS :  bit 0 = folded LayerNorm (p.ln_in), bit 1 = GELU (p.act)
+//   EPI = SEPI_ROWLN:  bit 0 = a post LayerNorm (p.post_w: fc2), bit 1 = the head form (p.out_head: the last block) instead of the
+//                      folded statistics + centred store
+// SEPI_ROWLN (the workgroup's tile is BM whole rows, BN == p.N; inference with the LayerNorm folded into the consumer, GemmParams):
+//   y = acc + bias + resid ;  z = POST ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;
+//   folded: (mean, rstd) of z -> ln_stats[m], out_x = z - mean      |  HEAD: n = LN(z; next), out_head = n head_w^T + head_b
+// All of it in registers: a token's row of the tile sits in the four lanes (c, qd = 0..3) of one wave.  The residual rows are
+// loaded into `fin` at the end of the tile (its previous contents left in the first chunks); bias / post_w / post_b are staged once per
+// workgroup in LDS behind the ring.  (Prefetching the residual rows inside the last chunks was tried first: hipcc either folds the
+// per-chunk if-chain into a dynamically indexed store - `fin` in scratch - or waits vmcnt(0) behind every load.)
+template <int NB, int RG, int NW, int EPI, int MINW, int FLAGS, int SPC = 4>
 __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams p) {
-    constexpr bool LNIN = (FLAGS & 1) != 0, ACT = (FLAGS & 2) != 0;
+    constexpr bool ROWLN = EPI == SEPI_ROWLN;
+    constexpr bool LNIN = !ROWLN && (FLAGS & 1) != 0, ACT = !ROWLN && (FLAGS & 2) != 0;
+    constexpr bool POST = ROWLN && (FLAGS & 1) != 0, HEAD = ROWLN && (FLAGS & 2) != 0;
     PAFUSE_XQ_GUARD();
     using T = StripTile<NB, RG, NW, 2>;
     constexpr int BM = T::BM, BN = T::BN, IA = T::IA, IW = T::IW, IWT = T::IWT;
     constexpr int TOT = NB * RG * 6;          // MFMAs (= filler slots) of a chunk
     constexpr int NSPLIT = RG * 4 * 5;        // split stage-steps of one chunk's A fragments (4 pairs x 5 stages per row group)
-    constexpr int SPC = 4;                    // deferred stores per chunk
+    //                                           SPC: deferred stores (and residual loads) per chunk
     constexpr int NSTORE = RG * NB, KST = (NSTORE + SPC - 1) / SPC;   // chunks of the next tile that carry them (host: nk >= KST)
-    static_assert(TOT >= 48, "filler schedule needs room");
+    constexpr int VEC_OFF = 2 * T::STAGE_BYTES;   // SEPI_ROWLN: bias | post_w | post_b, BN floats each, behind the ring
+    static_assert(TOT >= 48 && TOT / SPC >= 4, "filler schedule needs room");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;
@@ -355,7 +367,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, qd = lane >> 4;
 
-    const int tiles_n = p.N / BN;
+    const int tiles_n = ROWLN ? 1 : p.N / BN;
     const int tiles_m = (int)((p.M + BM - 1) / BM);
     const int ntiles = tiles_m * tiles_n;
     const int b = blockIdx.x, G = gridDim.x;
@@ -363,6 +375,14 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
     const int my_tiles = (ntiles - b + G - 1) / G;
     const int K = p.K, nk = K / 32;
     const int total = my_tiles * nk;
+    if constexpr (ROWLN) {   // the per-column vectors of the chain, once per workgroup (before any DMA is in flight)
+        float* const vec = smem + VEC_OFF / 4;
+        for (int i = tid; i < BN; i += T::NTHR) {
+            vec[i] = p.bias[i];
+            if constexpr (POST) vec[BN + i] = p.post_w[i], vec[2 * BN + i] = p.post_b[i];
+        }
+        __syncthreads();
+    }
     auto tile_of = [&](int j, int& tm, int& tn) {
         const int v = b + j * G;
         const int xcd = v & 7, q = ntiles >> 3, rem = ntiles & 7;
@@ -431,8 +451,9 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
         for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f}, fin[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     float* fin_ptr[RG];     // row base of the pending tile's stores (+ 16 n)
     bool fin_live[RG];
+    const float* rsd_ptr[RG];   // SEPI_ROWLN: row base of the current tile's residual rows
 #pragma unroll
-    for (int g = 0; g < RG; ++g) fin_ptr[g] = p.out, fin_live[g] = false;
+    for (int g = 0; g < RG; ++g) fin_ptr[g] = ROWLN ? p.out_x : p.out, fin_live[g] = false, rsd_ptr[g] = p.resid;
     bool pend = false;
 
     u32x4 cur[RG][3];       // the three slices of the current chunk's A fragments
@@ -482,6 +503,13 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
         tile_of(tj, tm, tn);
         const int64_t m0 = (int64_t)tm * BM;
         const int n0 = tn * BN;
+        if constexpr (ROWLN) {
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
+                rsd_ptr[g] = p.resid + (m < p.M ? m : p.M - 1) * p.N + 4 * qd;
+            }
+        }
         for (int kc = 0; kc < nk; ++kc, ++g_idx) {
             // in flight at most: the A rows of chunk g_idx + 2 (issued mid-chunk g_idx - 1, behind W' of this chunk).  Deferred stores are
             // not counted: an operation assumed absent only makes the wait stricter.
@@ -574,7 +602,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
                         asm volatile("" ::: "memory");
                     }
                     // (iv) SPC deferred stores of the previous tile, spread over the chunk
-                    if constexpr (t % (TOT / SPC) == TOT / SPC - 3) {
+                    if constexpr (t % (TOT / SPC) == TOT / SPC - 3 && t / (TOT / SPC) < SPC) {
                         constexpr int i = t / (TOT / SPC);
                         if (st_now) {
                             static_for<KST>([&](auto C_) {
@@ -601,36 +629,140 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
         SGEMM_T(t4);
 
         // ---- end of tile tj: the epilogue arithmetic into `fin` (lane (c, qd): token m0 + wave RG 16 + 16 g + c, columns n0 + 16 n + 4 qd + ..)
-        static_assert(EPI == SEPI_BIAS, "whole-row form: sgemm2_rowln_kernel");
+        if constexpr (!ROWLN) {
 #pragma unroll
-        for (int g = 0; g < RG; ++g) {
-            const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
-            const bool live = m < p.M;
-            const int64_t mm = live ? m : p.M - 1;
-            float rstd = 1.0f;
-            if constexpr (LNIN) rstd = p.ln_in[2 * mm + 1];
-            fin_ptr[g] = p.out + mm * p.N + n0 + 4 * qd;
-            fin_live[g] = live;
+            for (int g = 0; g < RG; ++g) {
+                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
+                const bool live = m < p.M;
+                const int64_t mm = live ? m : p.M - 1;
+                float rstd = 1.0f;
+                if constexpr (LNIN) rstd = p.ln_in[2 * mm + 1];
+                fin_ptr[g] = p.out + mm * p.N + n0 + 4 * qd;
+                fin_live[g] = live;
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
-                f32x4 v;
-                if constexpr (LNIN) {
+                for (int n = 0; n < NB; ++n) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
+                    f32x4 v;
+                    if constexpr (LNIN) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
+                    }
+                    if constexpr (ACT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    fin[g][n] = v;
+                    acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
+            const float* const vec = smem + VEC_OFF / 4 + 4 * qd;   // + 16 n (+ BN: post_w, + 2 BN: post_b)
+            const float invC = 1.0f / (float)p.N;
+            auto row_sum = [&](float v) {   // over the row's four lanes (c, qd = 0..3)
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                return v;
+            };
+#pragma unroll
+            for (int g = 0; g < RG; ++g) {
+                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
+                const bool live = m < p.M;
+                const int64_t mm = live ? m : p.M - 1;
+                f32x4(&y)[NB] = acc[g];
+#pragma unroll
+                for (int n = 0; n < NB; ++n) fin[g][n] = *reinterpret_cast<const f32x4*>(rsd_ptr[g] + 16 * n);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + 16 * n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[n][e] = (y[n][e] + b4[e]) + fin[g][n][e];   // (acc + bias) + residual
+                }
+                // the two fixed-order reductions of a LayerNorm: mean, then the centred second moment
+                auto stats = [&](float eps, float& mean, float& rstd) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s += y[n][e];
+                    mean = row_sum(s) * invC;
+                    asm volatile("" : "+v"(mean));   // ONE rounded value: `y - mean` must not contract into an fma on the unrounded product
+                    float q = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = y[n][e] - mean;
+                            q = fmaf(d, d, q);
+                        }
+                    rstd = 1.0f / sqrtf(fmaf(row_sum(q), invC, eps));
+                };
+                if constexpr (POST) {
+                    float mean, rstd;
+                    stats(p.post_eps, mean, rstd);
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(vec + BN + 16 * n);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + 2 * BN + 16 * n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[n][e] = fmaf((y[n][e] - mean) * rstd, g4[e], b4[e]);
+                    }
+                }
+                if (p.pos) {   // only the first spatial block of a pass (workgroup-uniform)
+                    const float* const pe = p.pos + (int64_t)((mm / p.posJ) % p.posF) * p.N + 4 * qd;
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(pe + 16 * n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) y[n][e] += e4[e];
+                    }
+                }
+                float mean, rstd;
+                stats(p.next_eps, mean, rstd);
+                if constexpr (!HEAD) {
+                    // the next LayerNorm is folded into the GEMM that consumes the row: its statistics, and the row CENTRED on its mean
+                    if (live && qd == 0) {
+                        p.ln_stats[2 * m] = mean;
+                        p.ln_stats[2 * m + 1] = rstd;
+                    }
+                    fin_ptr[g] = p.out_x + mm * p.N + 4 * qd;
+                    fin_live[g] = live;
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fin[g][n][e] = y[n][e] - mean;
                 } else {
+                    // the head keeps its own LayerNorm (eps 1e-5) and Linear(C -> 3): common/mixste.py:207-210
+                    const float* const gw = p.next_w + 4 * qd;
+                    const float* const gb = p.next_b + 4 * qd;
+                    float s3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
-                }
-                if constexpr (ACT) {
+                    for (int n = 0; n < NB; ++n) {
+                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + 16 * n);
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + 16 * n);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                        for (int e = 0; e < 4; ++e) y[n][e] = fmaf((y[n][e] - mean) * rstd, g4[e], b4[e]);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + 4 * qd + 16 * n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s3[k] = fmaf(y[n][e], hw[e], s3[k]);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float s = row_sum(s3[k]);
+                        if (live && qd == 0) p.out_head[m * 3 + k] = s + p.head_b[k];
+                    }
+                    fin_live[g] = false;
                 }
-                fin[g][n] = v;
-                acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        pend = true;
+        pend = !HEAD;
         SGEMM_T(t5);
         SGEMM_ADD(3, t4, t5);
     }

@@ -33,6 +33,24 @@ def cosine_beta_schedule(timesteps, s=0.008):
 _SHARED_AUX = {}                      # device index -> side streams of this process (D3DP._aux_for)
 _SHARED_AUX_LOCK = threading.Lock()
 
+# The librccl.so builds whose gfx950 kernels were disassembled and found free of the packed-fp32 form that returns wrong lanes beside
+# v_mfma_f32_32x32x16_bf16 waves of another queue (tools/rccl_packed_fp32_census.py): SHA-256 of the first 64 MiB of the file.
+DDP_SPLIT_PRODUCTS_CHECKED_RCCL = {
+    "58640d64a170f044356e059f7ce2a7a06a41249fbb160f3a04cd192025b409ba": "torch 2.10.0+rocm7.0 bundled librccl.so (profiles/r06_rccl_packed_fp32_census.json)",
+}
+
+
+def _rccl_build_is_the_checked_one():
+    import hashlib
+    import os
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read(64 << 20)).hexdigest() in DDP_SPLIT_PRODUCTS_CHECKED_RCCL
+    except OSError:
+        return False
+
+
 class D3DP(nn.Module):
     def __init__(self, args, joints_left, joints_right, dataset, is_train=True, num_proposals=1,
                  sampling_timesteps=1):
@@ -371,18 +389,25 @@ class D3DP(nn.Module):
     # ------------------------------------------------------------------------------------------------ training
     def prepare_for_ddp(self):
         """Call ONCE, on every rank, before wrapping a training model in DistributedDataParallel (or stepping it beside any other
-        collective): a step in 'bf16x3' issues v_mfma_f32_32x32x16_bf16 (whole-row forward tiles, dX, dW), the instruction beside
-        which a packed-fp32 VALU instruction of ANOTHER queue's kernel returns wrong lanes on MI355X
-        (profiles/r03_bf16_mfma_concurrency.md).  This library is compiled without such instructions; RCCL's reduction kernels,
-        which DDP overlaps with the backward on its own stream, are not ours.  Until a multi-GPU soak shows bit-equal gradients a
-        process group of more than one rank trains on the fp32 matrix cores: this method switches the model to 'f32' (unless
-        allow_split_products_under_ddp is set) and returns the precision in effect.  The decision is made here, explicitly and
-        once - forward() never changes the configuration; it refuses to run a split-precision step under a multi-rank process
-        group that was not prepared."""
+        collective); returns the precision in effect.  Background: a step in 'bf16x3' issues v_mfma_f32_32x32x16_bf16 (whole-row
+        forward tiles, dX, dW), the instruction beside which a packed-fp32 VALU instruction of ANOTHER queue's kernel whose src1
+        selects the high register for the low result returns wrong lanes on MI355X (profiles/r03_bf16_mfma_concurrency.md).  This
+        library is compiled without packed-fp32 instructions; the collective's kernels, which DDP overlaps with the backward on its
+        own stream, are not ours.  Round 6 settled the question per backend:
+          * 'nccl' (RCCL): the gfx950 code object of the librccl.so torch loads was disassembled and every v_pk_*_f32 classified
+            (tools/rccl_packed_fp32_census.py, profiles/r06_rccl_packed_fp32_census.json): 325 packed-fp32 instructions, all plain or
+            with a src0 select (forms that never failed in the two-kernel reproducer), NONE with the failing src1 select.  Split
+            products stay on - for THAT library build: ddp_split_products_checked_rccl holds the digest the census was taken on, and
+            another librccl.so moves the model to 'f32' until the census has been re-run on it.
+          * 'gloo' and other host-side backends: no foreign GPU kernel runs beside ours; split products stay on.
+        allow_split_products_under_ddp = True skips the check.  The decision is made here, explicitly and once - forward() never
+        changes the configuration; it refuses to run a split-precision step under a multi-rank process group that was not prepared."""
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if multi and self.is_train and not self.allow_split_products_under_ddp and self.precision in ("bf16x3_images", "bf16x3"):
-            self.precision = "f32"
+            backend = str(dist.get_backend())
+            if "nccl" in backend and not _rccl_build_is_the_checked_one():
+                self.precision = "f32"
         self._ddp_prepared = True
         return self.precision
 
@@ -393,9 +418,9 @@ class D3DP(nn.Module):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             raise _lib.PafuseError("pafuse_amd.D3DP: training under torch.distributed with world size > 1: call model.prepare_for_ddp() on "
-                                   "every rank before the first step (it moves the model to 'f32' products: the bf16 matrix instruction "
-                                   "of 'bf16x3' is not proven safe beside RCCL's kernels on MI355X), or set "
-                                   "allow_split_products_under_ddp = True to keep 'bf16x3' at your own risk")
+                                   "every rank before the first step (it keeps 'bf16x3' products beside a collective library whose GPU kernels "
+                                   "were checked for the packed-fp32 form that fails beside bf16 MFMAs on MI355X, and moves the model to 'f32' "
+                                   "beside an unchecked one), or set allow_split_products_under_ddp = True to skip the check")
 
     def prepare_targets(self, targets):
         """common/diffusionpose.py:358-388: per sample one timestep and one noise draw (in that order, on the

@@ -459,22 +459,22 @@ def fused_mlp_fc2_image(weight):
 def folded_linear(get, name, f16=False, x=False, image=True):
     """(image, ls, lt) of the linear layer `name` (a state-dict key ending in attn.qkv.weight / mlp.fc1.weight) with the
     LayerNorm in front of it folded in (include/pafuse_hip.h, pafuse_block_weights.qkv_ls): the split image of W (.) g
-    (one fp32 rounding per element, then split exactly), ls = W g and lt = W beta + b formed in fp64, rounded once."""
+    (one fp32 rounding per element, then split exactly), lt = W beta + b formed in fp64, rounded once; ls is None (the
+    centred fold of round 5 has no mean term)."""
     block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
     weight = get(name).detach()
     g, beta = get(f"{block}.{norm}.weight").detach(), get(f"{block}.{norm}.bias").detach()
     bias = get(name[:-len("weight")] + "bias").detach()
-    w64 = weight.double()
-    ls = (w64 @ g.double()).float().contiguous()
-    lt = (w64 @ beta.double() + bias.double()).float().contiguous()
-    return (split_image((weight * g[None, :]).contiguous(), image_layout(name), f16, x) if image else None), ls, lt
+    lt = (weight.double() @ beta.double() + bias.double()).float().contiguous()
+    # (ls = W g, the mean term of round 3's uncentred fold, is not read by any kernel since round 5 and no longer formed: None)
+    return (split_image((weight * g[None, :]).contiguous(), image_layout(name), f16, x) if image else None), None, lt
 
 
 def head_major_qkv(get, name, heads, fold, f16=False, x=False):
     """(image, hb, hl) for the fused qkv + attention kernel (include/pafuse_hip.h pafuse_block_weights.qkv_hs): the qkv weight
     [3C, C] re-ordered head by head - q_h, k_h, v_h, each zero-padded from d to DP rows (DP = 32 for d <= 32, else 48) - as
-    a layout-2 image; hb = the bias in that order; with the LayerNorm folded the image is that of W (.) g, hb = W beta + b
-    and hl = W g (folded_linear's vectors, re-ordered)."""
+    a layout-2 image; hb = the bias in that order; with the LayerNorm folded the image is that of W (.) g and hb = W beta + b
+    (folded_linear's vector, re-ordered); hl is None (not read by any kernel since the centred fold of round 5)."""
     weight = get(name).detach()
     C3, C = weight.shape
     d = C3 // 3 // heads
@@ -485,9 +485,7 @@ def head_major_qkv(get, name, heads, fold, f16=False, x=False):
     if fold:
         block, norm = name.rsplit(".", 3)[0], FOLDED_LINEAR[name.split(".", 2)[2]]
         g, beta = get(f"{block}.{norm}.weight").detach(), get(f"{block}.{norm}.bias").detach()
-        w64 = weight.double()
-        hl = (w64 @ g.double()).float()
-        bias = (w64 @ beta.double() + bias.double()).float()
+        bias = (weight.double() @ beta.double() + bias.double()).float()     # (hl = W g: not read since round 5, not formed)
         weight = weight * g[None, :]
 
     def reorder(t):                     # [3C, ...] -> [heads * 3 * dp, ...]

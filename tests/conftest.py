@@ -21,8 +21,26 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
+# The frozen MPJPE bounds (tests/parity_bounds.json): the SHA-256 of its `cases` object (keys sorted, no whitespace).  A changed bound
+# fails the whole session here, so loosening one is a visible diff in TWO files (the file was rewritten in the round
+# that froze it).  The `what` text is not part of the digest.
+PARITY_BOUNDS_CASES_SHA256 = "f64ef3ce6dc32b59109908d46f7b2f04e78f9c79ebed44f79810ddfb0c1d3898"
+
+
+def _check_parity_bounds_digest():
+    import hashlib
+    import json
+    with open(os.path.join(ROOT, "tests", "parity_bounds.json")) as f:
+        cases = json.load(f)["cases"]
+    got = hashlib.sha256(json.dumps(cases, sort_keys=True, separators=(",", ":")).encode()).hexdigest()
+    if got != PARITY_BOUNDS_CASES_SHA256:
+        raise pytest.UsageError(f"tests/parity_bounds.json: the bounds changed (sha256 of `cases` {got}, pinned {PARITY_BOUNDS_CASES_SHA256}); "
+                                "frozen bounds are not edited - if a bound must move, change the pin in tests/conftest.py in the same commit and say why")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _check_parity_bounds_digest()
 
 
 def pytest_collection_modifyitems(config, items):

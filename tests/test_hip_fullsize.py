@@ -71,7 +71,7 @@ def test_p160_in_eight_p20_shards_equals_single_run(full160):
         m.proposal_shard = None
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 def test_p20_t10_equals_its_halves_and_the_p160_prefix(full160, precision):
     """configs[2], the metric's own configuration (B=1, P=20, T=10): the run equals the concatenation of its
     proposal_shard halves, and - same noise, same product scheme - the first 20 hypotheses of the P=160 run."""
@@ -109,7 +109,7 @@ def test_full_size_trajectories_vs_oracle(full160):
         _assert_mpjpe_parity(out[:, :, sel].contiguous(), ref[:, :, sel].contiguous(), target, full160["x2d"], case)
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "bf16x3_images"])
+@pytest.mark.parametrize("precision", ["f16x2"])
 def test_full_size_opt_in_modes_vs_oracle(full160, precision):
     """the metric's configuration (P=20, T=10) with the opt-in product modes - f16x2, and bf16x3 on the image pipeline - against
     the oracle on all 20 hypotheses, all ten steps: pointwise 1e-5 and the four MPJPE protocols within the frozen bounds of the
@@ -126,7 +126,7 @@ def test_full_size_opt_in_modes_vs_oracle(full160, precision):
     _assert_mpjpe_parity(out, ref, target, full160["x2d"], f"fullsize_20of20_T10_{precision}")
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
 def test_metric_config_vs_fp64_truth(full160, precision):
     """hypotheses {0, 7, 19} of the metric's configuration (P=20, T=10) through all ten steps against the
     oracle evaluated in fp64 - per protocol the HIP path is not further from exact arithmetic than the reference's own fp32
@@ -168,7 +168,7 @@ def g19_compare(out20, z, x2d):
     return pt, diffs, d, float(flipped.double().mean()), worst
 
 
-@pytest.mark.parametrize("precision", ["bf16x3", "bf16x3_images", "f32", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f32", "f16x2"])
 def test_g19_metric_config_vs_reference(full160, precision):
     """BASELINE configs[2] - the configuration the metric is quoted on (B=1, P=20, T=10, flip-TTA) - against the output
     of the REFERENCE itself on the same weights, inputs and noise (golden G19, made by tests/golden/make_golden.py from
@@ -389,10 +389,10 @@ def test_grouped_launches_equal_part_by_part_launches():
     """The single-stream schedule (no aux streams) puts the same layer of the three parts into shared grids
     (grouped_*_kernel).  A tile's products and sums do not depend on the grid it runs in: the same loop with every layer
     launched part by part (pafuse_d3dp_config.part_by_part_launches, a per-call option: the library keeps no process-wide
-    schedule state) is the same function.  Since round 5 the per-part whole-row launches write their rows through per-wave LDS
+    schedule state) is the same function, BIT FOR BIT.  The per-part whole-row launches write their rows through per-wave LDS
     slabs (epilogue_rows_h) while the shared grid keeps the direct epilogue (three tile shapes in one kernel: the slab form
-    spilled there) - the same arithmetic, contracted differently by the compiler in the two code shapes, so the outputs agree
-    to rounding, not bit for bit: both within 1e-5 of the oracle, within 4e-6 of each other."""
+    spilled there): the same arithmetic in the same order, and since round 6 every multiply-add of both is an explicit fmaf, so
+    the compiler cannot contract the two code shapes differently (round 5 had left that to chance: 4e-6 apart)."""
     from __graft_entry__ import make_model
     model, sd = make_model(20, 2, seed=52)
     model.precision = "bf16x3"       # (the shared grids are the single-stream schedule of the round-3 kernels)
@@ -403,13 +403,13 @@ def test_grouped_launches_equal_part_by_part_launches():
     grouped = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
     model.part_by_part_launches = True
     part_by_part = model(x2d.to(DEV), None, input_2d_flip=x2f.to(DEV)).cpu()
-    assert float((grouped - part_by_part).abs().max()) <= 4e-6, float((grouped - part_by_part).abs().max())
+    assert torch.equal(grouped, part_by_part), float((grouped - part_by_part).abs().max())
     sub = [0, 7, 19]
     ref = orc.ddim_sample(sd, x2d, [n[:, sub] for n in noises], 2, gu.SYN_JOINTS_LEFT, gu.SYN_JOINTS_RIGHT, inputs_2d_flip=x2f)
     assert float((grouped[:, :, sub] - ref).abs().max()) <= 1e-5 and float((part_by_part[:, :, sub] - ref).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("precision", ["bf16x3_images", "bf16x3", "f32", "f16x2"])
+@pytest.mark.parametrize("precision", ["bf16x3", "f32", "f16x2"])
 def test_side_streams_return_the_single_stream_bits(precision):
     """The default schedule runs the three parts on three HIP streams (queues).  In round 2 that was wrong now and then
     in the bf16-MFMA modes; the cause - packed-fp32 VALU instructions beside v_mfma_f32_32x32x16_bf16 waves of another
@@ -425,8 +425,8 @@ def test_side_streams_return_the_single_stream_bits(precision):
     for aux in (0, 2, 5):
         model, _ = make_model(20, T_FULL, seed=52)
         model.precision, model.n_aux_streams = precision, aux
-        model.part_by_part_launches = True      # the single-stream reference launches what the streams launch (no shared grids: their
-        #                                         whole-row epilogue is another code shape, equal to rounding only - round 5)
+        # (the single-stream reference runs its DEFAULT schedule - the shared whole-row grids - since round 6: their direct epilogue
+        # and the per-part launches' slab epilogue return the same bits again, test_grouped_launches_equal_part_by_part_launches)
         model.noise_fn = lambda k, shape, device: noises[k]
         lanes = _lib.check(_lib.load().pafuse_d3dp_lanes(ctypes.byref(model.config_struct(True)), 1, 20, aux))
         assert lanes == aux + 1, (aux, lanes)

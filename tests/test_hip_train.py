@@ -248,6 +248,61 @@ def test_ddp_wrapper_produces_the_same_gradients():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("train_dtype", ["bf16x3", "f32"])
+def test_train_two_rank_rehearsal_on_one_gpu(tmp_path, train_dtype):
+    """The one parallel mechanism of the reference's training (main_h3wb.py:699-705,850-871: replicas + gradient averaging) as it
+    runs here: torch DistributedDataParallel around pafuse_amd.D3DP, TWO real ranks started the way the driver starts a scaling run
+    (`python bench.py --train --gpus 2`: the parent spawns torch.distributed.run before it touches the GPU), sharing this box's one
+    GPU over gloo (a rehearsal of the code path: prepare_for_ddp, the autograd node's hooks under a multi-rank process group, the
+    bucketed all-reduce).  The gradients rank 0 holds after ONE backward - DDP's average over the two ranks, each on its own
+    disjoint batch - must equal a single-process step on the CONCATENATED batch (same weights, same per-sample draws, DropPath
+    off): within 5e-4 of every tensor's largest entry.  Both requested precisions: 'bf16x3' (kept under the process group since
+    round 6) and 'f32'."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from __graft_entry__ import make_model
+    from tests.conftest import ROOT
+    B = 3
+    dump = str(tmp_path / "grads.pt")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--train", "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--batch", str(B), "--train-dtype", train_dtype, "--no-cpu-baseline", "--dump-grads", dump]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2, res.stdout
+    got = torch.load(dump)
+    assert got["world"] == 2 and got["B_per_rank"] == B
+    # the same step in ONE process on the concatenated batch (rank r's clips: seeds 1234 + r / 1235 + r, draws 7000 + r B + i)
+    model, _ = make_model(1, 1, seed=51, is_train=True)
+    model.precision = got["precision"]          # what prepare_for_ddp left in effect on the ranks
+    assert got["precision"] == train_dtype, got["precision"]
+    for m in model.denoisers().values():
+        m.drop_path_rate = 0.0
+
+    def draw(i):
+        g = torch.Generator().manual_seed(7000 + i)
+        return torch.randint(0, 1000, (1,), generator=g), torch.randn(27, 134, 3, generator=g)
+    model.train_draw_fn = draw
+    x2d = torch.cat([gu.synthetic_inputs_2d(B=B, seed=1234 + r)[0] for r in range(2)]).to(DEV)
+    target = torch.cat([gu.synthetic_target_3d(B=B, seed=1235 + r) for r in range(2)]).to(DEV)
+    pred = model(x2d, target)
+    torch.mean(torch.norm(pred - target, dim=-1)).backward()
+    names = [n for n, p in model.named_parameters() if p.grad is not None]
+    assert set(names) == set(got["grads"]) and len(names) == 624, (len(names), len(got["grads"]))
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = got["grads"][n].double(), p.grad.detach().cpu().double()
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        worst = max(worst, err / max(scale, 1e-30))
+        assert err <= 5e-4 * scale + 1e-12, (n, err, scale)
+    print(f"two-rank averaged gradients vs one process on the concatenated batch ({train_dtype}): worst max|d| / max|g| = {worst:.2e}")
+
+
 def test_training_errors_are_loud():
     """unsupported width, CPU tensors and a short activation buffer are refused - nothing falls back"""
     import ctypes as C

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Collects the rocprofv3 evidence behind profiles/rNN_* on the GPU box (run through gpurun from the repo root):
+# Collects the rocprofv3 evidence behind profiles/rNN_* on the GPU box (run through gpurun from the repo root), ONCE per round on the
+# tree that ships (A/Bs in between use `bench.py --no-secondary --no-cpu-baseline --no-train-leg`):
 #   bash tools/collect_profiles.sh            -> gpurun_out/prof/*
 # One pass per counter group (FETCH_SIZE and WRITE_SIZE cannot share a pass; counters never together with --stats),
 # program directly after `--`, from /tmp with TMPDIR=/tmp as the pool requires.  Summaries are made afterwards in the
@@ -26,14 +27,10 @@ run rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --ou
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o train -- python3 "$R/bench.py" --train --steps 3 --warmup 1 --no-cpu-baseline > "$O/train_bench_line.json" 2> "$O/train.err" || exit 1
 run python3 "$R/bench.py" > "$O/bench_line.json" 2> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --dtype f32 --no-cpu-baseline --no-train-leg > "$O/bench_line_f32.json" 2>> "$O/bench.err" || exit 1
-run python3 "$R/bench.py" --dtype bf16x3_images --no-cpu-baseline --no-train-leg > "$O/bench_line_bf16x3_images.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --dtype f16x2 --no-cpu-baseline --no-train-leg > "$O/bench_line_f16x2.json" 2>> "$O/bench.err" || exit 1
-run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats1x -- python3 "$R/bench.py" --dtype bf16x3_images --streams 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-roofline > "$O/stats1x_bench_line.json" 2> "$O/stats1x.err" || exit 1
 run rocprofv3 --kernel-trace --stats --output-format csv -d "$O" -o stats1h -- python3 "$R/bench.py" --dtype f16x2 --streams 0 --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-roofline > "$O/stats1h_bench_line.json" 2> "$O/stats1h.err" || exit 1
-run python3 "$R/tests/reports/error_growth.py" --out "$O/error_growth.json" > "$O/error_growth.log" 2>&1 || exit 1
 run python3 "$R/bench.py" --train --no-cpu-baseline > "$O/train_bench_line_unprofiled.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/bench.py" --train --train-dtype f32 --no-cpu-baseline > "$O/train_bench_line_f32_unprofiled.json" 2>> "$O/bench.err" || exit 1
 run python3 "$R/tools/soak_determinism.py" 200 bf16x3 > "$O/soak_determinism.json" 2>> "$O/bench.err" || exit 1
-run python3 "$R/tests/reports/error_budget.py" --out "$O/error_budget.json" > "$O/error_budget.log" 2>&1 || exit 1
 run python3 "$R/tests/reports/parity_report.py" --out "$O/parity_report.json" > "$O/parity_report.log" 2>&1 || exit 1
 ls -la "$O" | head -40

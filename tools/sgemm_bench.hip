@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include "../pafuse_amd/csrc/sgemm.hpp"
+#include "../pafuse_amd/csrc/hgemm.hpp"   // epilogue_rows_h: the whole-row epilogue of the production gemm_dma_kernel
 using namespace pafuse;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -168,6 +169,117 @@ void run2(const char* shape, GemmParams p) {
 #endif
 }
 
+// ---- whole-row layers (proj, fc2 + residual + LayerNorms): the production LDS-DMA kernel against the strip kernel's SEPI_ROWLN form.
+// The two reduce a row's statistics in different orders, so the compare is numeric: max |d| of the centred rows and of (mean, rstd).
+static float *g_x0 = nullptr, *g_xa = nullptr, *g_xb = nullptr, *g_sa = nullptr, *g_sb = nullptr;
+static void compare_rows(const char* tag, int64_t M, int C) {
+    std::vector<float> a((size_t)M * C), b((size_t)M * C), sa((size_t)M * 2), sb((size_t)M * 2);
+    CK(hipMemcpy(a.data(), g_xa, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), g_xb, b.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(sa.data(), g_sa, sa.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(sb.data(), g_sb, sb.size() * 4, hipMemcpyDeviceToHost));
+    double dx = 0, mx = 0, ds = 0;
+    size_t bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (!(std::fabs(a[i] - b[i]) <= 1e-3)) ++bad;
+        dx = std::max(dx, (double)std::fabs(a[i] - b[i])), mx = std::max(mx, (double)std::fabs(a[i]));
+    }
+    for (size_t i = 0; i < sa.size(); ++i) ds = std::max(ds, (double)std::fabs(sa[i] - sb[i]) / std::max(1.0, (double)std::fabs(sa[i])));
+    printf("      %s: centred rows max |d| %.3e (max |x| %.3f, elements off by > 1e-3: %zu), statistics max rel d %.3e\n", tag, dx, mx, bad, ds);
+}
+template <int WM, int WN, int NT>
+void run_rowln_ref(const char* shape, GemmParams p) {   // production: gemm_dma_kernel<.., EPI_ROWLN, 2 stages, 2 per CU, 16-deep chunks>
+    using T = DmaTile<WM, WN, NT, 16>;
+    char tag[160];
+    snprintf(tag, sizeof tag, "%s gemm_dma<%d,%d,%d> %dx%d (production)", shape, WM, WN, NT, T::BM, T::BN);
+    constexpr size_t lds = 2 * T::STAGE_BYTES;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI_ROWLN, 2, 2, 0, 16>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long tiles = (p.M + T::BM - 1) / T::BM;
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T::NTHR, lds));
+    p.resid = p.out_x = g_xa, p.ln_stats = g_sa;
+    CK(hipMemcpy(g_xa, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, 0, p);   // the compared result: ONE launch on fresh rows
+    CK(hipDeviceSynchronize());
+    p.resid = p.out_x = g_ref, p.ln_stats = g_sb + 0;   // timing on scratch rows (in place: the values drift, the work does not)
+    float* scratch_stats; CK(hipMalloc(&scratch_stats, (size_t)p.M * 8)); p.ln_stats = scratch_stats;
+    CK(hipMemcpy(g_ref, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
+    const double us = time_us([&] { hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, 0, p); });
+    CK(hipFree(scratch_stats));
+    const double tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    printf("%-58s tiles %5ld grid %5ld (%d/CU, %3zu KB) %7.2f us %6.1f TF (%.3f of 417)  (reference)\n", tag, tiles, tiles, occ, lds / 1024, us, tf, tf / 416.7);
+    fflush(stdout);
+}
+// the shared-grid form (grouped_rowln_kernel, direct epilogue) of ONE part against the per-part launch (slab epilogue): equal bits?
+static void run_rowln_grouped_bits(const char* shape, GemmParams p, int bm) {
+    GroupedGemmParams g{};
+    g.n = 1;
+    p.resid = p.out_x = g_xb, p.ln_stats = g_sb;
+    g.p[0] = p;
+    const long tiles = (p.M + bm - 1) / bm;
+    g.first[0] = 0;
+    for (int k = 1; k <= GROUP_MAX; ++k) g.first[k] = (int)((tiles + 7) / 8 * 8);
+    constexpr size_t lds = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES;
+    auto k = grouped_rowln_kernel<EPI_ROWLN>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipMemcpy(g_xb, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(k, dim3((unsigned)g.first[1]), dim3(256), lds, 0, g);
+    CK(hipDeviceSynchronize());
+    printf("      %s shared-grid kernel vs per-part launch: differing words rows %llu, statistics %llu\n", shape,
+           differing(g_xa, g_xb, p.M * p.N), differing(g_sa, g_sb, p.M * 2));
+    {
+        const size_t n = (size_t)512 * p.N;
+        std::vector<float> a(n), b(n), x0(n), st(1024);
+        CK(hipMemcpy(a.data(), g_xa, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), g_xb, n * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(st.data(), g_sa, 4096, hipMemcpyDeviceToHost));
+        int shown = 0;
+        for (size_t i = 0; i < n && shown < 12; ++i)
+            if (a[i] != b[i]) {
+                printf("        row %zu col %zu: per-part %.9g shared %.9g (d %.3g) mean %.9g\n", i / p.N, i % p.N, a[i], b[i], a[i] - b[i], st[2 * (i / p.N)]);
+                ++shown;
+            }
+    }
+}
+
+template <int NB, int NW, int FLAGS, int SPC>
+void run_rowln(const char* shape, GemmParams p) {
+    using T = StripTile<NB, 1, NW, 2>;
+    char tag[160];
+    snprintf(tag, sizeof tag, "%s strip2-rowln<NB%d,RG1,NW%d,SPC%d> %dx%d pipelined", shape, NB, NW, SPC, T::BM, T::BN);
+    if (g_filter && !strstr(tag, g_filter)) return;
+    constexpr size_t lds = T::LDS_BYTES + 3 * T::BN * 4;
+    auto k = sgemm2_kernel<NB, 1, NW, SEPI_ROWLN, 2, FLAGS, SPC>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T::NTHR, lds));
+    if (occ < 1) { printf("%s: does not fit a CU\n", tag); return; }
+    const long tiles = (p.M + T::BM - 1) / T::BM;
+    long grid = std::min<long>(tiles, 256L * occ);
+    if (grid < tiles) grid = grid / 8 * 8;
+    p.resid = p.out_x = g_xb, p.ln_stats = g_sb;
+    CK(hipMemcpy(g_xb, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(T::NTHR), lds, 0, p);
+    CK(hipDeviceSynchronize());
+    float* scratch_stats; CK(hipMalloc(&scratch_stats, (size_t)p.M * 8));
+    p.resid = p.out_x = g_ref, p.ln_stats = scratch_stats;
+    CK(hipMemcpy(g_ref, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
+#ifdef SGEMM_STAMPS
+    unsigned long long* st;
+    const size_t nw = (size_t)grid * NW;
+    CK(hipMalloc(&st, nw * 64)); CK(hipMemset(st, 0, nw * 64));
+    p.stamps = st;
+#endif
+    const double us = time_us([&] { hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(T::NTHR), lds, 0, p); });
+    CK(hipFree(scratch_stats));
+    const double tf = 2.0 * p.M * p.N * p.K / (us * 1e-6) / 1e12;
+    printf("%-58s tiles %5ld grid %5ld (%d/CU, %3zu KB) %7.2f us %6.1f TF (%.3f of 417)\n", tag, tiles, grid, occ, lds / 1024, us, tf, tf / 416.7);
+    compare_rows("vs production", p.M, p.N);
+#ifdef SGEMM_STAMPS
+    stamp_report(st, nw, (double)tiles * (p.K / 32) / (double)grid, NB * 96);
+    CK(hipFree(st));
+#endif
+    fflush(stdout);
+}
+
 int main() {
     g_filter = getenv("SB_FILTER");
     if (getenv("SB_REPS")) g_reps = atoi(getenv("SB_REPS"));
@@ -190,6 +302,46 @@ int main() {
 
     struct Part { const char* name; int64_t M; int C; };
     const Part parts[3] = {{"body", 25920, 384}, {"face", 73440, 224}, {"hands", 45360, 256}};
+    // ---- whole-row layers of the face and the hands (SB_ROWLN=0 skips them)
+    if (!getenv("SB_ROWLN") || atoi(getenv("SB_ROWLN"))) {
+        uint8_t* Wi1;
+        float* postv;
+        CK(hipMalloc(&Wi1, 1152 * 768 * 6)); CK(hipMalloc(&g_x0, Mmax * 256 * 4)); CK(hipMalloc(&g_xa, Mmax * 256 * 4)); CK(hipMalloc(&g_xb, Mmax * 256 * 4));
+        CK(hipMalloc(&g_sa, Mmax * 8)); CK(hipMalloc(&g_sb, Mmax * 8)); CK(hipMalloc(&postv, 4096 * 4));
+        {
+            std::vector<float> pv(4096);
+            for (int i = 0; i < 4096; ++i) pv[i] = 1.0f + 0.1f * (float)((i * 37) % 19 - 9) / 9.0f;
+            CK(hipMemcpy(postv, pv.data(), 4096 * 4, hipMemcpyHostToDevice));
+        }
+        CK(hipMemcpy(g_x0, X + 12345, Mmax * 256 * 4, hipMemcpyDeviceToDevice));
+        for (int pi = 1; pi < 3; ++pi) {
+            const Part& pt = parts[pi];
+            const int C = pt.C;
+            for (int layer = 0; layer < 2; ++layer) {   // 0 = proj (K = C), 1 = fc2 (K = 2C, with the post LayerNorm)
+                const int N = C, K = layer == 0 ? C : 2 * C;
+                hipLaunchKernelGGL((split_weights_kernel<16, 0>), dim3((unsigned)(((int64_t)N * (K / 8) + 255) / 256)), dim3(256), 0, 0, W, Wi1, N, K);
+                hipLaunchKernelGGL((split_weights_kernel<32, 1>), dim3((unsigned)(((int64_t)N * (K / 8) + 255) / 256)), dim3(256), 0, 0, W, Wi, N, K);
+                GemmParams p{};
+                p.A = X, p.bias = vec, p.M = pt.M, p.N = N, p.K = K, p.bf16 = 2;
+                p.next_w = vec, p.next_b = vec, p.next_eps = 1e-6f;
+                if (layer == 1) p.post_w = postv, p.post_b = vec + 512, p.post_eps = 1e-6f;
+                char shape[64];
+                snprintf(shape, sizeof shape, "%s %s", pt.name, layer == 0 ? "proj" : "fc2");
+                p.Wsplit = Wi1;
+                if (C == 256) run_rowln_ref<2, 2, 4>(shape, p);
+                else run_rowln_ref<4, 1, 7>(shape, p);
+                run_rowln_grouped_bits(shape, p, C == 256 ? 64 : 128);
+                p.Wsplit = Wi, p.wlayout = 2;
+                if (C == 256) {
+                    if (layer == 0) run_rowln<16, 8, 0, 4>(shape, p);
+                    else run_rowln<16, 8, 1, 4>(shape, p);
+                } else {
+                    if (layer == 0) run_rowln<14, 8, 0, 5>(shape, p);
+                    else run_rowln<14, 8, 1, 5>(shape, p);
+                }
+            }
+        }
+    }
     for (const Part& pt : parts) {
         const int C = pt.C;
         for (int layer = 0; layer < 2; ++layer) {   // 0 = qkv (N = 3C), 1 = fc1 + GELU (N = 2C); both with the LayerNorm folded
@@ -205,7 +357,10 @@ int main() {
                 run<8, 2, 4, 2, 2, 0>(shape, p);
                 run<8, 2, 4, 2, 2, 1>(shape, p);
                 run2<8, 2, 4, 2>(shape, p);
+                if (N % 96 == 0) run2<6, 2, 4, 2>(shape, p);   // more, narrower tiles: a better last round on 512 workgroups?
+                if (N % 64 == 0) run2<4, 2, 4, 2>(shape, p);
                 run2<8, 2, 8, 2>(shape, p);
+                if (N % 256 == 0) run2<16, 1, 8, 2>(shape, p);
                 run<8, 2, 8, 2, 2, 1>(shape, p);
                 run<8, 1, 8, 3, 2, 1>(shape, p);
                 if (N % 256 == 0) {
@@ -225,6 +380,7 @@ int main() {
                 run<7, 2, 4, 2, 2, 0>(shape, p);
                 run<7, 2, 4, 2, 2, 1>(shape, p);
                 run2<7, 2, 4, 2>(shape, p);
+                run2<14, 1, 8, 2>(shape, p);
                 run<7, 2, 8, 2, 2, 1>(shape, p);
                 run<14, 2, 4, 2, 1, 1>(shape, p);
                 run<14, 1, 8, 2, 2, 1>(shape, p);

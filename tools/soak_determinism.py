@@ -37,7 +37,6 @@ def main():
     single, _ = make_model(20, 10, seed=77)
     single.precision = precision
     single.n_aux_streams = 0
-    single.part_by_part_launches = True      # the launches of the streamed run (the shared grids keep another whole-row epilogue)
     x2d, x2f = gu.synthetic_inputs_2d(B=1)
     noises = gu.synthetic_noises(B=1, P=20, n=10, seed=3)
     model.noise_fn = single.noise_fn = lambda k, shape, device: noises[k]
