@@ -706,7 +706,7 @@ __device__ __forceinline__ void epilogue_row_per_lane(f32x16 (&acc)[NT], const G
 // in LDS and is split into three bf16 slices in registers when a fragment is read (each wave owns its rows, so every A
 // element is split once per workgroup); W comes pre-split (p.Wsplit, the W' image above) and is staged as it lies.  Per
 // 16-deep step lane (r, h) multiplies k = 16*s2 + 8*h + 0..7 - six MFMAs per (A, W) fragment pair.
-// (the body is a device function: gemm_kernel runs it for workgroup blockIdx.x of gridDim.x, grouped_bias_kernel for
+// (the body is a device function: gemm_kernel runs it for workgroup blockIdx.x of gridDim.x, the shared-grid kernels for
 // workgroup b of the nb of one slot of a grouped launch; nb may exceed the tile count, surplus workgroups return)
 template <int WM, int WN, int NT, int EPI, int NSTAGE, int TR = 0, int BF16 = 0>
 __device__ __forceinline__ void gemm_tile(const GemmParams& p, const int b, const int nb, float* smem) {
@@ -1645,27 +1645,6 @@ __global__ void __launch_bounds__(256, 2) grouped_rowln_kernel(const GroupedGemm
         case 224: gemm_dma_tile<4, 1, 7, EPI, 2, 0, 16, false>(p, lb, nb, smem); break;
         default: break;
     }
-}
-
-// The plain layers (qkv, fc1 + GELU) of the parts in one grid, same slot scheme: split-precision register-staged tiles,
-// 128 x 128 where N allows, else 128 x 64, else 128 x 96 (row-per-lane epilogue); three workgroups per CU.
-template <int EPI>
-__global__ void __launch_bounds__(256, 3) grouped_bias_kernel(const GroupedGemmParams g) {
-    PAFUSE_XQ_GUARD();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x;
-    int s = 0;
-#pragma unroll
-    for (int i = 1; i < GROUP_MAX; ++i)
-        if (i < g.n && b >= g.first[i]) s = i;
-    const GemmParams& p = g.p[s];
-    const int lb = b - g.first[s], nb = g.first[s + 1] - g.first[s];
-    if (p.N % 128 == 0)  // (the order of the per-part dispatch, gemm_bias in pafuse_hip.hip)
-        gemm_tile<4, 1, 4, EPI, 1, 0, 2>(p, lb, nb, smem);
-    else if (p.N % 64 == 0)
-        gemm_tile<4, 1, 2, EPI, 1, 0, 2>(p, lb, nb, smem);
-    else
-        gemm_tile<4, 1, 3, EPI, 1, 1, 2>(p, lb, nb, smem);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -568,18 +568,15 @@ bool group_ok_rowln(const GemmParams& p) {
     return p.bf16 == 2 && p.Wsplit && (p.N == 384 || p.N == 256 || (p.N == 224 && p.M >= 4096)) && p.K % 16 == 0 && p.K > 0 &&
            !(debug_f32_mask() & 2);
 }
-bool group_ok_bias(const GemmParams& p) {   // (layout-0 images only: the shared plain grid is the 32x32x16 tile; since round 6 qkv AND fc1 carry M16
-    //                                             images and go part by part through the persistent strip kernel, which fills the chip alone)
-    return p.bf16 == 2 && p.Wsplit && p.wlayout == 0 && (p.N % 64 == 0 || p.N % 96 == 0) && p.K % BK == 0 && p.K > 0 && p.M >= 4096 &&
-           !(debug_f32_mask() & 29);
-}
+// (the plain layers - qkv, fc1 - have no shared grid since round 6: the persistent strip kernel fills the chip from one part's tiles;
+// grouped_bias_kernel, the shared 32x32x16 grid of rounds 3 - 5, is gone)
 // (whether the parts of a configuration share grids is the caller's choice per call: pafuse_d3dp_config.part_by_part_launches -
 // same tiles, same arithmetic, same bits either way; there is no process-wide schedule state)
 
 template <bool ROWLN>
 int gemm_group(const GemmParams* ps, int n, hipStream_t s, bool shared_grids) {
-    bool ok = shared_grids && n >= 2 && n <= GROUP_MAX;
-    for (int i = 0; i < n && ok; ++i) ok = ps[i].M > 0 && (ROWLN ? group_ok_rowln(ps[i]) : group_ok_bias(ps[i]));
+    bool ok = ROWLN && shared_grids && n >= 2 && n <= GROUP_MAX;
+    for (int i = 0; i < n && ok; ++i) ok = ps[i].M > 0 && group_ok_rowln(ps[i]);
     if (!ok) {
         for (int i = 0; i < n; ++i) {
             const int rc = ROWLN ? gemm_rowln(ps[i], s) : gemm_bias(ps[i], s);
@@ -594,8 +591,7 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s, bool shared_grids) {
     for (int i = 0; i < n; ++i) {
         const GemmParams& p = ps[i];
         int bm, bn;
-        if (ROWLN) bm = p.N == 224 ? 128 : 64, bn = p.N;
-        else bm = 128, bn = p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 96);
+        bm = p.N == 224 ? 128 : 64, bn = p.N;
         tiles[i] = (p.M + bm - 1) / bm * (p.N / bn);
         cost[i] = (double)bm * bn * p.K;
         order[i] = i;
@@ -612,20 +608,13 @@ int gemm_group(const GemmParams* ps, int n, hipStream_t s, bool shared_grids) {
     }
     g.first[n] = (int)first;
     for (int k = n + 1; k <= GROUP_MAX; ++k) g.first[k] = (int)first;
-    if (ROWLN) {
-        constexpr size_t lds = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES;  // the widest variant's ring
-        static_assert(lds >= 2 * DmaTile<2, 2, 4, 16>::STAGE_BYTES && lds >= 2 * DmaTile<4, 1, 7, 16>::STAGE_BYTES && lds <= 80 * 1024, "LDS");
-        auto k = grouped_rowln_kernel<EPI_ROWLN>;
-        static DeviceOnce once;
-        if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k, dim3((unsigned)first), dim3(256), lds, s, g);
-        return check_launch("grouped_rowln_kernel");
-    } else {
-        constexpr size_t lds = GemmTile<4, 1, 4>::STAGE_FLOATS_SPLIT * sizeof(float);
-        static_assert(lds <= 64 * 1024, "LDS");
-        hipLaunchKernelGGL(grouped_bias_kernel<EPI_BIAS>, dim3((unsigned)first), dim3(256), lds, s, g);
-        return check_launch("grouped_bias_kernel");
-    }
+    constexpr size_t lds = 2 * DmaTile<2, 2, 6, 16>::STAGE_BYTES;  // the widest variant's ring
+    static_assert(lds >= 2 * DmaTile<2, 2, 4, 16>::STAGE_BYTES && lds >= 2 * DmaTile<4, 1, 7, 16>::STAGE_BYTES && lds <= 80 * 1024, "LDS");
+    auto k = grouped_rowln_kernel<EPI_ROWLN>;
+    static DeviceOnce once;
+    if (once.first()) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)first), dim3(256), lds, s, g);
+    return check_launch("grouped_rowln_kernel");
 }
 
 bool width_supported(int C) { return C == 384 || C == 288 || C == 256 || C == 224 || C == 128 || C == 64; }
@@ -925,7 +914,7 @@ int run_blocks(const BlockLaunch* bl, int n, hipStream_t s, bool gemms_only = fa
         bool all = grouped;
         for (int i = 0; i < n; ++i) {
             g[i] = bl[i].*which;
-            all = all && g[i].M > 0 && (rowln ? group_ok_rowln(g[i]) : group_ok_bias(g[i]));
+            all = all && rowln && g[i].M > 0 && group_ok_rowln(g[i]);
         }
         const int r = rowln ? gemm_group<true>(g, n, s, shared_grids) : gemm_group<false>(g, n, s, shared_grids);
         if (flops) {

@@ -43,7 +43,8 @@ struct StripTile {
 // position swizzle of the A stage (see the header): x = (row >> 1) & 7
 __device__ __forceinline__ int strip_f(int x) { return x ^ ((((x + 2) >> 2) & 1) << 1); }
 
-enum { SEPI_BIAS = 0, SEPI_ROWLN = 1 };
+enum { SEPI_BIAS = 0 };   // (a whole-row form, SEPI_ROWLN, was built and measured in round 6 - it ties the LDS-DMA whole-row kernels and is
+//                           not part of the library: profiles/r06_whole_row_strip_experiment.patch, profiles/r06_sgemm_whole_row_strip_experiment.log)
 
 // -DSGEMM_STAMPS (tools/sgemm_bench.hip only): per wave, shader cycles summed over its stream in four phases - [0] waiting at the top of
 // a chunk (counted vmcnt + barrier), [1] A fragment reads + split, [2] the MFMA groups with the refill DMA in their shadow, [3] epilogues -
@@ -63,16 +64,36 @@ __device__ __forceinline__ unsigned long long sgemm_stamp() {
 #define SGEMM_ADD(i, a, b)
 #endif
 
-// EPI = SEPI_BIAS:  out = act(acc + bias)  |  act(rstd * acc + lt)  with the LayerNorm folded (p.ln_in; A is the centred row)
-// EPI = SEPI_ROWLN (BN == p.N): the whole-row chain of GemmParams (inference forms): y = acc + bias + resid; post LayerNorm; + pos;
-//       then statistics + centred store (folded), or the next LayerNorm -> out_n, or the head.
-template <int NB, int RG, int NW, int NSTAGE, int EPI, int MINW, int FLAGS>
-__global__ void __launch_bounds__(NW * 64, MINW) sgemm_kernel(const GemmParams p) {
-    constexpr bool LNIN = (FLAGS & 1) != 0, ACT = (FLAGS & 2) != 0;   // compile-time: the epilogue is straight-line code
+// ----------------------------------------------------------------------------------------------------------------
+// sgemm2_kernel - the strip GEMM with the two per-tile costs that the stamps of its plain first form show (sgemm_kernel, kept for
+// the A/B in tools/sgemm_v1.hpp; tools/sgemm_bench.hip, profiles/r06_sgemm_v1_stamps_and_ablations.log: the in-register split of the A
+// fragment 23 % of a chunk, the epilogue 18 - 27 % of a tile) taken off a wave's critical path:
+//   * A runs ONE CHUNK AHEAD of W' through the same two-stage ring.  A rows are private to their wave, so the fragment of chunk
+//     g + 1 is read (own vmcnt, no barrier) at the top of chunk g and split into its three bf16 slices in the gaps of chunk g's
+//     MFMAs, one SplitPair stage per gap (hand-placed, order pinned through data as in gemm_dma_tile); its LDS slot is then free and
+//     the DMA of chunk g + 3 goes into it mid-chunk.  W' of chunk g + 1 is issued in the first gaps of chunk g.  In flight at the top of a
+//     chunk: only the A rows two chunks ahead - `s_waitcnt vmcnt(IA)`.
+//   * DEFERRED STORES: at the end of a tile the epilogue arithmetic (bias / folded LayerNorm / GELU) runs at once into a second
+//     register set `fin`, the accumulators restart at zero, and the 1 KiB store instructions of `fin` are issued four per chunk inside
+//     the gaps of the NEXT tile's first chunks (the last tile of the stream flushes at the end).  A wave never sits in a store queue.
+// Same products in the same order as sgemm_kernel / gemm16_tile: equal bits.
+// ----------------------------------------------------------------------------------------------------------------
+#define SGEMM_PIN_ACC(A) asm volatile("" : "+v"(A))
+#define SGEMM_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
+
+// FLAGS (compile-time, so that the epilogue is straight-line code with every load issued up front): bit 0 = folded LayerNorm
+// (p.ln_in), bit 1 = GELU (p.act)
+template <int NB, int RG, int NW, int EPI, int MINW, int FLAGS>
+__global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams p) {
+    constexpr bool LNIN = (FLAGS & 1) != 0, ACT = (FLAGS & 2) != 0;
     PAFUSE_XQ_GUARD();
-    using T = StripTile<NB, RG, NW, NSTAGE>;
-    constexpr int BM = T::BM, BN = T::BN, IA = T::IA, IW = T::IW, IWT = T::IWT, CNT = T::CNT;
-    constexpr int NST = T::NSTC;   // dwordx4 stores per lane that the epilogue of a FULL tile issues at least, in every wave
+    using T = StripTile<NB, RG, NW, 2>;
+    constexpr int BM = T::BM, BN = T::BN, IA = T::IA, IW = T::IW, IWT = T::IWT;
+    constexpr int TOT = NB * RG * 6;          // MFMAs (= filler slots) of a chunk
+    constexpr int NSPLIT = RG * 4 * 5;        // split stage-steps of one chunk's A fragments (4 pairs x 5 stages per row group)
+    constexpr int SPC = 4;                    // deferred stores per chunk
+    constexpr int NSTORE = RG * NB, KST = (NSTORE + SPC - 1) / SPC;   // chunks of the next tile that carry them (host: nk >= KST)
+    static_assert(TOT >= 48, "filler schedule needs room");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;
@@ -87,302 +108,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm_kernel(const GemmParams p
     if (b >= ntiles) return;
     const int my_tiles = (ntiles - b + G - 1) / G;
     const int K = p.K, nk = K / 32;
-    const int total = my_tiles * nk;   // chunks of this workgroup's stream
-    // XCD-aware order (kernels.hpp): virtual workgroup v = b + j G of `ntiles` (G is a multiple of 8 or >= ntiles, so v & 7 == b & 7)
-    auto tile_of = [&](int j, int& tm, int& tn) {
-        const int v = b + j * G;
-        const int xcd = v & 7, q = ntiles >> 3, rem = ntiles & 7;
-        const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (v >> 3);
-        tm = tile / tiles_n, tn = tile % tiles_n;
-    };
-
-    // ---- DMA side: the issue cursor (tile index ij, chunk ikc) runs NSTAGE - 1 chunks ahead of the compute cursor
-    const int64_t ws_chunk = (int64_t)p.N * WSPLIT_ROW_BYTES;
-    int ij = 0, ikc = 0, ig = 0;     // next chunk to issue: tile ij of mine, chunk ikc; ig = its index in the stream
-    int a_off[IA];                   // float offset of this lane's source in A instruction i (row base + swizzled chunk), current issue tile
-    const uint8_t* w_src = nullptr;  // this lane's source of W' instruction 0, chunk 0, current issue tile
-    auto issue_tile_setup = [&]() {
-        int tm, tn;
-        tile_of(ij, tm, tn);
-        const int64_t m0 = (int64_t)tm * BM;
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const int64_t row = m0 + wave * (RG * 16) + 8 * i + (lane >> 3);
-            const int x = (4 * (i & 1) + (lane >> 4)) & 7;
-            const int ch = (lane & 7) ^ strip_f(x);
-            a_off[i] = (int)((row < p.M ? row : p.M - 1) * K) + 4 * ch;   // rows past the last token read a valid row (never stored)
-        }
-        w_src = p.Wsplit + (int64_t)tn * BN * WSPLIT_ROW_BYTES + lane * 16;
-    };
-    auto issue_piece = [&](int j) {   // DMA instruction slot j (0 .. CNT - 1) of the chunk under the issue cursor
-        uint8_t* const sa = lds + (ig % NSTAGE) * T::STAGE_BYTES;
-        if (j < IA) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + ikc * 32 + a_off[j]),
-                                             (__attribute__((address_space(3))) void*)(sa + wave * T::A_WAVE + j * 1024), 16, 0, 0);
-        } else {
-            int i = wave + (j - IA) * NW;   // wave-uniform
-            i = i < IWT ? i : IWT - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src + ikc * ws_chunk + i * 1024),
-                                             (__attribute__((address_space(3))) void*)(sa + T::A_BYTES + i * 1024), 16, 0, 0);
-        }
-    };
-    auto issue_advance = [&]() {
-        ++ig;
-        if (++ikc == nk) {
-            ikc = 0, ++ij;
-            if (ij < my_tiles) issue_tile_setup();
-        }
-    };
-
-    // ---- fragment addresses (bytes inside a stage)
-    const int fc = strip_f((c >> 1) & 7);
-    const uint32_t a_frag = (uint32_t)(wave * T::A_WAVE + c * 128 + (((2 * qd) ^ fc) * 16));   // + g * 2048; second half at ^ 16
-    const uint32_t w_frag = (uint32_t)(T::A_BYTES + c * WSPLIT_ROW_BYTES + wsplit_sub_offset<32, 1>(c, qd));   // + nb * 3072
-
-    f32x4 acc[RG][NB];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int g = 0; g < RG; ++g)
-#pragma unroll
-            for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-
-    // ---- prologue: the first NSTAGE - 1 chunks of the stream
-    issue_tile_setup();
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (ig < total) {
-#pragma unroll
-            for (int j = 0; j < CNT; ++j) issue_piece(j);
-            issue_advance();
-        }
-
-#ifdef SGEMM_STAMPS
-    unsigned long long st_acc[4] = {0, 0, 0, 0};
-    const unsigned long long st_begin = sgemm_stamp();
-    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
-#endif
-    int g_idx = 0;   // compute cursor in the stream
-    bool prev_counted = false;   // the previous tile was a full tile: every wave issued its NST epilogue stores (a wave whose rows
-    //                              are all past M branches around them, so a ragged tile's stores cannot be counted on)
-    for (int tj = 0; tj < my_tiles; ++tj) {
-        int tm, tn;
-        tile_of(tj, tm, tn);
-        const int64_t m0 = (int64_t)tm * BM;
-        const int n0 = tn * BN;
-        for (int kc = 0; kc < nk; ++kc, ++g_idx) {
-            // chunk g_idx has landed once at most the younger operations of this wave are still in flight: the DMAs of the chunks
-            // g_idx + 1 .. g_idx + NSTAGE - 2 and - in the first NSTAGE - 1 chunks behind an epilogue - that epilogue's stores
-            SGEMM_T(t0);
-            const int younger = total - 1 - g_idx;   // chunks of the stream behind this one
-            if (younger >= NSTAGE - 2) {
-                if (prev_counted && kc < NSTAGE - 1) wait_vmcnt<CNT*(NSTAGE - 2) + NST>();
-                else wait_vmcnt<CNT*(NSTAGE - 2)>();
-            } else {
-                wait_vmcnt<0>();
-            }
-            __builtin_amdgcn_s_barrier();   // W' of chunk g_idx visible to every wave; every wave is done reading chunk g_idx - 1
-            SGEMM_T(t1);
-            SGEMM_ADD(0, t0, t1);
-            const bool refill = ig < total;  // (ig == g_idx + NSTAGE - 1 while there is work left)
-            const uint32_t sbase = lds0 + (uint32_t)((g_idx % NSTAGE) * T::STAGE_BYTES);
-
-            __builtin_amdgcn_s_setprio(1);
-            u32x4 a_lo[RG], a_hi[RG];
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                a_lo[g] = lds_read128<0>(sbase + a_frag + g * 2048);
-                a_hi[g] = lds_read128<0>(sbase + (a_frag ^ 16u) + g * 2048);
-            }
-            u32x4 wf[2][3];
-            auto load_w = [&](auto N_) {
-                constexpr int n = decltype(N_)::value;
-                constexpr int off = n * 16 * WSPLIT_ROW_BYTES;
-                static_assert(off + 32 < 65536, "ds_read immediate");
-                const uint32_t addr = sbase + w_frag;
-                wf[n & 1][0] = lds_read128<off>(addr);
-                wf[n & 1][1] = lds_read128<off + 16>(addr);
-                wf[n & 1][2] = lds_read128<off + 32>(addr);
-            };
-            load_w(std::integral_constant<int, 0>{});
-            bf16x8x3 a[RG];
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                // the reads behind this fragment's pair stay in flight: 2 (RG - 1 - g) of A + 3 of W'
-                if (g == 0 && RG == 2) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a_lo[0]), "+v"(a_hi[0]));
-                else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a_lo[g]), "+v"(a_hi[g]));
-#if defined(SGEMM_ABL) && (SGEMM_ABL & 1)   // ablation (results wrong): the raw fragment bits as slices - what the K loop costs without the split
-                a[g].s0 = __builtin_bit_cast(bf16x8, a_lo[g]), a[g].s1 = __builtin_bit_cast(bf16x8, a_hi[g]), a[g].s2 = a[g].s0;
-#else
-                a[g] = split3(__builtin_bit_cast(f32x4, a_lo[g]), __builtin_bit_cast(f32x4, a_hi[g]));
-#endif
-            }
-            SGEMM_T(t2);
-            SGEMM_ADD(1, t1, t2);
-            static_for<NB>([&](auto N_) {
-                constexpr int n = decltype(N_)::value;
-                if constexpr (n + 1 < NB) {
-                    load_w(std::integral_constant<int, n + 1>{});
-                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[n & 1][0]), "+v"(wf[n & 1][1]), "+v"(wf[n & 1][2]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wf[n & 1][0]), "+v"(wf[n & 1][1]), "+v"(wf[n & 1][2]));
-                }
-                const bf16x8 w0 = __builtin_bit_cast(bf16x8, wf[n & 1][0]);
-                const bf16x8 w1 = __builtin_bit_cast(bf16x8, wf[n & 1][1]);
-                const bf16x8 w2 = __builtin_bit_cast(bf16x8, wf[n & 1][2]);
-#pragma unroll
-                for (int g = 0; g < RG; ++g) {   // small terms first, the leading product last
-                    acc[g][n] = mfma16_bf16_k32(w0, a[g].s2, acc[g][n]);
-                    acc[g][n] = mfma16_bf16_k32(w2, a[g].s0, acc[g][n]);
-                    acc[g][n] = mfma16_bf16_k32(w1, a[g].s1, acc[g][n]);
-                    acc[g][n] = mfma16_bf16_k32(w0, a[g].s1, acc[g][n]);
-                    acc[g][n] = mfma16_bf16_k32(w1, a[g].s0, acc[g][n]);
-                    acc[g][n] = mfma16_bf16_k32(w0, a[g].s0, acc[g][n]);
-                }
-                {   // this column block's share of the refill DMA, in the shadow of the MFMAs just issued
-                    constexpr int PER = (CNT + NB - 1) / NB, j0 = n * PER, j1 = (n + 1) * PER < CNT ? (n + 1) * PER : CNT;
-                    if constexpr (j0 < j1) {
-                        asm volatile("" ::: "memory");
-                        if (refill) {
-#pragma unroll
-                            for (int j = j0; j < j1; ++j) issue_piece(j);
-                        }
-                        asm volatile("" ::: "memory");
-                    }
-                }
-            });
-            __builtin_amdgcn_s_setprio(0);
-            if (refill) issue_advance();
-            SGEMM_T(t3);
-            SGEMM_ADD(2, t2, t3);
-        }
-        SGEMM_T(t4);
-
-        // ---- epilogue of tile tj: lane (c, qd) owns token m0 + wave RG 16 + 16 g + c, columns n0 + 16 n + 4 qd + {0,1,2,3}
-#if defined(SGEMM_ABL) && (SGEMM_ABL & 2)   // ablation (results wrong): no epilogue - the accumulators are kept alive, nothing is stored
-        {
-            float sacc = 0.f;
-#pragma unroll
-            for (int g = 0; g < RG; ++g)
-#pragma unroll
-                for (int n = 0; n < NB; ++n) sacc += acc[g][n][0] + acc[g][n][1] + acc[g][n][2] + acc[g][n][3];
-            if (sacc == 123.456f) p.out[0] = sacc;
-        }
-        if constexpr (false) {
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
-#else
-        if constexpr (EPI == SEPI_BIAS) {
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
-#endif
-                const bool live = m < p.M;
-                const int64_t mm = live ? m : p.M - 1;
-                float rstd = 1.0f;
-                if constexpr (LNIN) rstd = p.ln_in[2 * mm + 1];   // folded LayerNorm (A is the centred row): the lane owns the token
-                float* const orow = p.out + mm * p.N + n0 + 4 * qd;
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
-                    f32x4 v;
-                    if constexpr (LNIN) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
-                    }
-                    if constexpr (ACT) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    if (live) *reinterpret_cast<f32x4*>(orow + 16 * n) = v;
-                }
-            }
-        }
-        prev_counted = m0 + BM <= p.M;
-        zero_acc();
-        SGEMM_T(t5);
-        SGEMM_ADD(3, t4, t5);
-    }
-#ifdef SGEMM_STAMPS
-    if (p.stamps && lane == 0) {
-        unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
-        o[0] = st_acc[0], o[1] = st_acc[1], o[2] = st_acc[2], o[3] = st_acc[3];
-        o[4] = sgemm_stamp() - st_begin, o[5] = __builtin_amdgcn_s_memrealtime() - rt_begin;
-    }
-#endif
-}
-
-
-// ----------------------------------------------------------------------------------------------------------------
-// sgemm2_kernel - the strip GEMM with the two per-tile costs that the stamps of sgemm_kernel show (tools/sgemm_bench.hip,
-// profiles/r06_sgemm_*.log: the in-register split of the A fragment 23 % of a chunk, the epilogue 18 - 27 % of a tile) taken off a
-// wave's critical path:
-//   * A runs ONE CHUNK AHEAD of W' through the same two-stage ring.  A rows are private to their wave, so the fragment of chunk
-//     g + 1 is read (own vmcnt, no barrier) at the top of chunk g and split into its three bf16 slices in the gaps of chunk g's
-//     MFMAs, one SplitPair stage per gap (hand-placed, order pinned through data as in gemm_dma_tile); its LDS slot is then free and
-//     the DMA of chunk g + 3 goes into it mid-chunk.  W' of chunk g + 1 is issued in the first gaps of chunk g.  In flight at the top of a
-//     chunk: only the A rows two chunks ahead - `s_waitcnt vmcnt(IA)`.
-//   * DEFERRED STORES: at the end of a tile the epilogue arithmetic (bias / folded LayerNorm / GELU) runs at once into a second
-//     register set `fin`, the accumulators restart at zero, and the 1 KiB store instructions of `fin` are issued four per chunk inside
-//     the gaps of the NEXT tile's first chunks (the last tile of the stream flushes at the end).  A wave never sits in a store queue.
-// Same products in the same order as sgemm_kernel / gemm16_tile: equal bits.
-// ----------------------------------------------------------------------------------------------------------------
-#define SGEMM_PIN_ACC(A) asm volatile("" : "+v"(A))
-#define SGEMM_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
-
-// FLAGS (compile-time, so that the epilogue is straight-line code with every load issued up front):
-//   EPI = SEPI_BIAS :  bit 0 = folded LayerNorm (p.ln_in), bit 1 = GELU (p.act)
-//   EPI = SEPI_ROWLN:  bit 0 = a post LayerNorm (p.post_w: fc2), bit 1 = the head form (p.out_head: the last block) instead of the
-//                      folded statistics + centred store
-// SEPI_ROWLN (the workgroup's tile is BM whole rows, BN == p.N; inference with the LayerNorm folded into the consumer, GemmParams):
-//   y = acc + bias + resid ;  z = POST ? LN(y; post) : y ;  z += pos[(m / posJ) % posF] if pos ;
-//   folded: (mean, rstd) of z -> ln_stats[m], out_x = z - mean      |  HEAD: n = LN(z; next), out_head = n head_w^T + head_b
-// All of it in registers: a token's row of the tile sits in the four lanes (c, qd = 0..3) of one wave.  The residual rows are
-// loaded into `fin` at the end of the tile (its previous contents left in the first chunks); bias / post_w / post_b are staged once per
-// workgroup in LDS behind the ring.  (Prefetching the residual rows inside the last chunks was tried first: hipcc either folds the
-// per-chunk if-chain into a dynamically indexed store - `fin` in scratch - or waits vmcnt(0) behind every load.)
-template <int NB, int RG, int NW, int EPI, int MINW, int FLAGS, int SPC = 4>
-__global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams p) {
-    constexpr bool ROWLN = EPI == SEPI_ROWLN;
-    constexpr bool LNIN = !ROWLN && (FLAGS & 1) != 0, ACT = !ROWLN && (FLAGS & 2) != 0;
-    constexpr bool POST = ROWLN && (FLAGS & 1) != 0, HEAD = ROWLN && (FLAGS & 2) != 0;
-    PAFUSE_XQ_GUARD();
-    using T = StripTile<NB, RG, NW, 2>;
-    constexpr int BM = T::BM, BN = T::BN, IA = T::IA, IW = T::IW, IWT = T::IWT;
-    constexpr int TOT = NB * RG * 6;          // MFMAs (= filler slots) of a chunk
-    constexpr int NSPLIT = RG * 4 * 5;        // split stage-steps of one chunk's A fragments (4 pairs x 5 stages per row group)
-    //                                           SPC: deferred stores (and residual loads) per chunk
-    constexpr int NSTORE = RG * NB, KST = (NSTORE + SPC - 1) / SPC;   // chunks of the next tile that carry them (host: nk >= KST)
-    constexpr int VEC_OFF = 2 * T::STAGE_BYTES;   // SEPI_ROWLN: bias | post_w | post_b, BN floats each, behind the ring
-    static_assert(TOT >= 48 && TOT / SPC >= 4, "filler schedule needs room");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    uint8_t* const lds = reinterpret_cast<uint8_t*>(smem);
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c = lane & 15, qd = lane >> 4;
-
-    const int tiles_n = ROWLN ? 1 : p.N / BN;
-    const int tiles_m = (int)((p.M + BM - 1) / BM);
-    const int ntiles = tiles_m * tiles_n;
-    const int b = blockIdx.x, G = gridDim.x;
-    if (b >= ntiles) return;
-    const int my_tiles = (ntiles - b + G - 1) / G;
-    const int K = p.K, nk = K / 32;
     const int total = my_tiles * nk;
-    if constexpr (ROWLN) {   // the per-column vectors of the chain, once per workgroup (before any DMA is in flight)
-        float* const vec = smem + VEC_OFF / 4;
-        for (int i = tid; i < BN; i += T::NTHR) {
-            vec[i] = p.bias[i];
-            if constexpr (POST) vec[BN + i] = p.post_w[i], vec[2 * BN + i] = p.post_b[i];
-        }
-        __syncthreads();
-    }
     auto tile_of = [&](int j, int& tm, int& tn) {
         const int v = b + j * G;
         const int xcd = v & 7, q = ntiles >> 3, rem = ntiles & 7;
@@ -451,9 +177,8 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
         for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f}, fin[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     float* fin_ptr[RG];     // row base of the pending tile's stores (+ 16 n)
     bool fin_live[RG];
-    const float* rsd_ptr[RG];   // SEPI_ROWLN: row base of the current tile's residual rows
 #pragma unroll
-    for (int g = 0; g < RG; ++g) fin_ptr[g] = ROWLN ? p.out_x : p.out, fin_live[g] = false, rsd_ptr[g] = p.resid;
+    for (int g = 0; g < RG; ++g) fin_ptr[g] = p.out, fin_live[g] = false;
     bool pend = false;
 
     u32x4 cur[RG][3];       // the three slices of the current chunk's A fragments
@@ -503,13 +228,6 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
         tile_of(tj, tm, tn);
         const int64_t m0 = (int64_t)tm * BM;
         const int n0 = tn * BN;
-        if constexpr (ROWLN) {
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
-                rsd_ptr[g] = p.resid + (m < p.M ? m : p.M - 1) * p.N + 4 * qd;
-            }
-        }
         for (int kc = 0; kc < nk; ++kc, ++g_idx) {
             // in flight at most: the A rows of chunk g_idx + 2 (issued mid-chunk g_idx - 1, behind W' of this chunk).  Deferred stores are
             // not counted: an operation assumed absent only makes the wait stricter.
@@ -602,7 +320,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
                         asm volatile("" ::: "memory");
                     }
                     // (iv) SPC deferred stores of the previous tile, spread over the chunk
-                    if constexpr (t % (TOT / SPC) == TOT / SPC - 3 && t / (TOT / SPC) < SPC) {
+                    if constexpr (t % (TOT / SPC) == TOT / SPC - 3) {
                         constexpr int i = t / (TOT / SPC);
                         if (st_now) {
                             static_for<KST>([&](auto C_) {
@@ -629,140 +347,36 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
         SGEMM_T(t4);
 
         // ---- end of tile tj: the epilogue arithmetic into `fin` (lane (c, qd): token m0 + wave RG 16 + 16 g + c, columns n0 + 16 n + 4 qd + ..)
-        if constexpr (!ROWLN) {
+        static_assert(EPI == SEPI_BIAS, "the plain form is the one in the library");
 #pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
-                const bool live = m < p.M;
-                const int64_t mm = live ? m : p.M - 1;
-                float rstd = 1.0f;
-                if constexpr (LNIN) rstd = p.ln_in[2 * mm + 1];
-                fin_ptr[g] = p.out + mm * p.N + n0 + 4 * qd;
-                fin_live[g] = live;
+        for (int g = 0; g < RG; ++g) {
+            const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
+            const bool live = m < p.M;
+            const int64_t mm = live ? m : p.M - 1;
+            float rstd = 1.0f;
+            if constexpr (LNIN) rstd = p.ln_in[2 * mm + 1];
+            fin_ptr[g] = p.out + mm * p.N + n0 + 4 * qd;
+            fin_live[g] = live;
 #pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
-                    f32x4 v;
-                    if constexpr (LNIN) {
+            for (int n = 0; n < NB; ++n) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
+                f32x4 v;
+                if constexpr (LNIN) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
-                    }
-                    if constexpr (ACT) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    fin[g][n] = v;
-                    acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        } else {
-            const float* const vec = smem + VEC_OFF / 4 + 4 * qd;   // + 16 n (+ BN: post_w, + 2 BN: post_b)
-            const float invC = 1.0f / (float)p.N;
-            auto row_sum = [&](float v) {   // over the row's four lanes (c, qd = 0..3)
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                return v;
-            };
-#pragma unroll
-            for (int g = 0; g < RG; ++g) {
-                const int64_t m = m0 + wave * (RG * 16) + 16 * g + c;
-                const bool live = m < p.M;
-                const int64_t mm = live ? m : p.M - 1;
-                f32x4(&y)[NB] = acc[g];
-#pragma unroll
-                for (int n = 0; n < NB; ++n) fin[g][n] = *reinterpret_cast<const f32x4*>(rsd_ptr[g] + 16 * n);
-#pragma unroll
-                for (int n = 0; n < NB; ++n) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + 16 * n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[n][e] = (y[n][e] + b4[e]) + fin[g][n][e];   // (acc + bias) + residual
-                }
-                // the two fixed-order reductions of a LayerNorm: mean, then the centred second moment
-                auto stats = [&](float eps, float& mean, float& rstd) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int n = 0; n < NB; ++n)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s += y[n][e];
-                    mean = row_sum(s) * invC;
-                    asm volatile("" : "+v"(mean));   // ONE rounded value: `y - mean` must not contract into an fma on the unrounded product
-                    float q = 0.f;
-#pragma unroll
-                    for (int n = 0; n < NB; ++n)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = y[n][e] - mean;
-                            q = fmaf(d, d, q);
-                        }
-                    rstd = 1.0f / sqrtf(fmaf(row_sum(q), invC, eps));
-                };
-                if constexpr (POST) {
-                    float mean, rstd;
-                    stats(p.post_eps, mean, rstd);
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(vec + BN + 16 * n);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(vec + 2 * BN + 16 * n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[n][e] = fmaf((y[n][e] - mean) * rstd, g4[e], b4[e]);
-                    }
-                }
-                if (p.pos) {   // only the first spatial block of a pass (workgroup-uniform)
-                    const float* const pe = p.pos + (int64_t)((mm / p.posJ) % p.posF) * p.N + 4 * qd;
-#pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        const f32x4 e4 = *reinterpret_cast<const f32x4*>(pe + 16 * n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[n][e] += e4[e];
-                    }
-                }
-                float mean, rstd;
-                stats(p.next_eps, mean, rstd);
-                if constexpr (!HEAD) {
-                    // the next LayerNorm is folded into the GEMM that consumes the row: its statistics, and the row CENTRED on its mean
-                    if (live && qd == 0) {
-                        p.ln_stats[2 * m] = mean;
-                        p.ln_stats[2 * m + 1] = rstd;
-                    }
-                    fin_ptr[g] = p.out_x + mm * p.N + 4 * qd;
-                    fin_live[g] = live;
-#pragma unroll
-                    for (int n = 0; n < NB; ++n)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) fin[g][n][e] = y[n][e] - mean;
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(rstd, acc[g][n][e], b4[e]);
                 } else {
-                    // the head keeps its own LayerNorm (eps 1e-5) and Linear(C -> 3): common/mixste.py:207-210
-                    const float* const gw = p.next_w + 4 * qd;
-                    const float* const gb = p.next_b + 4 * qd;
-                    float s3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gw + 16 * n);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(gb + 16 * n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) y[n][e] = fmaf((y[n][e] - mean) * rstd, g4[e], b4[e]);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const f32x4 hw = *reinterpret_cast<const f32x4*>(p.head_w + k * p.N + 4 * qd + 16 * n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) s3[k] = fmaf(y[n][e], hw[e], s3[k]);
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float s = row_sum(s3[k]);
-                        if (live && qd == 0) p.out_head[m * 3 + k] = s + p.head_b[k];
-                    }
-                    fin_live[g] = false;
+                    for (int e = 0; e < 4; ++e) v[e] = acc[g][n][e] + b4[e];
                 }
+                if constexpr (ACT) {
 #pragma unroll
-                for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                fin[g][n] = v;
+                acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        pend = !HEAD;
+        pend = true;
         SGEMM_T(t5);
         SGEMM_ADD(3, t4, t5);
     }

@@ -426,7 +426,7 @@ __global__ void __launch_bounds__((XfqaTile<LP, DP, HPW>::NTHR), 2) xfqa_kernel(
                 *reinterpret_cast<f32x4*>(Qs + part * ROWS * LDV + row * LDV + cc0 + 4 * h) = v;
             }
         });
-        if (ROWS > TROWS)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
+        if constexpr (ROWS > TROWS)   // LP = 48: the key / value tiles of the last sequence reach 4 rows past the tile - keep them finite
             for (int i = tid; i < 3 * (ROWS - TROWS) * LDV; i += FT::NTHR) {
                 const int part = i / ((ROWS - TROWS) * LDV), rem = i % ((ROWS - TROWS) * LDV);
                 Qs[part * ROWS * LDV + TROWS * LDV + rem] = 0.f;

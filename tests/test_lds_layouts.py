@@ -20,3 +20,9 @@ def test_x_image_stage_fill_equals_reads(shape):
 def test_weight_gradient_stage_fill_equals_reads(shape):
     nb, kb, wn, wk = shape
     assert chk.check_tn_tile(*shape) == 3072 * (nb + kb) and 32 * (nb + kb) == 64 * wn * wk
+
+
+@pytest.mark.parametrize("shape", chk.STRIP_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_strip_kernel_stage_fill_equals_reads(shape):
+    nb, rg, nw = shape
+    assert chk.check_strip_tile(*shape) == nw * rg * 2048 + 16 * nb * 192

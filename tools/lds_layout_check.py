@@ -1,5 +1,5 @@
-"""CPU check of the LDS stages of the X pipeline (pafuse_amd/csrc/xgemm.hpp) and of the large-tile weight-gradient kernel
-(train_kernels.hpp, check_tn_tile): no GPU needed.
+"""CPU check of the LDS stages of the X pipeline (pafuse_amd/csrc/xgemm.hpp), of the large-tile weight-gradient kernel
+(train_kernels.hpp, check_tn_tile) and of the strip kernel of the plain bf16x3 layers (sgemm.hpp, check_strip_tile): no GPU needed.
 
 For every tile shape the library launches it replays, in integers, (a) the LDS-DMA fill of one stage - which source bytes
 (row, slice, sub-block of 8 k) each lane of each 1 KiB wave instruction deposits where - and (b) the fragment reads of the K
@@ -135,11 +135,70 @@ def _assert_b128_conflict_free(addrs, what):
                 assert seen.setdefault(bank, addrs[lane]) == addrs[lane], ("bank conflict",) + tuple(what)
 
 
+def strip_f(x):
+    """position swizzle of the strip kernel's A stage (pafuse_amd/csrc/sgemm.hpp strip_f): x = (row >> 1) & 7"""
+    return x ^ ((((x + 2) >> 2) & 1) << 1)
+
+
+def check_strip_tile(nb_, rg_, nw_):
+    """sgemm2_kernel<NB, RG, NW> (pafuse_amd/csrc/sgemm.hpp): one stage of the strip kernel - the waves' PRIVATE A rows (fp32, 128 bytes
+    per row of a 32-deep chunk, RG groups of 16 rows per wave, filled by RG * 2 DMA instructions of that wave with the swizzle on the
+    source address) and the W' tile in its M16 image layout (rows of 192 bytes, sub-block sb at ((sb + (n >> 1)) & 3) * 48, slices at
+    + 0 / 16 / 32, copied as it lies).  Asserts that lane (c, qd)'s two A reads find row c's 16-byte chunks 2 qd and 2 qd + 1, that its
+    three W' reads find (column 16 nb + c, sub-block qd, slice), and that every ds_read_b128 is conflict-free."""
+    a_wave = rg_ * 2048
+    a_bytes = nw_ * a_wave
+    bn = 16 * nb_
+    lds = {}
+    for wave in range(nw_):
+        for i in range(rg_ * 2):                       # A instruction i of the wave: its rows 8 i .. 8 i + 7
+            for lane in range(64):
+                row = 8 * i + (lane >> 3)
+                x = (4 * (i & 1) + (lane >> 4)) & 7
+                assert x == (row >> 1) & 7
+                ch = (lane & 7) ^ strip_f(x)
+                addr = wave * a_wave + i * 1024 + lane * 16
+                assert addr not in lds
+                lds[addr] = ("A", wave, row, ch)
+    for n in range(bn):                                # the W' tile's chunk of the image, as it lies
+        for sb in range(4):
+            for sl in range(3):
+                addr = a_bytes + n * 192 + ((sb + (n >> 1)) & 3) * 48 + 16 * sl
+                assert addr not in lds
+                lds[addr] = ("W", n, sb, sl)
+    assert len(lds) * 16 == a_bytes + bn * 192
+    for wave in range(nw_):
+        for g in range(rg_):
+            for o in range(2):
+                addrs = []
+                for lane in range(64):
+                    c, qd = lane & 15, lane >> 4
+                    fc = strip_f((c >> 1) & 7)
+                    a0 = wave * a_wave + c * 128 + ((2 * qd) ^ fc) * 16
+                    addr = (a0 ^ 16 if o else a0) + g * 2048
+                    assert lds[addr] == ("A", wave, 16 * g + c, 2 * qd + o), (lane, lds[addr], (16 * g + c, 2 * qd + o))
+                    addrs.append(addr)
+                _assert_b128_conflict_free(addrs, ("strip A", wave, g, o))
+        for nb in range(nb_):
+            for sl in range(3):
+                addrs = []
+                for lane in range(64):
+                    c, qd = lane & 15, lane >> 4
+                    addr = a_bytes + c * 192 + ((qd + (c >> 1)) & 3) * 48 + nb * 16 * 192 + 16 * sl
+                    assert lds[addr] == ("W", 16 * nb + c, qd, sl), (lane, lds[addr])
+                    addrs.append(addr)
+                _assert_b128_conflict_free(addrs, ("strip W'", wave, nb, sl))
+    return a_bytes + bn * 192
+
+
+STRIP_SHAPES = [(8, 2, 4), (7, 2, 4), (6, 2, 4)]
 X_SHAPES = [(4, 2, 2, 16), (4, 1, 7, 16), (4, 1, 3, 16), (4, 2, 6, 16), (2, 2, 4, 16), (4, 1, 9, 16), (4, 1, 6, 16), (5, 1, 3, 16),
             (4, 2, 2, 32), (2, 2, 4, 32), (4, 1, 7, 32)]
 TN_SHAPES = [(8, 8, 4, 2), (12, 4, 4, 2), (6, 6, 3, 2), (7, 7, 7, 1)]
 
 if __name__ == "__main__":
+    for s in STRIP_SHAPES:
+        print(f"sgemm2_kernel<NB={s[0]}, RG={s[1]}, NW={s[2]}>: stage {check_strip_tile(*s)} bytes: fill = reads, no bank conflicts")
     for s in TN_SHAPES:
         print(f"tn_split_big_kernel<NB={s[0]}, KB={s[1]}, WN={s[2]}, WK={s[3]}>: stage {check_tn_tile(*s)} bytes: fill = reads, no bank conflicts")
     for s in X_SHAPES:

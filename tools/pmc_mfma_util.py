@@ -23,7 +23,7 @@ def main():
         d = by[int(r["Dispatch_Id"])]
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["name"], d["grid"], d["wg"] = r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"])
-    gemm = [v for _, v in sorted(by.items()) if any(k in v["name"] for k in ("gemm_kernel", "gemm16_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "grouped_bias_kernel", "hfqa_kernel", "hmlp_kernel", "xfqa_kernel", "xgemm_kernel"))]
+    gemm = [v for _, v in sorted(by.items()) if any(k in v["name"] for k in ("gemm_kernel", "gemm16_kernel", "sgemm2_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "hfqa_kernel", "hmlp_kernel", "xfqa_kernel", "xgemm_kernel"))]
     gemm = gemm[-last - skip:-skip] if skip else gemm[-last:]
     groups = collections.defaultdict(lambda: [0.0, 0.0, 0])
     for v in gemm:

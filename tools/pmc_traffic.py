@@ -22,7 +22,7 @@ import sys
 
 
 def family(name):
-    for key, fam in (("gemm16_kernel", "gemm"), ("grouped_rowln_kernel", "gemm"), ("grouped_bias_kernel", "gemm"), ("gemm_dma_kernel", "gemm"), ("hfqa_kernel", "gemm"), ("hmlp_kernel", "gemm"), ("xfqa_kernel", "gemm"), ("xgemm_kernel", "gemm"), ("hgemm_kernel", "gemm"), ("tn_gemm_kernel", "gemm_dw"), ("gemm_kernel", "gemm"),
+    for key, fam in (("gemm16_kernel", "gemm"), ("sgemm2_kernel", "gemm"), ("grouped_rowln_kernel", "gemm"), ("gemm_dma_kernel", "gemm"), ("hfqa_kernel", "gemm"), ("hmlp_kernel", "gemm"), ("xfqa_kernel", "gemm"), ("xgemm_kernel", "gemm"), ("hgemm_kernel", "gemm"), ("tn_gemm_kernel", "gemm_dw"), ("gemm_kernel", "gemm"),
                      ("attn_backward", "attention_bwd"), ("attn_kernel", "attention"), ("embed_kernel", "embed"),
                      ("finalize_kernel", "finalize"), ("time_embed", "time_embed"), ("split_weights", "split_weights"),
                      ("ln_backward", "ln_bwd")):

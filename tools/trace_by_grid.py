@@ -20,7 +20,7 @@ def main():
         wgs = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
         name = r["Kernel_Name"]
         groups[(name, wgs)].append(us)
-        if any(k in name for k in ("gemm_kernel", "gemm16_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "grouped_bias_kernel", "hgemm_kernel", "hfqa_kernel", "hmlp_kernel", "xfqa_kernel", "xgemm_kernel")) and "tn_gemm" not in name:
+        if any(k in name for k in ("gemm_kernel", "gemm16_kernel", "sgemm2_kernel", "gemm_dma_kernel", "grouped_rowln_kernel", "hgemm_kernel", "hfqa_kernel", "hmlp_kernel", "xfqa_kernel", "xgemm_kernel")) and "tn_gemm" not in name:
             gemm.append((int(r["Start_Timestamp"]), us))
     w = csv.writer(sys.stdout)
     w.writerow(["kernel", "workgroups", "calls", "min_us", "median_us", "max_us"])
