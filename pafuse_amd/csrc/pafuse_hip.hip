@@ -276,6 +276,7 @@ int launch_strip2(const GemmParams& p, hipStream_t s) {
 // stores of a tile go out inside the first four chunks of the next one), a column count one of its tiles divides
 bool strip2_ok(const GemmParams& p) {
     return p.bf16 == 2 && p.wlayout == 2 && !p.out_act && !p.dact_u && p.K % 32 == 0 && p.K >= 128 && p.M > 0 &&
+           p.M * (int64_t)p.N < (int64_t)1 << 31 && p.M * (int64_t)p.K < (int64_t)1 << 31 &&   // (32-bit float offsets of its rows)
            (p.N % 128 == 0 || p.N % 112 == 0 || p.N % 96 == 0);
 }
 template <int NB>

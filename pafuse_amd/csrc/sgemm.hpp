@@ -175,10 +175,9 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
     for (int g = 0; g < RG; ++g)
 #pragma unroll
         for (int n = 0; n < NB; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f}, fin[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float* fin_ptr[RG];     // row base of the pending tile's stores (+ 16 n)
-    bool fin_live[RG];
+    int fin_off[RG];        // float offset in p.out of the pending tile's row stores (+ 16 n); negative: the lane's row is past M (no store)
 #pragma unroll
-    for (int g = 0; g < RG; ++g) fin_ptr[g] = p.out, fin_live[g] = false;
+    for (int g = 0; g < RG; ++g) fin_off[g] = -1;
     bool pend = false;
 
     u32x4 cur[RG][3];       // the three slices of the current chunk's A fragments
@@ -327,7 +326,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
                                 constexpr int cs = decltype(C_)::value, si = cs * SPC + i;
                                 if constexpr (si < NSTORE) {
                                     constexpr int sg = si / NB, sn = si % NB;
-                                    if (kc == cs && fin_live[sg]) *reinterpret_cast<f32x4*>(fin_ptr[sg] + 16 * sn) = fin[sg][sn];
+                                    if (kc == cs && fin_off[sg] >= 0) *reinterpret_cast<f32x4*>(p.out + fin_off[sg] + 16 * sn) = fin[sg][sn];
                                 }
                             });
                         }
@@ -355,8 +354,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
             const int64_t mm = live ? m : p.M - 1;
             float rstd = 1.0f;
             if constexpr (LNIN) rstd = p.ln_in[2 * mm + 1];
-            fin_ptr[g] = p.out + mm * p.N + n0 + 4 * qd;
-            fin_live[g] = live;
+            fin_off[g] = live ? (int)(m * p.N) + n0 + 4 * qd : -1;   // (M N < 2^31 floats: checked by the host)
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * n + 4 * qd);
@@ -386,7 +384,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
     for (int g = 0; g < RG; ++g)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-            if (fin_live[g]) *reinterpret_cast<f32x4*>(fin_ptr[g] + 16 * n) = fin[g][n];
+            if (fin_off[g] >= 0) *reinterpret_cast<f32x4*>(p.out + fin_off[g] + 16 * n) = fin[g][n];
 #ifdef SGEMM_STAMPS
     if (p.stamps && lane == 0) {
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
