@@ -272,21 +272,25 @@ int launch_strip2(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(T::NTHR), T::LDS_BYTES, s, p);
     return check_launch("sgemm2_kernel");
 }
-// which plain layers the strip kernel takes: an M16 image, no training epilogue options, at least four 32-deep chunks (the deferred
+// which plain layers the strip kernel takes: an M16 image, at most one training epilogue option (alone), at least four 32-deep chunks (the deferred
 // stores of a tile go out inside the first four chunks of the next one), a column count one of its tiles divides
 bool strip2_ok(const GemmParams& p) {
-    return p.bf16 == 2 && p.wlayout == 2 && !p.out_act && !p.dact_u && p.K % 32 == 0 && p.K >= 128 && p.M > 0 &&
+    if ((p.out_act || p.dact_u) && (p.ln_in || p.act || (p.out_act && p.dact_u))) return false;   // training options: alone, on a plain product
+    return p.bf16 == 2 && p.wlayout == 2 && p.K % 32 == 0 && p.K >= 128 && p.M > 0 &&
            p.M * (int64_t)p.N < (int64_t)1 << 31 && p.M * (int64_t)p.K < (int64_t)1 << 31 &&   // (32-bit float offsets of its rows)
            (p.N % 128 == 0 || p.N % 112 == 0 || p.N % 96 == 0);
 }
 template <int NB>
 int launch_strip2_flags(const GemmParams& p, hipStream_t s) {
-    const int flags = (p.ln_in ? 1 : 0) | (p.act ? 2 : 0);
+    const int flags = (p.ln_in ? 1 : 0) | (p.act ? 2 : 0) | (p.dact_u ? 4 : 0) | (p.out_act ? 8 : 0);
     switch (flags) {
         case 0: return launch_strip2<NB, 0>(p, s);
         case 1: return launch_strip2<NB, 1>(p, s);
         case 2: return launch_strip2<NB, 2>(p, s);
-        default: return launch_strip2<NB, 3>(p, s);
+        case 3: return launch_strip2<NB, 3>(p, s);
+        case 4: return launch_strip2<NB, 4>(p, s);   // training: dX of fc2
+        case 8: return launch_strip2<NB, 8>(p, s);   // training: fc1 forward
+        default: return fail(PAFUSE_E_ARG, "strip GEMM: epilogue options %d", flags);
     }
 }
 int strip2_bias(const GemmParams& p, hipStream_t s) {

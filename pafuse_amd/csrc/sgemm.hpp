@@ -82,10 +82,13 @@ __device__ __forceinline__ unsigned long long sgemm_stamp() {
 #define SGEMM_PIN_PAIR(P) asm volatile("" : "+v"((P).x0), "+v"((P).x1), "+v"((P).s0), "+v"((P).s1), "+v"((P).s2))
 
 // FLAGS (compile-time, so that the epilogue is straight-line code with every load issued up front): bit 0 = folded LayerNorm
-// (p.ln_in), bit 1 = GELU (p.act)
+// (p.ln_in), bit 1 = GELU (p.act); training's two epilogue options (GemmParams): bit 2 = p.dact_u (out = (acc + bias) * gelu'(dact_u): the
+// dX GEMM of fc2), bit 3 = p.out_act (`out` receives the pre-activation u - stored at the end of the tile -, `out_act` gelu(u) - the
+// deferred stores: fc1 forward)
 template <int NB, int RG, int NW, int EPI, int MINW, int FLAGS>
 __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams p) {
-    constexpr bool LNIN = (FLAGS & 1) != 0, ACT = (FLAGS & 2) != 0;
+    constexpr bool LNIN = (FLAGS & 1) != 0, ACT = (FLAGS & 2) != 0, DACT = (FLAGS & 4) != 0, OUTACT = (FLAGS & 8) != 0;
+    float* const fin_base = OUTACT ? p.out_act : p.out;   // where the deferred stores go
     PAFUSE_XQ_GUARD();
     using T = StripTile<NB, RG, NW, 2>;
     constexpr int BM = T::BM, BN = T::BN, IA = T::IA, IW = T::IW, IWT = T::IWT;
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
                                 constexpr int cs = decltype(C_)::value, si = cs * SPC + i;
                                 if constexpr (si < NSTORE) {
                                     constexpr int sg = si / NB, sn = si % NB;
-                                    if (kc == cs && fin_off[sg] >= 0) *reinterpret_cast<f32x4*>(p.out + fin_off[sg] + 16 * sn) = fin[sg][sn];
+                                    if (kc == cs && fin_off[sg] >= 0) *reinterpret_cast<f32x4*>(fin_base + fin_off[sg] + 16 * sn) = fin[sg][sn];
                                 }
                             });
                         }
@@ -370,6 +373,16 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                 }
+                if constexpr (DACT) {   // the gradient reaches the pre-activation in the same pass
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(p.dact_u + mm * p.N + n0 + 16 * n + 4 * qd);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad(u[e]);
+                }
+                if constexpr (OUTACT) {   // `out` keeps the pre-activation (the backward needs both), `out_act` its GELU
+                    if (live) *reinterpret_cast<f32x4*>(p.out + mm * p.N + n0 + 16 * n + 4 * qd) = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
                 fin[g][n] = v;
                 acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -384,7 +397,7 @@ __global__ void __launch_bounds__(NW * 64, MINW) sgemm2_kernel(const GemmParams 
     for (int g = 0; g < RG; ++g)
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-            if (fin_off[g] >= 0) *reinterpret_cast<f32x4*>(p.out + fin_off[g] + 16 * n) = fin[g][n];
+            if (fin_off[g] >= 0) *reinterpret_cast<f32x4*>(fin_base + fin_off[g] + 16 * n) = fin[g][n];
 #ifdef SGEMM_STAMPS
     if (p.stamps && lane == 0) {
         unsigned long long* o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 8;

@@ -186,13 +186,15 @@ static void compare_rows(const char* tag, int64_t M, int C) {
     for (size_t i = 0; i < sa.size(); ++i) ds = std::max(ds, (double)std::fabs(sa[i] - sb[i]) / std::max(1.0, (double)std::fabs(sa[i])));
     printf("      %s: centred rows max |d| %.3e (max |x| %.3f, elements off by > 1e-3: %zu), statistics max rel d %.3e\n", tag, dx, mx, bad, ds);
 }
-template <int WM, int WN, int NT>
+// ABL (gemm_dma_tile's diagnostic builds, results wrong by design): 2 = no DMA (the compute side alone), 3 = 2 without the split arithmetic
+template <int WM, int WN, int NT, int ABL = 0>
 void run_rowln_ref(const char* shape, GemmParams p) {   // production: gemm_dma_kernel<.., EPI_ROWLN, 2 stages, 2 per CU, 16-deep chunks>
     using T = DmaTile<WM, WN, NT, 16>;
     char tag[160];
-    snprintf(tag, sizeof tag, "%s gemm_dma<%d,%d,%d> %dx%d (production)", shape, WM, WN, NT, T::BM, T::BN);
+    snprintf(tag, sizeof tag, "%s gemm_dma<%d,%d,%d> %dx%d (production%s)", shape, WM, WN, NT, T::BM, T::BN,
+             ABL == 2 ? ", ABL 2: no operand stream" : ABL == 3 ? ", ABL 3: no operand stream, no split" : "");
     constexpr size_t lds = 2 * T::STAGE_BYTES;
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI_ROWLN, 2, 2, 0, 16>;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI_ROWLN, 2, 2, ABL, 16>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (p.M + T::BM - 1) / T::BM;
     int occ = 0;
@@ -292,6 +294,10 @@ int main() {
                 if (C == 256) run_rowln_ref<2, 2, 4>(shape, p);
                 else run_rowln_ref<4, 1, 7>(shape, p);
                 run_rowln_grouped_bits(shape, p, C == 256 ? 64 : 128);
+                if (getenv("SB_ROWLN_ABL")) {   // what the operand stream and the in-register split cost the whole-row tiles
+                    if (C == 256) run_rowln_ref<2, 2, 4, 2>(shape, p), run_rowln_ref<2, 2, 4, 3>(shape, p);
+                    else run_rowln_ref<4, 1, 7, 2>(shape, p), run_rowln_ref<4, 1, 7, 3>(shape, p);
+                }
             }
         }
     }
