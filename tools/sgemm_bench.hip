@@ -187,20 +187,21 @@ static void compare_rows(const char* tag, int64_t M, int C) {
     printf("      %s: centred rows max |d| %.3e (max |x| %.3f, elements off by > 1e-3: %zu), statistics max rel d %.3e\n", tag, dx, mx, bad, ds);
 }
 // ABL (gemm_dma_tile's diagnostic builds, results wrong by design): 2 = no DMA (the compute side alone), 3 = 2 without the split arithmetic
-template <int WM, int WN, int NT, int ABL = 0>
+template <int WM, int WN, int NT, int ABL = 0, int MINW = 2>
 void run_rowln_ref(const char* shape, GemmParams p) {   // production: gemm_dma_kernel<.., EPI_ROWLN, 2 stages, 2 per CU, 16-deep chunks>
     using T = DmaTile<WM, WN, NT, 16>;
     char tag[160];
     snprintf(tag, sizeof tag, "%s gemm_dma<%d,%d,%d> %dx%d (production%s)", shape, WM, WN, NT, T::BM, T::BN,
              ABL == 2 ? ", ABL 2: no operand stream" : ABL == 3 ? ", ABL 3: no operand stream, no split" : "");
     constexpr size_t lds = 2 * T::STAGE_BYTES;
-    auto k = gemm_dma_kernel<WM, WN, NT, EPI_ROWLN, 2, 2, ABL, 16>;
+    auto k = gemm_dma_kernel<WM, WN, NT, EPI_ROWLN, 2, MINW, ABL, 16>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (p.M + T::BM - 1) / T::BM;
     int occ = 0;
     CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, T::NTHR, lds));
-    p.resid = p.out_x = g_xa, p.ln_stats = g_sa;
-    CK(hipMemcpy(g_xa, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
+    float* const xdst = (WM == 3) ? g_xb : g_xa;   // (the 96-row experiment writes the second buffer and is compared with the production result)
+    p.resid = p.out_x = xdst, p.ln_stats = (WM == 3) ? g_sb : g_sa;
+    CK(hipMemcpy(xdst, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, 0, p);   // the compared result: ONE launch on fresh rows
     CK(hipDeviceSynchronize());
     p.resid = p.out_x = g_ref, p.ln_stats = g_sb + 0;   // timing on scratch rows (in place: the values drift, the work does not)
@@ -294,6 +295,10 @@ int main() {
                 if (C == 256) run_rowln_ref<2, 2, 4>(shape, p);
                 else run_rowln_ref<4, 1, 7>(shape, p);
                 run_rowln_grouped_bits(shape, p, C == 256 ? 64 : 128);
+                if (C == 256) {   // 96-row tiles on six waves, two workgroups (twelve waves) per CU: 473 tiles = 0.92 rounds, 26 B per clock of operands
+                    run_rowln_ref<3, 2, 4, 0, 3>(shape, p);
+                    printf("      96-row tile vs production: differing words rows %llu, statistics %llu\n", differing(g_xa, g_xb, p.M * p.N), differing(g_sa, g_sb, p.M * 2));
+                }
                 if (getenv("SB_ROWLN_ABL")) {   // what the operand stream and the in-register split cost the whole-row tiles
                     if (C == 256) run_rowln_ref<2, 2, 4, 2>(shape, p), run_rowln_ref<2, 2, 4, 3>(shape, p);
                     else run_rowln_ref<4, 1, 7, 2>(shape, p), run_rowln_ref<4, 1, 7, 3>(shape, p);
