@@ -336,3 +336,23 @@ def test_evaluation_log_lines_are_the_reference_s():
     assert printed[-1] == written[-1] == "----------" and len(printed) == 2 + 2 * 18 + 1
     p2, w2 = harness.format_report(rep, False)
     assert p2[0] == "----------" and w2[0].startswith("step 0") and p2[1] == "Test time augmentation: False"
+
+
+def test_bench_parity_object_on_known_differences():
+    """bench.py's `parity` object (the HIP default against the oracle on the CPU baseline's sample) computed on
+    tensors with a KNOWN difference: identical runs give zeros and all pairs inside 1e-4 mm; a uniform shift of one hypothesis by
+    1e-6 m moves P-Agg by at most 1e-3 mm / P and shows in max_abs_m; the object names its yardstick and its sizes."""
+    import bench
+    from oracle import d3dp_oracle as orc
+    from pafuse_amd import synthetic as gu
+    g = torch.Generator().manual_seed(3)
+    ref = orc.center_pose_parts(torch.randn(1, 2, 3, 27, 134, 3, generator=g) * 0.25)
+    x2d, _ = gu.synthetic_inputs_2d(B=1)
+    same = bench.parity_object(orc, ref.clone(), ref, gu, x2d, 3, 2)
+    assert same["max_abs_m"] == 0.0 and same["pairs_within_1e-4_mm"] == "8 of 8" and same["j_agg_different_picks"] == 0.0
+    assert all(v == 0.0 for v in same["dMPJPE_mm"].values()) and same["P"] == 3 and same["T"] == 2 and "oracle" in same["vs"]
+    out = ref.clone()
+    out[:, :, 1] += 1e-6
+    moved = bench.parity_object(orc, out, ref, gu, x2d, 3, 2)
+    assert abs(moved["max_abs_m"] - 1e-6) < 2e-7
+    assert 0.0 < moved["dMPJPE_mm"]["P-Agg"] <= 1e-3 / 3 + 1e-9 and set(moved["dMPJPE_mm"]) == {"J-Best", "P-Best", "P-Agg", "J-Agg"}
