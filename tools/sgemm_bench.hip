@@ -172,6 +172,9 @@ void run2(const char* shape, GemmParams p) {
 // ---- whole-row layers (proj, fc2 + residual + LayerNorms): the production LDS-DMA kernel per part (slab epilogue) and in the shared grid
 // (direct epilogue): equal bits.  (The strip kernel's whole-row form that was measured against them in round 6 is
 // profiles/r06_whole_row_strip_experiment.patch; it ties them and is not in the tree.)
+#ifndef PAFUSE_DMA_APIPE   // only defined with profiles/r06_dma_apipe_experiment.patch applied
+#define PAFUSE_DMA_APIPE 0
+#endif
 static float *g_x0 = nullptr, *g_xa = nullptr, *g_xb = nullptr, *g_sa = nullptr, *g_sb = nullptr;
 static void compare_rows(const char* tag, int64_t M, int C) {
     std::vector<float> a((size_t)M * C), b((size_t)M * C), sa((size_t)M * 2), sb((size_t)M * 2);
@@ -204,6 +207,15 @@ void run_rowln_ref(const char* shape, GemmParams p) {   // production: gemm_dma_
     CK(hipMemcpy(xdst, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(T::NTHR), lds, 0, p);   // the compared result: ONE launch on fresh rows
     CK(hipDeviceSynchronize());
+    if (ABL == 0) {   // a digest of the compared result: equal across builds (-DPAFUSE_DMA_APIPE=0 / 1) = equal bits
+        std::vector<uint32_t> hx((size_t)p.M * p.N), hs((size_t)p.M * 2);
+        CK(hipMemcpy(hx.data(), xdst, hx.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hs.data(), (WM == 3) ? g_sb : g_sa, hs.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long h = 1469598103934665603ull;
+        for (uint32_t v : hx) h = (h ^ v) * 1099511628211ull;
+        for (uint32_t v : hs) h = (h ^ v) * 1099511628211ull;
+        printf("      digest of rows + statistics (APIPE %d): %016llx\n", (int)PAFUSE_DMA_APIPE, h);
+    }
     p.resid = p.out_x = g_ref, p.ln_stats = g_sb + 0;   // timing on scratch rows (in place: the values drift, the work does not)
     float* scratch_stats; CK(hipMalloc(&scratch_stats, (size_t)p.M * 8)); p.ln_stats = scratch_stats;
     CK(hipMemcpy(g_ref, g_x0, (size_t)p.M * p.N * 4, hipMemcpyDeviceToDevice));
